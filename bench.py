@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio frames/s (and real-time factor) of the CSM-1B audio-token loop.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one generated 80 ms audio frame for every stream of the batch: one backbone step,
+the c0 head, 31 depth-decoder steps and 32 samplings (reference: Model.generate_frame,
+sesameai/models.py:132-184, driven as in sesameai/generator.py:283-294).  The N=1 workload is
+BASELINE.json configs[1]: CSM-1B, one utterance (B=1), one voice-prompt segment
+(S = 40 text + 125 audio + 1 EOS + 24 text = 190 prompt rows), bf16, seeded
+random weights (no checkpoint can be downloaded), greedy-free sampling T=0.9 / top-k 50.
+Multi-GPU = independent replicas (one process per GPU, weights broadcast once over RCCL, no
+per-step collective): "weak" scaling, value = all ranks' frames / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
+`cpu_baseline` objects.  Inputs are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "sesameai-tts_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synthetic_prompt(args, batch, text_vocab, seed0=2025):
+    """config-2 shape: context segment (40 text + 125 audio + EOS rows) + 24 text rows."""
+    toks, masks = [], []
+    for b in range(batch):
+        g = torch.Generator().manual_seed(seed0 + b)
+        rows = args.ctx_text + args.ctx_frames + 1 + args.gen_text
+        t = torch.zeros(rows, 33, dtype=torch.long)
+        m = torch.zeros(rows, 33, dtype=torch.bool)
+        r = 0
+        t[r:r + args.ctx_text, 32] = torch.randint(0, text_vocab, (args.ctx_text,), generator=g); m[r:r + args.ctx_text, 32] = True
+        r += args.ctx_text
+        t[r:r + args.ctx_frames, :32] = torch.randint(0, 2048, (args.ctx_frames, 32), generator=g); m[r:r + args.ctx_frames + 1, :32] = True
+        r += args.ctx_frames + 1                      # the all-zero EOS frame
+        t[r:r + args.gen_text, 32] = torch.randint(0, text_vocab, (args.gen_text,), generator=g); m[r:r + args.gen_text, 32] = True
+        toks.append(t); masks.append(m)
+    return torch.stack(toks), torch.stack(masks)
+
+
+def cpu_baseline(args, tokens, mask, sample_frames):
+    """The oracle (CPU restatement of the reference's eager `-d cpu` bf16 graph) timed on this
+    host's cores on a bounded sample of the same workload: the S=190 prefill is part of frame 0
+    (as in the reference's first generate_frame call), then sample_frames-1 decode frames."""
+    from oracle import csm_ref as C
+    torch.set_num_threads(os.cpu_count() or 1)
+    shape = C.csm_1b()
+    w = C.make_weights(shape, seed=1234)
+    m = C.OracleModel(shape, w)
+    m.setup_caches(1)
+    g = torch.Generator().manual_seed(0)
+    torch.manual_seed(0)
+    t0 = time.time()
+    frames = C.generate_codes(m, tokens[0], mask[0], sample_frames * 80, 0.9, 50)
+    dt = time.time() - t0
+    n = max(1, len(frames))
+    # decode-loop rate excluding the prefill-carrying first frame, if we have more than one
+    return dict(value=n / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/csm_ref.py (PyTorch-CPU bf16), same S={tokens.shape[1]} prompt, {n} frames incl. prefill, "
+                       f"{dt:.1f}s wall, torch {torch.__version__}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=125)       # 10 s of audio (config 2)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU")
+    ap.add_argument("--ctx-text", type=int, default=40)
+    ap.add_argument("--ctx-frames", type=int, default=125)
+    ap.add_argument("--gen-text", type=int, default=24)
+    ap.add_argument("--temperature", type=float, default=0.9)
+    ap.add_argument("--topk", type=int, default=50)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=12)
+    ap.add_argument("--tiny", action="store_true", help="tiny shapes (plumbing check only; not a valid bench)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from sesameai.models import Model, csm_1b_args, csm_tiny_args, state_dict_layout, synthetic_state_dict
+    margs = csm_tiny_args() if args.tiny else csm_1b_args()
+    B = args.batch
+    # ---- weights: rank 0 seeds them, the others receive one RCCL broadcast over xGMI --------
+    if world > 1:
+        from sesameai.parallel import broadcast_state_dict
+        sd = broadcast_state_dict(margs, synthetic_state_dict(margs, seed=1234) if rank == 0 else None, dev)
+    else:
+        sd = synthetic_state_dict(margs, seed=1234)
+    model = Model(margs, sd, device=str(dev), max_frames=args.steps + args.warmup + 8,
+                  max_prefill_rows=B * (args.ctx_text + args.ctx_frames + 1 + args.gen_text))
+    del sd
+    model.setup_caches(B)
+    model.seed(1234 + rank)
+    tokens, mask = synthetic_prompt(args, B, margs.text_vocab_size, seed0=2025 + rank * B)
+    S = tokens.shape[1]
+    pos = torch.arange(S).unsqueeze(0).repeat(B, 1)
+    tok_d, mask_d, pos_d = tokens.to(dev), mask.to(dev), pos.to(dev)
+    use_graph = not args.no_graph
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- prefill (+ frame 0), timed separately --------------------------------------------
+    sync_all()
+    t0 = time.perf_counter()
+    model.reset_caches()
+    model.prefill(tok_d, mask_d, pos_d)
+    model.depth(B, args.temperature, args.topk, commit=True)
+    torch.cuda.synchronize()
+    prefill_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(args.warmup):
+        model.step(B, args.temperature, args.topk, use_graph)
+    # ---- timed region: exactly K frame steps ---------------------------------------------
+    stream = torch.cuda.current_stream()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync_all()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        model.step(B, args.temperature, args.topk, use_graph)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)          # HIP events on the stream the frame graph runs on
+    if dist is not None:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        dist.barrier()
+    frames, eos = model.read_frames(B)
+    assert frames.shape[0] == 1 + args.warmup + args.steps
+    assert int((frames < 0).sum()) == 0 and int(frames.max()) < margs.audio_vocab_size
+
+    ms_per_step = wall * 1e3 / args.steps
+    value = world * B * args.steps / wall
+    p_mean = S + args.warmup + args.steps / 2.0
+    bytes_frame = model.bytes_per_frame(B, p_mean)
+    t_frame = ev_ms * 1e-3 / args.steps
+    achieved = bytes_frame / t_frame / 1e9
+    out = {
+        "metric": "audio frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic (seeded random weights of CSM-1B shapes, seeded random prompts)",
+        "config": {"workload": ("tiny plumbing check" if args.tiny else
+                                f"CSM-1B single utterance per GPU (B={B}), one voice-prompt segment, S={S} prompt rows, "
+                                f"{args.steps} frames, T={args.temperature} top-k {args.topk}, "
+                                f"{'hipGraph' if use_graph else 'eager'} frame step"),
+                   "batch_per_gpu": B, "prompt_rows": S, "parallelism": f"replicas x{world}"},
+        "rtf": round(value / 12.5, 2), "rtf_per_stream": round(value / 12.5 / (world * B), 2),
+        "prefill_plus_frame0_ms": round(prefill_ms, 2),
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "frame step (1 backbone + 31 depth-decoder steps, unique weights + KV)",
+                     "bytes_per_launch": bytes_frame, "launch_ms": round(t_frame * 1e3, 4),
+                     "streamed_GBps": round((bytes_frame + 30 * 2 * 111.15e6 + 30 * 2 * 2.1e6) / t_frame / 1e9, 1)},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1 and not args.tiny:
+            out["cpu_baseline"] = cpu_baseline(args, tokens, mask, args.cpu_frames)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

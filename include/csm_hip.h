@@ -1,0 +1,142 @@
+/*
+ * libcsm_hip.so -- C ABI of the MI355X-native CSM speech-generation hot path.
+ *
+ * The reference (zenoran/sesameai-tts) has no FFI: its boundary for this path is the Python
+ * surface `Model.generate_frame` / `Model.setup_caches` / `Model.reset_caches`
+ * (sesameai/models.py:120-188) and `mimi.decode` (sesameai/generator.py:299).  This header is
+ * the C ABI the build puts UNDER that surface; each entry point cites the reference
+ * interface it replaces.  The Python shim (sesameai-tts_amd/sesameai/_abi.py) binds exactly
+ * these symbols with ctypes; tests/test_abi.py checks that every one is exported.
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  Every pointer marked
+ * `dev` is a device pointer owned by the caller and must stay valid for the lifetime of the
+ * handle (weights) or of the call (inputs/outputs).  `stream` is a hipStream_t passed as
+ * void*.  All functions return 0 on success or a negative CSM_E_* code; the message is
+ * available from csm_last_error().  A handle is not thread-safe: one handle per GPU
+ * (the reference model is single-threaded too: one KV-cache set, tts_service.py:191).
+ */
+#ifndef CSM_HIP_H
+#define CSM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSM_OK            0
+#define CSM_E_INVALID    -1   /* bad argument / unsupported shape                       */
+#define CSM_E_HIP        -2   /* a HIP runtime call failed                              */
+#define CSM_E_STATE      -3   /* call order violated (e.g. frame step before prefill)   */
+#define CSM_E_TOO_LONG   -4   /* position would exceed max_seq (generator.py:276-281)   */
+
+#define CSM_MAX_LAYERS   32
+
+/* One Llama stack = torchtune llama3_2(...) with tok_embeddings/output stripped
+ * (sesameai/models.py:10-52). */
+typedef struct CsmLlamaDims {
+    int32_t n_layers, n_heads, n_kv_heads, dim, ffn, max_seq;
+    float   norm_eps;
+} CsmLlamaDims;
+
+/* ModelArgs (sesameai/models.py:90-96) + the two flavours. */
+typedef struct CsmConfig {
+    CsmLlamaDims backbone;      /* llama-1B   : 16L 32H/8KV d2048 ffn8192 */
+    CsmLlamaDims decoder;       /* llama-100M :  4L  8H/2KV d1024 ffn8192 */
+    int32_t text_vocab;         /* 128256 */
+    int32_t audio_vocab;        /* 2051   */
+    int32_t n_codebooks;        /* 32     */
+} CsmConfig;
+
+/* bf16 tensors, row-major, nn.Linear layout [out][in]. */
+typedef struct CsmLayerWeights {
+    const void *wq, *wk, *wv, *wo;      /* [H*hd][d] [KV*hd][d] [KV*hd][d] [d][H*hd] */
+    const void *w1, *w2, *w3;           /* gate [ffn][d], down [d][ffn], up [ffn][d] */
+    const void *sa_norm, *mlp_norm;     /* [d] */
+} CsmLayerWeights;
+
+typedef struct CsmWeights {
+    const void *text_emb;               /* [text_vocab][d_bb]                         */
+    const void *audio_emb;              /* [n_codebooks*audio_vocab][d_bb]            */
+    CsmLayerWeights bb[CSM_MAX_LAYERS];
+    const void *bb_norm;                /* [d_bb]                                     */
+    CsmLayerWeights dec[CSM_MAX_LAYERS];
+    const void *dec_norm;               /* [d_dec]                                    */
+    const void *projection;             /* [d_dec][d_bb]                              */
+    const void *c0_head;                /* [audio_vocab][d_bb]                        */
+    const void *audio_head_t;           /* [n_codebooks-1][audio_vocab][d_dec]: the reference's
+                                           K-major audio_head (models.py:118,176) transposed once
+                                           at load time so each logit is a contiguous row      */
+    const void *bb_rope;                /* [max_seq][hd/2][2] bf16 (cos,sin), Llama3ScaledRoPE
+                                           cache after model.to(bf16) (generator.py:343)       */
+    const void *dec_rope;               /* same for the decoder's head_dim                     */
+} CsmWeights;
+
+typedef struct CsmModel* csm_handle;
+
+/* Model(config) + setup_caches(max_batch) (models.py:107-130): allocates KV caches
+ * [L][B][KV][max_seq][hd] (backbone) / [L][B][KV][n_codebooks][hd] (decoder) and workspaces.
+ * max_rows = largest B*S one csm_prefill call will carry.                                   */
+int  csm_create(const CsmConfig* cfg, const CsmWeights* w /*dev ptrs*/, int max_batch, int max_rows,
+                int max_frames, csm_handle* out);
+void csm_destroy(csm_handle h);
+const char* csm_last_error(csm_handle h);   /* h may be NULL: last create() error */
+
+/* Model.reset_caches() (models.py:186-188): rewinds positions and the frame history.  The
+ * caches need no zeroing: attention is bounded by position, never by a 2048-wide mask.     */
+int csm_reset(csm_handle h, void* stream);
+
+/* Seeds the on-device Philox sampler (the reference uses the global torch RNG, models.py:73). */
+int csm_seed(csm_handle h, uint64_t seed, void* stream);
+
+/* The backbone half of Model.generate_frame (models.py:153-160) on B sequences x S rows:
+ * masked embedding sum -> 16 layers with KV append at pos -> final norm of each sequence's
+ * last row (kept in the handle as last_h).  tokens [B][S][33] i32, mask [B][S][33] u8,
+ * pos [B][S] i32, all dev.  After it the internal position of sequence b is pos[b][S-1]+1. */
+int csm_prefill(csm_handle h, const int32_t* tokens, const uint8_t* mask, const int32_t* pos,
+                int B, int S, void* stream);
+
+/* The depth half of Model.generate_frame (models.py:160-184): c0 head + sample, then 31
+ * decoder steps.  Consumes last_h; writes the frame into out_frame [B][32] i32 (dev, may be
+ * NULL) and into the handle's history.  topk==1 selects the deterministic lowest-index argmax.
+ * forced [B][32] i32 (dev, may be NULL): teacher forcing -- fed back instead of the samples.
+ * logits_out (dev, may be NULL): [32][B][audio_vocab] bf16 capture for tests.
+ * noise (dev, may be NULL): [32][B][audio_vocab] bf16 Exp(1) draws replacing the Philox RNG.
+ * commit != 0: append the frame to the history and stage it (or `forced`, if given) as the
+ * input of the next csm_frame_step -- the first generated frame after a prefill.             */
+int csm_depth(csm_handle h, int B, float temperature, int topk, const int32_t* forced,
+              int32_t* out_frame, void* logits_out, const void* noise, int commit, void* stream);
+
+/* One whole generated frame for the continuing loop (generator.py:283-294): the previous
+ * frame (kept on device) is embedded with mask [1 x32, 0] at the internal position, one
+ * backbone step, csm_depth, position += 1, frame appended to the history, EOS flag
+ * (all 32 codes == 0, generator.py:285) accumulated per sequence.  No host sync; the whole
+ * step is captured once into a hipGraph and replayed.                                       */
+int csm_frame_step(csm_handle h, int B, float temperature, int topk, int use_graph, void* stream);
+/* Copies the most recent frame [B][32] i32 to out_frame (dev) on the stream.                 */
+int csm_copy_frame(csm_handle h, int B, int32_t* out_frame, void* stream);
+
+/* Replace the "previous frame" inputs of the next csm_frame_step with caller data
+ * (Model.generate_frame called directly with S==1, tts_service.py:225):
+ * tokens [B][33] i32, mask [B][33] u8, pos [B] i32, dev.                                     */
+int csm_set_step_inputs(csm_handle h, const int32_t* tokens, const uint8_t* mask, const int32_t* pos,
+                        int B, void* stream);
+
+/* History readback: frames [n][B][32] i32 into host memory (synchronises the stream);
+ * eos_at[b] = index of the first all-zero frame of sequence b, or -1.                        */
+int csm_num_frames(csm_handle h);
+int csm_read_frames(csm_handle h, int B, int first, int n, int32_t* host_frames, int32_t* host_eos_at,
+                    void* stream);
+/* Device pointer to the history [max_frames][B_stride=max_batch][32] i32 (for Mimi decode). */
+const int32_t* csm_frames_dev(csm_handle h);
+/* Device pointer to last_h [max_batch][d_bb] bf16 (tests). */
+const void* csm_last_h_dev(csm_handle h);
+
+/* Bytes the dominant kernels stream per generated frame (unique weights + KV at mean
+ * position p_mean); used by bench.py's roofline.                              */
+double csm_bytes_per_frame(csm_handle h, int B, double p_mean);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSM_HIP_H */

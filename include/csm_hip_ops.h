@@ -1,0 +1,41 @@
+/*
+ * Op-level entry points of libcsm_hip.so: thin launchers over the SAME kernels csm_prefill /
+ * csm_depth / csm_frame_step sequence, exported so that the parity tests (tests/test_ops_gpu.py)
+ * can check each hot-path op against the oracle in isolation.  Not part of the drop-in surface.
+ * All pointers are device pointers; bf16 tensors are raw 16-bit words.
+ */
+#ifndef CSM_HIP_OPS_H
+#define CSM_HIP_OPS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* kind: 0 Linear; 1 Linear + residual; 2 RMSNorm + Linear (heads); 3 RMSNorm + fused q/k/v +
+ * interleaved RoPE + KV append; 4 RMSNorm + gate/up + SiLU*up.  K = 512*{1,2,4,16}.
+ * Replaces torchtune's RMSNorm / nn.Linear / Llama3ScaledRoPE / KVCache.update / FeedForward
+ * as called from sesameai/models.py:158,173.                          */
+int csm_op_gemv(int kind, int M, int K, int N, const void* x, long x_row_stride, long x_row_offset,
+                const void* norm_scale, float eps, const void* w0, const void* w1, const void* w2,
+                const void* resid, void* out, long ldo, void* normed_out, long normed_stride, int nt,
+                int head_dim, int nq, int nkv, int kv_heads, int smax, int rows_per_seq, const int32_t* pos,
+                const void* rope, void* kcache, void* vcache, void* stream);
+
+/* GQA attention of M rows over keys [0,pos[m]] of their sequence's cache (SDPA at
+ * sesameai/models.py:154,158,172-173).  part: fp32 scratch [M][H][nsplit][head_dim+4] if nsplit>1. */
+int csm_op_attn(int M, int rows_per_seq, int H, int KV, int head_dim, int smax, int nsplit, const void* q,
+                const void* kcache, const void* vcache, const int32_t* pos, void* out, float* part, void* stream);
+
+/* masked 33-slot embedding sum (sesameai/models.py:155-157,193-203). */
+int csm_op_embed_sum(int M, int ncb, int d, int audio_vocab, int text_vocab, const int32_t* tokens,
+                     const uint8_t* mask, const void* text_emb, const void* audio_emb, void* h, void* stream);
+
+/* sample_topk (sesameai/models.py:72-87): logits [B][ldl] bf16 (ldl = 512*ceil(V/512)),
+ * noise optional [B][V] bf16 Exp(1); writes frame[b*ncb + codebook].                        */
+int csm_op_sample(int B, int V, int ldl, const void* logits, float temperature, int topk, const void* noise,
+                  const uint64_t* rng, int codebook, int ncb, int32_t* frame, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,146 @@
+"""Generates the committed golden vectors under tests/golden/ from the oracle.
+
+TEST INFRASTRUCTURE ONLY.  Run here (CPU, minutes):  python -m oracle.make_golden [--only ...]
+Nothing in this script reads /root/reference; the vectors are functions of the oracle code,
+the seeds below and torch's CPU generator.
+
+Files (all torch.save'd dicts of small tensors):
+  csm1b_frames.pt   CSM-1B shapes, seeded weights (seed 1234), config-1 prompt (16 text tokens):
+                    the oracle's greedy trajectory for N frames, and for every frame/codebook
+                    the top-8 (value, index) of the bf16 logits, teacher-forced on that
+                    trajectory, plus the bf16-vs-fp32 oracle logit gap (the rounding-noise floor
+                    any bf16 implementation lives in).
+  tiny_frames.pt    same for the tiny shapes with a 2-segment prompt, full logits kept.
+  sampler_cases.pt  sample_topk inputs/outputs incl. tie cases and supplied Exp(1) noise.
+  prompt_layout.pt  (tokens, mask) of a 2-segment toy prompt (generator.py:63-109 layout).
+  mimi_*.pt         Mimi decode of a seeded (1,32,10) code block: whole and stateless chunks.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+
+import torch
+
+from . import csm_ref as C
+from . import mimi_ref as M
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def toy_prompt(shape: C.CsmShape, seed: int, n_text: int, ctx_frames: int):
+    g = torch.Generator().manual_seed(seed)
+    segs = []
+    if ctx_frames:
+        ids = torch.randint(0, shape.text_vocab_size, (n_text,), generator=g).tolist()
+        codes = torch.randint(0, 2048, (shape.audio_num_codebooks, ctx_frames), generator=g)
+        segs.append((ids, codes))
+    ids = torch.randint(0, shape.text_vocab_size, (n_text,), generator=g).tolist()
+    segs.append((ids, None))
+    return C.build_prompt(segs)
+
+
+@torch.inference_mode()
+def frames_golden(shape: C.CsmShape, weights, prompt, n_frames: int, keep_full: bool, with_fp32: bool):
+    tok, msk = prompt
+    m = C.OracleModel(shape, weights)
+    m.setup_caches(1)
+    m32 = None
+    if with_fp32:
+        m32 = C.OracleModel(shape, {k: v.float() for k, v in weights.items()}, dtype=torch.float32)
+        m32.setup_caches(1)
+    cur_t, cur_m = tok.unsqueeze(0), msk.unsqueeze(0)
+    pos = torch.arange(tok.size(0)).unsqueeze(0)
+    codes, top_v, top_i, full, gap, margin = [], [], [], [], [], []
+    for f in range(n_frames):
+        t0 = time.time()
+        tr = C.FrameTrace()
+        # greedy frame; the oracle feeds back its own choice == teacher forcing on its trajectory
+        s = m.generate_frame(cur_t, cur_m, pos, 1.0, 1, greedy=True, trace=tr)
+        lg = torch.stack(tr.logits, 0)[:, 0]                     # (32, V) bf16
+        v, i = torch.topk(lg.float(), 8, dim=-1)
+        codes.append(s[0]); top_v.append(v.to(torch.bfloat16)); top_i.append(i.to(torch.int16))
+        margin.append((v[:, 0] - v[:, 1]))
+        if keep_full:
+            full.append(lg)
+        if m32 is not None:
+            tr32 = C.FrameTrace()
+            m32.generate_frame(cur_t, cur_m, pos, 1.0, 1, greedy=True, forced=s, trace=tr32)
+            lg32 = torch.stack(tr32.logits, 0)[:, 0]
+            gap.append((lg.float() - lg32).abs().max(dim=-1)[0])
+        cur_t = torch.cat([s.long(), torch.zeros(1, 1).long()], dim=1).unsqueeze(1)
+        cur_m = torch.cat([torch.ones_like(s).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
+        pos = pos[:, -1:] + 1
+        print(f"  frame {f}: {time.time() - t0:.1f}s  c0..3={s[0, :4].tolist()}", flush=True)
+    out = dict(prompt_tokens=tok, prompt_mask=msk, codes=torch.stack(codes), top_v=torch.stack(top_v),
+               top_i=torch.stack(top_i), margin=torch.stack(margin))
+    if keep_full:
+        out["logits"] = torch.stack(full)
+    if gap:
+        out["bf16_vs_fp32_gap"] = torch.stack(gap)
+    return out
+
+
+def sampler_cases():
+    g = torch.Generator().manual_seed(77)
+    V = 2051
+    logits = (torch.randn(48, V, generator=g) * 3).to(torch.bfloat16)
+    logits[3, 100:160] = logits[3].max()                       # a 60-way tie at the top
+    logits[4, :] = 0.5                                         # all equal
+    logits[5, 7] = 40.0                                        # one dominant logit
+    kth = torch.topk(logits[6].float(), 50)[0][-1]
+    logits[6, 2000:2010] = kth.to(torch.bfloat16)              # ties exactly at the kth value
+    cases = []
+    for (T, k) in ((0.9, 50), (0.7, 30), (1.0, 2051), (0.8, 1), (1.3, 5)):
+        q = torch.empty(48, V, dtype=torch.bfloat16).exponential_(1, generator=g)
+        out = C.sample_topk(logits, k, T, q=q, greedy_lowest_index=(k == 1))
+        cases.append(dict(temperature=T, topk=k, noise=q, out=out[:, 0].clone()))
+    return dict(logits=logits, cases=cases)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--frames", type=int, default=12)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    want = lambda n: (not a.only) or (n in a.only.split(","))
+
+    if want("prompt"):
+        shape = C.csm_tiny()
+        tok, msk = toy_prompt(shape, 5, 4, 3)
+        torch.save(dict(tokens=tok, mask=msk, seed=5, n_text=4, ctx_frames=3), os.path.join(OUT, "prompt_layout.pt"))
+    if want("sampler"):
+        torch.save(sampler_cases(), os.path.join(OUT, "sampler_cases.pt"))
+    if want("tiny"):
+        shape = C.csm_tiny()
+        w = C.make_weights(shape, seed=1234)
+        gold = frames_golden(shape, w, toy_prompt(shape, 11, 6, 5), 6, keep_full=True, with_fp32=True)
+        gold.update(weight_seed=1234, prompt_seed=11)
+        torch.save(gold, os.path.join(OUT, "tiny_frames.pt"))
+    if want("mimi"):
+        for name, s in (("tiny", M.mimi_tiny()), ("full", M.mimi_full())):
+            w = M.make_weights(s, seed=4321)
+            codes = torch.randint(0, s.codebook_size, (1, 32, 10 if name == "full" else 23),
+                                  generator=torch.Generator().manual_seed(9))
+            whole = M.decode(s, w, codes)
+            chunks = M.decode_stateless_chunks(s, w, codes, 10)
+            # keep every 16th sample of the full-size clip + exact head/tail windows (small file)
+            torch.save(dict(codes=codes, weight_seed=4321, pcm=whole if name == "tiny" else None,
+                            pcm_stride16=whole[..., ::16].clone(), pcm_head=whole[..., :4096].clone(),
+                            pcm_tail=whole[..., -4096:].clone(),
+                            chunks_stride16=chunks[..., ::16].clone(),
+                            rms=whole.pow(2).mean().sqrt()), os.path.join(OUT, f"mimi_{name}.pt"))
+    if want("csm1b"):
+        shape = C.csm_1b()
+        t0 = time.time()
+        w = C.make_weights(shape, seed=1234)
+        print(f"weights: {time.time() - t0:.0f}s", flush=True)
+        gold = frames_golden(shape, w, toy_prompt(shape, 2025, 16, 0), a.frames, keep_full=False, with_fp32=True)
+        gold.update(weight_seed=1234, prompt_seed=2025)
+        torch.save(gold, os.path.join(OUT, "csm1b_frames.pt"))
+
+
+if __name__ == "__main__":
+    main()

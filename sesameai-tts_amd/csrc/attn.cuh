@@ -1,0 +1,115 @@
+// KV-cached GQA attention for token rows with per-row absolute positions (decode and
+// chunked prefill): softmax(q k^T / sqrt(hd)) v over keys [0, pos] of the row's sequence.
+//
+// Replaces torchtune's SDPA over the full 2048-slot cache with a boolean mask row
+// (sesameai/models.py:154,172): attention is bounded by position, so
+// only (pos+1) keys of the 8 (resp. 2) real KV heads are read.
+//
+// grid = (M rows, KV heads, nsplit key ranges); block = 4 waves = the 4 query heads of the GQA
+// group, so a K/V tile fetched by one wave is an L1/L2 hit for its three siblings.  Inside a
+// wave a key row (hd bf16) is spread over hd/8 lanes with 16-byte loads (8 resp. 4 keys per
+// wave-instruction); the q.k dot is finished with 3-4 xor-shuffles, each key slot keeps its
+// own online-softmax state and the slots are merged by shuffles at the end.
+#pragma once
+#include "common.cuh"
+
+struct AttnArgs {
+    const bf16_t* q;        // [M][H*HD]
+    const bf16_t* kcache;   // [B][KV][smax][HD]
+    const bf16_t* vcache;
+    const int* pos;         // [M]
+    int M, rows_per_seq, H, KV, smax, nsplit;
+    float scale;
+    bf16_t* out;            // [M][H*HD]                 (nsplit == 1)
+    float* part;            // [M][H][nsplit][HD + 4]    (nsplit  > 1): o[HD], m, l
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
+    constexpr int LPK = HD / 8;          // lanes per key
+    constexpr int KPI = 64 / LPK;        // keys per wave-iteration
+    const int m = blockIdx.x, kvh = blockIdx.y, sp = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int G = a.H / a.KV;
+    const int slot = lane / LPK, e = lane % LPK;
+    const int p = min(max(a.pos[m], 0), a.smax - 1);
+    const int b = m / a.rows_per_seq;
+    const int nkeys = p + 1;
+    const int chunk = (nkeys + a.nsplit - 1) / a.nsplit;
+    const int j0 = sp * chunk, j1 = min(nkeys, j0 + chunk);
+    const bf16_t* kb = a.kcache + ((long)b * a.KV + kvh) * a.smax * HD;
+    const bf16_t* vb = a.vcache + ((long)b * a.KV + kvh) * a.smax * HD;
+
+    for (int g = wave; g < G; g += 4) {
+        const int h = kvh * G + g;
+        const uint4 qv = *reinterpret_cast<const uint4*>(a.q + ((long)m * a.H + h) * HD + e * 8);
+        float mx = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+
+        for (int j = j0 + slot; j < j1; j += KPI) {
+            const uint4 kv = *reinterpret_cast<const uint4*>(kb + (long)j * HD + e * 8);
+            const uint4 vv = *reinterpret_cast<const uint4*>(vb + (long)j * HD + e * 8);
+            float s = dot8(qv, kv, 0.f);
+#pragma unroll
+            for (int off = 1; off < LPK; off <<= 1) s += __shfl_xor(s, off, WAVE);
+            s *= a.scale;
+            const float mn = fmaxf(mx, s);
+            const float corr = __expf(mx - mn);          // mx = -inf on the first key -> 0
+            const float pw = __expf(s - mn);
+            l = l * corr + pw;
+            o[0] = o[0] * corr + pw * lo2f(vv.x); o[1] = o[1] * corr + pw * hi2f(vv.x);
+            o[2] = o[2] * corr + pw * lo2f(vv.y); o[3] = o[3] * corr + pw * hi2f(vv.y);
+            o[4] = o[4] * corr + pw * lo2f(vv.z); o[5] = o[5] * corr + pw * hi2f(vv.z);
+            o[6] = o[6] * corr + pw * lo2f(vv.w); o[7] = o[7] * corr + pw * hi2f(vv.w);
+            mx = mn;
+        }
+        // merge the KPI key slots (lanes that share e)
+#pragma unroll
+        for (int off = LPK; off < 64; off <<= 1) {
+            const float mo = __shfl_xor(mx, off, WAVE);
+            const float lo = __shfl_xor(l, off, WAVE);
+            const float mn = fmaxf(mx, mo);
+            const float c0 = (mx == -INFINITY) ? 0.f : __expf(mx - mn);
+            const float c1 = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+            l = l * c0 + lo * c1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float oo = __shfl_xor(o[i], off, WAVE);
+                o[i] = o[i] * c0 + oo * c1;
+            }
+            mx = mn;
+        }
+        if (slot == 0) {
+            if (a.nsplit == 1) {
+                const float inv = 1.0f / l;
+                uint4 r;
+                r.x = pack_bf(o[0] * inv, o[1] * inv); r.y = pack_bf(o[2] * inv, o[3] * inv);
+                r.z = pack_bf(o[4] * inv, o[5] * inv); r.w = pack_bf(o[6] * inv, o[7] * inv);
+                *reinterpret_cast<uint4*>(a.out + ((long)m * a.H + h) * HD + e * 8) = r;
+            } else {
+                float* dst = a.part + (((long)m * a.H + h) * a.nsplit + sp) * (HD + 4);
+                *reinterpret_cast<float4*>(dst + e * 8) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(dst + e * 8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                if (e == 0) { dst[HD] = mx; dst[HD + 1] = l; }
+            }
+        }
+    }
+}
+
+// merges the nsplit partial softmax states of one (row, head): grid (M, H), block HD threads
+template <int HD>
+__global__ void k_attn_combine(const float* part, int nsplit, bf16_t* out, int H) {
+    const int m = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
+    const float* src = part + ((long)m * H + h) * nsplit * (HD + 4);
+    float mx = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, src[s * (HD + 4) + HD]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float ms = src[s * (HD + 4) + HD];
+        const float w = (ms == -INFINITY) ? 0.f : __expf(ms - mx);
+        num += w * src[s * (HD + 4) + t];
+        den += w * src[s * (HD + 4) + HD + 1];
+    }
+    out[((long)m * H + h) * HD + t] = f2bf(num / den);
+}

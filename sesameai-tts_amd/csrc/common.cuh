@@ -1,0 +1,73 @@
+// Shared device helpers for the gfx950 kernels (wave64, bf16 storage, fp32 math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;                                       // raw bf16 bits
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+#define WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+// round-to-nearest-even, NaN-preserving (hipcc emits v_cvt_pk_bf16_f32 for the cast)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
+
+// low / high bf16 of a packed dword as fp32
+__device__ __forceinline__ float lo2f(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi2f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// acc += a.lo*b.lo + a.hi*b.hi  (v_dot2c_f32_bf16: products of bf16 are exact in fp32)
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
+}
+__device__ __forceinline__ float dot8(const uint4& a, const uint4& b, float acc) {
+    acc = dot2(a.x, b.x, acc);
+    acc = dot2(a.y, b.y, acc);
+    acc = dot2(a.z, b.z, acc);
+    acc = dot2(a.w, b.w, acc);
+    return acc;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+// streamed-once weight load: non-temporal keeps the 1.9 GB backbone stream from evicting
+// the depth decoder's 222 MB out of the 256 MB Infinity Cache.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 ldg16(const uint4* p) {
+    if (NT) {
+        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+
+// Philox4x32-10 counter RNG (one call = 4 x 32 random bits)
+__device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+        uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += W0; key.y += W1;
+    }
+    return ctr;
+}

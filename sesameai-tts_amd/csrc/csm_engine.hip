@@ -1,0 +1,532 @@
+// Host side of libcsm_hip.so: owns the KV caches / workspaces, sequences the gfx950 kernels
+// for prefill, the depth decoder and the whole frame step, captures the frame step into a
+// hipGraph, and exports the C ABI declared in include/csm_hip.h.
+//
+// Reference being replaced: Model.generate_frame / setup_caches / reset_caches
+// (sesameai/models.py:120-188) and the frame loop of Generator.generate
+// (sesameai/generator.py:283-294).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/csm_hip.h"
+#include "../../include/csm_hip_ops.h"
+#include "attn.cuh"
+#include "gemv.cuh"
+#include "sampler.cuh"
+
+#define BB_NSPLIT_MAX 8
+#define PART_ROWS 32
+
+static thread_local std::string g_create_err;
+
+struct Stack {
+    CsmLlamaDims d;
+    const CsmLayerWeights* lw;
+    const bf16_t* final_norm;
+    const bf16_t* rope;
+    int hd, nq, nkv, cache_len;
+    bf16_t *kc, *vc;            // [L][B][KV][cache_len][hd]
+    long layer_stride;          // elements per layer
+    int nt;                     // stream weights non-temporally
+};
+
+struct CsmModel {
+    CsmConfig cfg;
+    CsmWeights w;
+    int max_batch, max_rows, max_frames, ldl;
+    Stack bb, dec;
+    // workspaces (bf16 unless noted)
+    bf16_t *h, *q, *att, *act;          // backbone rows [max_rows][..]
+    float* part;                        // [PART_ROWS][H][NSPLIT][hd+2]
+    bf16_t *dec_in;                     // [B][2][d_bb]   row0 = last_h, row1 = c0 embedding
+    bf16_t *dec_in1;                    // [B][d_bb]      embedding of c_{i-1}, i >= 2
+    bf16_t *hdec, *qd, *attd, *actd;    // decoder rows [2B][..]
+    bf16_t* logits;                     // [B][ldl]
+    int *frame, *cur_tokens, *cur_pos, *history, *n_frames, *eos_at, *dec_pos;
+    uint8_t* cur_mask;
+    uint64_t* rng;
+    int *pf_tokens, *pf_pos;            // staging for csm_prefill inputs is the caller's memory
+    int host_frames;                    // frames launched since reset (host mirror)
+    bool have_last;                     // prefill or a frame step has produced h for csm_depth
+    int last_S;                         // rows per sequence of the h buffer feeding csm_depth
+    int host_pos_max;                   // host mirror of max position (overflow guard)
+    // graph
+    hipGraphExec_t gexec; hipGraph_t graph;
+    int g_B, g_topk; float g_temp; hipStream_t g_stream;
+    std::string err;
+};
+
+#define HIPCHK(h, x)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (x);                                                                 \
+        if (e_ != hipSuccess) {                                                              \
+            char buf_[256];                                                                  \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            if (h) (h)->err = buf_; else g_create_err = buf_;                                \
+            return CSM_E_HIP;                                                                \
+        }                                                                                    \
+    } while (0)
+
+static int fail(CsmModel* h, int code, const char* msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------
+// GEMV dispatch: (KITERS, MT) are runtime -> template switch
+// ---------------------------------------------------------------------------------------
+template <int KITERS, int R, int PRO, int EPI, int HD>
+static hipError_t launch_gemv_mt(const GemvArgs& a, int units, hipStream_t st) {
+    const int blocks = (units + 3) / 4;
+    int mt = a.M >= 3 ? 4 : (a.M == 2 ? 2 : 1);
+    if (KITERS >= 16 && mt > 2) mt = 2;                     // keep the x tile <= 32 KB of LDS
+    const size_t smem = (size_t)mt * KITERS * 512 * 2 + 64;
+    switch (mt) {
+        case 1: hipLaunchKernelGGL((k_gemv<1, KITERS, R, PRO, EPI, HD>), dim3(blocks), dim3(256), smem, st, a); break;
+        case 2: hipLaunchKernelGGL((k_gemv<2, KITERS, R, PRO, EPI, HD>), dim3(blocks), dim3(256), smem, st, a); break;
+        default: hipLaunchKernelGGL((k_gemv<4, KITERS, R, PRO, EPI, HD>), dim3(blocks), dim3(256), smem, st, a); break;
+    }
+    return hipGetLastError();
+}
+
+// kind: 0 = plain store, 1 = plain + residual, 2 = norm + store (head), 3 = norm + qkv/rope, 4 = norm + swiglu
+static hipError_t launch_gemv(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
+    if (K % 512 != 0) return hipErrorInvalidValue;
+    const int ki = K / 512;
+#define GEMV_CASE(KI, RS, RG)                                                                                   \
+    case KI:                                                                                                    \
+        switch (kind) {                                                                                         \
+            case 0: return launch_gemv_mt<KI, RS, PRO_PLAIN, EPI_STORE, 64>(a, (a.N + RS - 1) / RS, st);        \
+            case 1: return launch_gemv_mt<KI, RS, PRO_PLAIN, EPI_RESID, 64>(a, (a.N + RS - 1) / RS, st);        \
+            case 2: return launch_gemv_mt<KI, RS, PRO_NORM, EPI_STORE, 64>(a, (a.N + RS - 1) / RS, st);         \
+            case 3: return hd == 64 ? launch_gemv_mt<KI, 2, PRO_NORM, EPI_QKV_ROPE, 64>(a, (a.N + 1) / 2, st)   \
+                                    : launch_gemv_mt<KI, 2, PRO_NORM, EPI_QKV_ROPE, 128>(a, (a.N + 1) / 2, st); \
+            case 4: return launch_gemv_mt<KI, RG, PRO_NORM, EPI_SWIGLU, 64>(a, (a.N + RG / 2 - 1) / (RG / 2), st); \
+        }                                                                                                       \
+        return hipErrorInvalidValue;
+    switch (ki) {
+        GEMV_CASE(1, 4, 4)
+        GEMV_CASE(2, 2, 4)
+        GEMV_CASE(4, 2, 2)
+        GEMV_CASE(16, 1, 2)
+    }
+#undef GEMV_CASE
+    return hipErrorInvalidValue;
+}
+
+static hipError_t launch_attn(int hd, const AttnArgs& a, hipStream_t st) {
+    dim3 grid(a.M, a.KV, a.nsplit);
+    if (hd == 64) hipLaunchKernelGGL((k_attn<64>), grid, dim3(256), 0, st, a);
+    else if (hd == 128) hipLaunchKernelGGL((k_attn<128>), grid, dim3(256), 0, st, a);
+    else return hipErrorInvalidValue;
+    if (a.nsplit > 1) {
+        if (hd == 64) hipLaunchKernelGGL((k_attn_combine<64>), dim3(a.M, a.H), dim3(64), 0, st, a.part, a.nsplit, a.out, a.H);
+        else hipLaunchKernelGGL((k_attn_combine<128>), dim3(a.M, a.H), dim3(128), 0, st, a.part, a.nsplit, a.out, a.H);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// one Llama stack over M token rows (in place on h)
+// ---------------------------------------------------------------------------------------
+static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t* att, bf16_t* act,
+                            int M, int rows_per_seq, const int* pos, hipStream_t st) {
+    const int d = S.d.dim;
+    int nsplit = 1;
+    if (&S == &m->bb && M <= PART_ROWS) {
+        nsplit = 256 / (M * S.d.n_kv_heads);
+        nsplit = nsplit < 1 ? 1 : (nsplit > BB_NSPLIT_MAX ? BB_NSPLIT_MAX : nsplit);
+    }
+    hipError_t e;
+    for (int l = 0; l < S.d.n_layers; ++l) {
+        const CsmLayerWeights& w = S.lw[l];
+        bf16_t* kc = S.kc + (long)l * S.layer_stride;
+        bf16_t* vc = S.vc + (long)l * S.layer_stride;
+        GemvArgs a;
+        memset(&a, 0, sizeof a);
+        a.nt = S.nt;
+        // (1) RMSNorm -> q/k/v projections -> RoPE -> KV append
+        a.x = h; a.x_row_stride = d; a.M = M;
+        a.norm_scale = (const bf16_t*)w.sa_norm; a.eps = S.d.norm_eps;
+        a.w0 = (const bf16_t*)w.wq; a.w1 = (const bf16_t*)w.wk; a.w2 = (const bf16_t*)w.wv;
+        a.N = S.nq + 2 * S.nkv; a.out = q; a.ldo = S.nq;
+        a.nq = S.nq; a.nkv = S.nkv; a.smax = S.cache_len; a.rows_per_seq = rows_per_seq; a.kv_heads = S.d.n_kv_heads;
+        a.pos = pos; a.rope = S.rope; a.kcache = kc; a.vcache = vc;
+        if ((e = launch_gemv(3, d, S.hd, a, st)) != hipSuccess) return e;
+        // (2) attention over keys [0, pos]
+        AttnArgs t;
+        t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
+        t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = nsplit;
+        t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
+        if ((e = launch_attn(S.hd, t, st)) != hipSuccess) return e;
+        // (3) output projection + residual
+        memset(&a, 0, sizeof a);
+        a.nt = S.nt;
+        a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)w.wo; a.N = d;
+        a.out = h; a.ldo = d; a.resid = h;
+        if ((e = launch_gemv(1, S.nq, S.hd, a, st)) != hipSuccess) return e;
+        // (4) RMSNorm -> gate/up -> SiLU*up
+        memset(&a, 0, sizeof a);
+        a.nt = S.nt;
+        a.x = h; a.x_row_stride = d; a.M = M; a.norm_scale = (const bf16_t*)w.mlp_norm; a.eps = S.d.norm_eps;
+        a.w0 = (const bf16_t*)w.w1; a.w1 = (const bf16_t*)w.w3; a.N = S.d.ffn; a.out = act; a.ldo = S.d.ffn;
+        if ((e = launch_gemv(4, d, S.hd, a, st)) != hipSuccess) return e;
+        // (5) down projection + residual
+        memset(&a, 0, sizeof a);
+        a.nt = S.nt;
+        a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)w.w2; a.N = d;
+        a.out = h; a.ldo = d; a.resid = h;
+        if ((e = launch_gemv(1, S.d.ffn, S.hd, a, st)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+static hipError_t launch_embed(CsmModel* m, const int* tokens, const uint8_t* mask, int M, hipStream_t st) {
+    hipLaunchKernelGGL(k_embed_sum, dim3(M), dim3(256), 0, st, tokens, mask, (const bf16_t*)m->w.text_emb,
+                       (const bf16_t*)m->w.audio_emb, m->cfg.audio_vocab, m->cfg.text_vocab, m->cfg.n_codebooks,
+                       m->cfg.backbone.dim, m->h);
+    return hipGetLastError();
+}
+
+// c0 head + 31 depth-decoder steps (models.py:160-184); h rows = [B][S][d_bb], last row used
+static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int topk, const int* forced,
+                            void* logits_out, const void* noise, hipStream_t st) {
+    const CsmConfig& c = m->cfg;
+    const int dbb = c.backbone.dim, dd = c.decoder.dim, V = c.audio_vocab, ncb = c.n_codebooks;
+    hipError_t e;
+    for (int cb = 0; cb < ncb; ++cb) {
+        GemvArgs a;
+        if (cb >= 1) {
+            // projection of [last_h, emb(c0)] (cb == 1, two rows per sequence) or emb(c_{cb-1})
+            const int rows = cb == 1 ? 2 * B : B;
+            memset(&a, 0, sizeof a);
+            a.x = cb == 1 ? m->dec_in : m->dec_in1; a.x_row_stride = dbb; a.M = rows;
+            a.w0 = (const bf16_t*)m->w.projection; a.N = dd; a.out = m->hdec; a.ldo = dd; a.nt = 0;
+            if ((e = launch_gemv(0, dbb, 0, a, st)) != hipSuccess) return e;
+            const int* pos = m->dec_pos + (long)(cb == 1 ? 0 : cb) * 2 * m->max_batch;
+            if ((e = run_stack(m, m->dec, m->hdec, m->qd, m->attd, m->actd, rows, cb == 1 ? 2 : 1, pos, st)) != hipSuccess) return e;
+        }
+        // final RMSNorm + head -> logits (bf16, padded rows)
+        memset(&a, 0, sizeof a);
+        if (cb == 0) {
+            a.x = m->h; a.x_row_stride = (long)S * dbb; a.x_row_offset = (long)(S - 1) * dbb;
+            a.norm_scale = (const bf16_t*)m->w.bb_norm; a.eps = c.backbone.norm_eps;
+            a.normed_out = m->dec_in; a.normed_stride = 2L * dbb;
+            a.w0 = (const bf16_t*)m->w.c0_head; a.nt = 1;
+        } else {
+            const int rps = cb == 1 ? 2 : 1;
+            a.x = m->hdec; a.x_row_stride = (long)rps * dd; a.x_row_offset = (long)(rps - 1) * dd;
+            a.norm_scale = (const bf16_t*)m->w.dec_norm; a.eps = c.decoder.norm_eps;
+            a.w0 = (const bf16_t*)m->w.audio_head_t + (long)(cb - 1) * V * dd; a.nt = 1;
+        }
+        a.M = B; a.N = V; a.out = m->logits; a.ldo = m->ldl;
+        if ((e = launch_gemv(2, cb == 0 ? dbb : dd, 0, a, st)) != hipSuccess) return e;
+        if (logits_out) {
+            e = hipMemcpy2DAsync((char*)logits_out + (size_t)cb * B * V * 2, (size_t)V * 2, m->logits, (size_t)m->ldl * 2,
+                                 (size_t)V * 2, B, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return e;
+        }
+        SampleArgs s;
+        memset(&s, 0, sizeof s);
+        s.logits = m->logits; s.ldl = m->ldl; s.V = V; s.temperature = temperature; s.topk = topk;
+        s.noise = noise ? (const bf16_t*)noise + (size_t)cb * B * V : nullptr;
+        s.rng = m->rng; s.codebook = cb; s.forced = forced; s.ncb = ncb; s.frame = m->frame;
+        s.audio_emb = (const bf16_t*)m->w.audio_emb; s.audio_vocab = V; s.d = dbb;
+        if (cb == 0) { s.emb_out = m->dec_in + dbb; s.emb_stride = 2L * dbb; }
+        else if (cb < ncb - 1) { s.emb_out = m->dec_in1; s.emb_stride = dbb; }
+        if ((e = launch_sample(s, B, st)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+static hipError_t launch_advance(CsmModel* m, int B, const int* fed, int pos_inc, hipStream_t st) {
+    AdvanceArgs a;
+    a.frame = m->frame; a.B = B; a.ncb = m->cfg.n_codebooks; a.bstride = m->max_batch; a.history = m->history;
+    a.n_frames = m->n_frames; a.max_frames = m->max_frames; a.eos_at = m->eos_at; a.cur_tokens = m->cur_tokens;
+    a.cur_mask = m->cur_mask; a.cur_pos = m->cur_pos; a.rng = m->rng; a.out_frame = nullptr; a.fed = fed; a.pos_inc = pos_inc;
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+__global__ void k_set_prefill_state(const int* pos, int B, int S, int* cur_pos) {
+    for (int b = threadIdx.x; b < B; b += blockDim.x) cur_pos[b] = pos[(long)b * S + S - 1] + 1;
+}
+__global__ void k_fill_i32(int* p, int v, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_copy_step_inputs(const int* tokens, const uint8_t* mask, const int* pos, int n_tok, int B,
+                                   int* cur_tokens, uint8_t* cur_mask, int* cur_pos) {
+    for (int i = threadIdx.x; i < n_tok; i += blockDim.x) { cur_tokens[i] = tokens[i]; cur_mask[i] = mask[i]; }
+    for (int b = threadIdx.x; b < B; b += blockDim.x) cur_pos[b] = pos[b];
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+static void init_stack(Stack& S, const CsmLlamaDims& d, const CsmLayerWeights* lw, const void* norm, const void* rope,
+                       int cache_len, int nt) {
+    S.d = d; S.lw = lw; S.final_norm = (const bf16_t*)norm; S.rope = (const bf16_t*)rope;
+    S.hd = d.dim / d.n_heads; S.nq = d.n_heads * S.hd; S.nkv = d.n_kv_heads * S.hd; S.cache_len = cache_len; S.nt = nt;
+}
+
+extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_batch, int max_rows, int max_frames,
+                          csm_handle* out) {
+    if (!cfg || !w || !out || max_batch < 1 || max_frames < 1) return fail(nullptr, CSM_E_INVALID, "csm_create: null/invalid argument");
+    const CsmLlamaDims* dims[2] = {&cfg->backbone, &cfg->decoder};
+    for (const CsmLlamaDims* d : dims) {
+        if (d->n_layers < 1 || d->n_layers > CSM_MAX_LAYERS || d->dim % 512 || d->ffn % 512 || d->n_heads % d->n_kv_heads)
+            return fail(nullptr, CSM_E_INVALID, "csm_create: dims must satisfy dim%512==0, ffn%512==0, layers<=32");
+        const int hd = d->dim / d->n_heads, ki = d->dim / 512, kf = d->ffn / 512;
+        if (hd != 64 && hd != 128) return fail(nullptr, CSM_E_INVALID, "csm_create: head_dim must be 64 or 128");
+        if ((ki != 1 && ki != 2 && ki != 4 && ki != 16) || (kf != 1 && kf != 2 && kf != 4 && kf != 16))
+            return fail(nullptr, CSM_E_INVALID, "csm_create: dim and ffn must be 512*{1,2,4,16}");
+    }
+    if (cfg->audio_vocab > SAMPLE_MAX_ITERS * 512) return fail(nullptr, CSM_E_INVALID, "csm_create: audio_vocab too large");
+    if (cfg->n_codebooks > cfg->decoder.max_seq) return fail(nullptr, CSM_E_INVALID, "csm_create: n_codebooks > decoder max_seq");
+    CsmModel* m = new CsmModel();
+    m->cfg = *cfg; m->w = *w; m->max_batch = max_batch; m->max_frames = max_frames;
+    if (max_rows < 2 * max_batch) max_rows = 2 * max_batch;
+    m->max_rows = max_rows;
+    m->ldl = ((cfg->audio_vocab + 511) / 512) * 512;
+    m->gexec = nullptr; m->graph = nullptr; m->g_B = -1;
+    m->host_frames = 0; m->have_last = false; m->last_S = 1; m->host_pos_max = 0;
+    init_stack(m->bb, cfg->backbone, m->w.bb, w->bb_norm, w->bb_rope, cfg->backbone.max_seq, 1);
+    init_stack(m->dec, cfg->decoder, m->w.dec, w->dec_norm, w->dec_rope, cfg->n_codebooks, 0);
+    const int ncb = cfg->n_codebooks, dbb = cfg->backbone.dim, dd = cfg->decoder.dim;
+#define ALLOC(ptr, bytes) HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&(ptr), (bytes)))
+    m->bb.layer_stride = (long)max_batch * cfg->backbone.n_kv_heads * m->bb.cache_len * m->bb.hd;
+    m->dec.layer_stride = (long)max_batch * cfg->decoder.n_kv_heads * m->dec.cache_len * m->dec.hd;
+    ALLOC(m->bb.kc, (size_t)m->bb.layer_stride * cfg->backbone.n_layers * 2);
+    ALLOC(m->bb.vc, (size_t)m->bb.layer_stride * cfg->backbone.n_layers * 2);
+    ALLOC(m->dec.kc, (size_t)m->dec.layer_stride * cfg->decoder.n_layers * 2);
+    ALLOC(m->dec.vc, (size_t)m->dec.layer_stride * cfg->decoder.n_layers * 2);
+    ALLOC(m->h, (size_t)max_rows * dbb * 2);
+    ALLOC(m->q, (size_t)max_rows * m->bb.nq * 2);
+    ALLOC(m->att, (size_t)max_rows * m->bb.nq * 2);
+    ALLOC(m->act, (size_t)max_rows * cfg->backbone.ffn * 2);
+    ALLOC(m->part, (size_t)PART_ROWS * cfg->backbone.n_heads * BB_NSPLIT_MAX * (m->bb.hd + 4) * 4);
+    ALLOC(m->dec_in, (size_t)max_batch * 2 * dbb * 2);
+    ALLOC(m->dec_in1, (size_t)max_batch * dbb * 2);
+    ALLOC(m->hdec, (size_t)2 * max_batch * dd * 2);
+    ALLOC(m->qd, (size_t)2 * max_batch * m->dec.nq * 2);
+    ALLOC(m->attd, (size_t)2 * max_batch * m->dec.nq * 2);
+    ALLOC(m->actd, (size_t)2 * max_batch * cfg->decoder.ffn * 2);
+    ALLOC(m->logits, (size_t)max_batch * m->ldl * 2);
+    ALLOC(m->frame, (size_t)max_batch * ncb * 4);
+    ALLOC(m->cur_tokens, (size_t)max_batch * (ncb + 1) * 4);
+    ALLOC(m->cur_mask, (size_t)max_batch * (ncb + 1));
+    ALLOC(m->cur_pos, (size_t)max_batch * 4);
+    ALLOC(m->history, (size_t)max_frames * max_batch * ncb * 4);
+    ALLOC(m->n_frames, 16);
+    ALLOC(m->eos_at, (size_t)max_batch * 4);
+    ALLOC(m->rng, 16);
+    ALLOC(m->dec_pos, (size_t)(ncb + 1) * 2 * max_batch * 4);
+#undef ALLOC
+    // decoder positions: slot 0 = {0,1} pairs (first decoder call), slot k = k (one row per sequence)
+    std::vector<int> dp((size_t)(ncb + 1) * 2 * max_batch);
+    for (int k = 0; k <= ncb; ++k)
+        for (int i = 0; i < 2 * max_batch; ++i) dp[(size_t)k * 2 * max_batch + i] = k == 0 ? (i & 1) : k;
+    HIPCHK((CsmModel*)nullptr, hipMemcpy(m->dec_pos, dp.data(), dp.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK((CsmModel*)nullptr, hipMemset(m->logits, 0, (size_t)max_batch * m->ldl * 2));
+    HIPCHK((CsmModel*)nullptr, hipMemset(m->rng, 0, 16));
+    HIPCHK((CsmModel*)nullptr, hipMemset(m->n_frames, 0, 16));
+    HIPCHK((CsmModel*)nullptr, hipMemset(m->cur_pos, 0, (size_t)max_batch * 4));
+    HIPCHK((CsmModel*)nullptr, hipMemset(m->eos_at, 0xff, (size_t)max_batch * 4));
+    HIPCHK((CsmModel*)nullptr, hipDeviceSynchronize());
+    *out = m;
+    return CSM_OK;
+}
+
+extern "C" void csm_destroy(csm_handle m) {
+    if (!m) return;
+    if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
+    if (m->graph) (void)hipGraphDestroy(m->graph);
+    void* ptrs[] = {m->bb.kc, m->bb.vc, m->dec.kc, m->dec.vc, m->h, m->q, m->att, m->act, m->part, m->dec_in, m->dec_in1,
+                    m->hdec, m->qd, m->attd, m->actd, m->logits, m->frame, m->cur_tokens, m->cur_mask, m->cur_pos,
+                    m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos};
+    for (void* p : ptrs) (void)hipFree(p);
+    delete m;
+}
+
+extern "C" const char* csm_last_error(csm_handle m) { return m ? m->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int csm_reset(csm_handle m, void* stream) {
+    if (!m) return CSM_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(m, hipMemsetAsync(m->n_frames, 0, 4, st));
+    HIPCHK(m, hipMemsetAsync(m->cur_pos, 0, (size_t)m->max_batch * 4, st));
+    HIPCHK(m, hipMemsetAsync(m->eos_at, 0xff, (size_t)m->max_batch * 4, st));
+    m->host_frames = 0; m->have_last = false; m->host_pos_max = 0;
+    return CSM_OK;
+}
+
+extern "C" int csm_seed(csm_handle m, uint64_t seed, void* stream) {
+    if (!m) return CSM_E_INVALID;
+    uint64_t v[2] = {seed, 0};
+    HIPCHK(m, hipMemcpyAsync(m->rng, v, 16, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(m, hipStreamSynchronize((hipStream_t)stream));   // v is a stack temporary
+    return CSM_OK;
+}
+
+extern "C" int csm_prefill(csm_handle m, const int32_t* tokens, const uint8_t* mask, const int32_t* pos, int B, int S,
+                           void* stream) {
+    if (!m || !tokens || !mask || !pos) return fail(m, CSM_E_INVALID, "csm_prefill: null argument");
+    if (B < 1 || B > m->max_batch || S < 1 || (long)B * S > m->max_rows)
+        return fail(m, CSM_E_INVALID, "csm_prefill: B/S outside the limits given to csm_create");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(m, launch_embed(m, tokens, mask, B * S, st));
+    HIPCHK(m, run_stack(m, m->bb, m->h, m->q, m->att, m->act, B * S, S, pos, st));
+    hipLaunchKernelGGL(k_set_prefill_state, dim3(1), dim3(64), 0, st, pos, B, S, m->cur_pos);
+    HIPCHK(m, hipGetLastError());
+    m->have_last = true; m->last_S = S;
+    return CSM_OK;
+}
+
+extern "C" int csm_depth(csm_handle m, int B, float temperature, int topk, const int32_t* forced, int32_t* out_frame,
+                         void* logits_out, const void* noise, int commit, void* stream) {
+    if (!m || B < 1 || B > m->max_batch) return fail(m, CSM_E_INVALID, "csm_depth: bad batch");
+    if (!m->have_last) return fail(m, CSM_E_STATE, "csm_depth: no backbone state (call csm_prefill first)");
+    if (!(temperature > 0.f) || topk < 1) return fail(m, CSM_E_INVALID, "csm_depth: temperature must be > 0 and topk >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(m, run_depth(m, B, m->last_S, temperature, topk, forced, logits_out, noise, st));
+    if (out_frame) HIPCHK(m, hipMemcpyAsync(out_frame, m->frame, (size_t)B * m->cfg.n_codebooks * 4, hipMemcpyDeviceToDevice, st));
+    if (commit) {
+        if (m->host_frames >= m->max_frames) return fail(m, CSM_E_TOO_LONG, "csm_depth: frame history full (max_frames)");
+        HIPCHK(m, launch_advance(m, B, forced, 0, st));
+        m->host_frames += 1;
+    }
+    return CSM_OK;
+}
+
+extern "C" int csm_copy_frame(csm_handle m, int B, int32_t* out_frame, void* stream) {
+    if (!m || !out_frame || B < 1 || B > m->max_batch) return fail(m, CSM_E_INVALID, "csm_copy_frame: bad argument");
+    HIPCHK(m, hipMemcpyAsync(out_frame, m->frame, (size_t)B * m->cfg.n_codebooks * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return CSM_OK;
+}
+
+static hipError_t enqueue_frame(CsmModel* m, int B, float temperature, int topk, hipStream_t st) {
+    hipError_t e;
+    if ((e = launch_embed(m, m->cur_tokens, m->cur_mask, B, st)) != hipSuccess) return e;
+    if ((e = run_stack(m, m->bb, m->h, m->q, m->att, m->act, B, 1, m->cur_pos, st)) != hipSuccess) return e;
+    if ((e = run_depth(m, B, 1, temperature, topk, nullptr, nullptr, nullptr, st)) != hipSuccess) return e;
+    return launch_advance(m, B, nullptr, 1, st);
+}
+
+extern "C" int csm_frame_step(csm_handle m, int B, float temperature, int topk, int use_graph, void* stream) {
+    if (!m || B < 1 || B > m->max_batch) return fail(m, CSM_E_INVALID, "csm_frame_step: bad batch");
+    if (!(temperature > 0.f) || topk < 1) return fail(m, CSM_E_INVALID, "csm_frame_step: temperature must be > 0 and topk >= 1");
+    if (m->host_frames >= m->max_frames) return fail(m, CSM_E_TOO_LONG, "csm_frame_step: frame history full (max_frames)");
+    hipStream_t st = (hipStream_t)stream;
+    if (!use_graph) {
+        HIPCHK(m, enqueue_frame(m, B, temperature, topk, st));
+    } else {
+        if (!m->gexec || m->g_B != B || m->g_topk != topk || m->g_temp != temperature) {
+            if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }
+            if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+            HIPCHK(m, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            hipError_t e = enqueue_frame(m, B, temperature, topk, st);
+            hipError_t e2 = hipStreamEndCapture(st, &m->graph);
+            HIPCHK(m, e);
+            HIPCHK(m, e2);
+            HIPCHK(m, hipGraphInstantiate(&m->gexec, m->graph, nullptr, nullptr, 0));
+            m->g_B = B; m->g_topk = topk; m->g_temp = temperature;
+        }
+        HIPCHK(m, hipGraphLaunch(m->gexec, st));
+    }
+    m->host_frames += 1; m->have_last = true; m->last_S = 1;
+    return CSM_OK;
+}
+
+extern "C" int csm_set_step_inputs(csm_handle m, const int32_t* tokens, const uint8_t* mask, const int32_t* pos, int B,
+                                   void* stream) {
+    if (!m || !tokens || !mask || !pos || B < 1 || B > m->max_batch) return fail(m, CSM_E_INVALID, "csm_set_step_inputs: bad argument");
+    hipLaunchKernelGGL(k_copy_step_inputs, dim3(1), dim3(256), 0, (hipStream_t)stream, tokens, mask, pos,
+                       B * (m->cfg.n_codebooks + 1), B, m->cur_tokens, m->cur_mask, m->cur_pos);
+    HIPCHK(m, hipGetLastError());
+    return CSM_OK;
+}
+
+extern "C" int csm_num_frames(csm_handle m) { return m ? m->host_frames : 0; }
+
+extern "C" int csm_read_frames(csm_handle m, int B, int first, int n, int32_t* host_frames, int32_t* host_eos_at, void* stream) {
+    if (!m || B < 1 || B > m->max_batch || first < 0 || n < 0 || first + n > m->max_frames)
+        return fail(m, CSM_E_INVALID, "csm_read_frames: bad range");
+    hipStream_t st = (hipStream_t)stream;
+    const int ncb = m->cfg.n_codebooks;
+    if (n > 0 && host_frames)
+        HIPCHK(m, hipMemcpy2DAsync(host_frames, (size_t)B * ncb * 4, m->history + (size_t)first * m->max_batch * ncb,
+                                   (size_t)m->max_batch * ncb * 4, (size_t)B * ncb * 4, n, hipMemcpyDeviceToHost, st));
+    if (host_eos_at) HIPCHK(m, hipMemcpyAsync(host_eos_at, m->eos_at, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(m, hipStreamSynchronize(st));
+    return CSM_OK;
+}
+
+extern "C" const int32_t* csm_frames_dev(csm_handle m) { return m ? m->history : nullptr; }
+extern "C" const void* csm_last_h_dev(csm_handle m) { return m ? m->dec_in : nullptr; }
+
+extern "C" double csm_bytes_per_frame(csm_handle m, int B, double p_mean) {
+    if (!m) return 0.0;
+    const CsmConfig& c = m->cfg;
+    auto layer = [](const CsmLlamaDims& d) {
+        const double hd = d.dim / d.n_heads;
+        return 2.0 * (d.dim * (d.n_heads * hd) * 2 + 2.0 * d.dim * (d.n_kv_heads * hd) + 3.0 * d.dim * d.ffn);
+    };
+    double w = c.backbone.n_layers * layer(c.backbone) + c.decoder.n_layers * layer(c.decoder);
+    w += 2.0 * c.audio_vocab * c.backbone.dim;                                   // c0 head
+    w += 2.0 * c.decoder.dim * c.backbone.dim;                                   // projection
+    w += 2.0 * (c.n_codebooks - 1) * (double)c.audio_vocab * c.decoder.dim;      // audio heads
+    const double kv = 2.0 * c.backbone.n_layers * 2.0 * c.backbone.n_kv_heads * (c.backbone.dim / c.backbone.n_heads) * (p_mean + 1);
+    return w + B * kv;
+}
+
+// ---------------------------------------------------------------------------------------
+// op-level test hooks (include/csm_hip_ops.h)
+// ---------------------------------------------------------------------------------------
+extern "C" int csm_op_gemv(int kind, int M, int K, int N, const void* x, long x_row_stride, long x_row_offset,
+                           const void* norm_scale, float eps, const void* w0, const void* w1, const void* w2,
+                           const void* resid, void* out, long ldo, void* normed_out, long normed_stride, int nt,
+                           int head_dim, int nq, int nkv, int kv_heads, int smax, int rows_per_seq, const int32_t* pos,
+                           const void* rope, void* kcache, void* vcache, void* stream) {
+    GemvArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = (const bf16_t*)x; a.x_row_stride = x_row_stride; a.x_row_offset = x_row_offset; a.M = M;
+    a.norm_scale = (const bf16_t*)norm_scale; a.eps = eps; a.normed_out = (bf16_t*)normed_out; a.normed_stride = normed_stride;
+    a.w0 = (const bf16_t*)w0; a.w1 = (const bf16_t*)w1; a.w2 = (const bf16_t*)w2; a.N = N;
+    a.out = (bf16_t*)out; a.ldo = ldo; a.nt = nt; a.resid = (const bf16_t*)resid;
+    a.nq = nq; a.nkv = nkv; a.smax = smax; a.rows_per_seq = rows_per_seq; a.kv_heads = kv_heads; a.pos = pos;
+    a.rope = (const bf16_t*)rope; a.kcache = (bf16_t*)kcache; a.vcache = (bf16_t*)vcache;
+    hipError_t e = launch_gemv(kind, K, head_dim, a, (hipStream_t)stream);
+    if (e != hipSuccess) { g_create_err = std::string("csm_op_gemv: ") + hipGetErrorString(e); return e == hipErrorInvalidValue ? CSM_E_INVALID : CSM_E_HIP; }
+    return CSM_OK;
+}
+
+extern "C" int csm_op_attn(int M, int rows_per_seq, int H, int KV, int head_dim, int smax, int nsplit, const void* q,
+                           const void* kcache, const void* vcache, const int32_t* pos, void* out, float* part, void* stream) {
+    AttnArgs t;
+    t.q = (const bf16_t*)q; t.kcache = (const bf16_t*)kcache; t.vcache = (const bf16_t*)vcache; t.pos = pos; t.M = M;
+    t.rows_per_seq = rows_per_seq; t.H = H; t.KV = KV; t.smax = smax; t.nsplit = nsplit;
+    t.scale = 1.0f / sqrtf((float)head_dim); t.out = (bf16_t*)out; t.part = part;
+    hipError_t e = launch_attn(head_dim, t, (hipStream_t)stream);
+    if (e != hipSuccess) { g_create_err = std::string("csm_op_attn: ") + hipGetErrorString(e); return CSM_E_HIP; }
+    return CSM_OK;
+}
+
+extern "C" int csm_op_embed_sum(int M, int ncb, int d, int audio_vocab, int text_vocab, const int32_t* tokens,
+                                const uint8_t* mask, const void* text_emb, const void* audio_emb, void* h, void* stream) {
+    hipLaunchKernelGGL(k_embed_sum, dim3(M), dim3(256), 0, (hipStream_t)stream, tokens, mask, (const bf16_t*)text_emb,
+                       (const bf16_t*)audio_emb, audio_vocab, text_vocab, ncb, d, (bf16_t*)h);
+    return hipGetLastError() == hipSuccess ? CSM_OK : CSM_E_HIP;
+}
+
+extern "C" int csm_op_sample(int B, int V, int ldl, const void* logits, float temperature, int topk, const void* noise,
+                             const uint64_t* rng, int codebook, int ncb, int32_t* frame, void* stream) {
+    if (V > SAMPLE_MAX_ITERS * 512 || ldl < ((V + 511) / 512) * 512) return CSM_E_INVALID;
+    SampleArgs s;
+    memset(&s, 0, sizeof s);
+    s.logits = (const bf16_t*)logits; s.ldl = ldl; s.V = V; s.temperature = temperature; s.topk = topk;
+    s.noise = (const bf16_t*)noise; s.rng = rng; s.codebook = codebook; s.ncb = ncb; s.frame = frame;
+    return launch_sample(s, B, (hipStream_t)stream) == hipSuccess ? CSM_OK : CSM_E_HIP;
+}

@@ -1,0 +1,304 @@
+// Frame-level glue kernels: masked embedding sum, temperature/top-k sampler (+ embedding of
+// the fed-back code), and the per-frame state advance.
+#pragma once
+#include "common.cuh"
+#include <math.h>
+
+// ---------------------------------------------------------------------------------------
+// h[m] = sum over the 33 slots of mask * embedding  (sesameai/models.py:155-157,193-203):
+// slot cb<32 -> audio_emb[tok + cb*audio_vocab], slot 32 -> text_emb[tok]; fp32 accumulate in
+// slot order, one bf16 rounding.  Masked-out slots are skipped (the reference looks them up
+// and multiplies by 0).  grid = M rows, block = 256, 8 columns per thread.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_embed_sum(const int* tokens /*[M][33]*/, const uint8_t* mask /*[M][33]*/,
+                                                   const bf16_t* text_emb, const bf16_t* audio_emb,
+                                                   int audio_vocab, int text_vocab, int ncb, int d,
+                                                   bf16_t* h /*[M][d]*/) {
+    const int m = blockIdx.x;
+    const int* tk = tokens + (long)m * (ncb + 1);
+    const uint8_t* mk = mask + (long)m * (ncb + 1);
+    for (int c = threadIdx.x; c < d / 8; c += 256) {
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int s = 0; s <= ncb; ++s) {
+            if (!mk[s]) continue;
+            int t = tk[s];
+            const bf16_t* row;
+            if (s < ncb) { t = min(max(t, 0), audio_vocab - 1); row = audio_emb + ((long)s * audio_vocab + t) * d; }
+            else         { t = min(max(t, 0), text_vocab - 1);  row = text_emb + (long)t * d; }
+            const uint4 v = reinterpret_cast<const uint4*>(row)[c];
+            acc[0] += lo2f(v.x); acc[1] += hi2f(v.x); acc[2] += lo2f(v.y); acc[3] += hi2f(v.y);
+            acc[4] += lo2f(v.z); acc[5] += hi2f(v.z); acc[6] += lo2f(v.w); acc[7] += hi2f(v.w);
+        }
+        uint4 o;
+        o.x = pack_bf(acc[0], acc[1]); o.y = pack_bf(acc[2], acc[3]);
+        o.z = pack_bf(acc[4], acc[5]); o.w = pack_bf(acc[6], acc[7]);
+        reinterpret_cast<uint4*>(h + (long)m * d)[c] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// sample_topk (sesameai/models.py:72-87), one wave per sequence, everything in registers:
+//   t = bf16(logit / T); drop t < kth-largest (ties kept); log_softmax; softmax;
+//   argmax(p / Exp(1)) with the first index winning ties.
+// The bf16 rounding points are those of torch-CPU's reduced-precision kernels (verified by
+// probe): the log-softmax keeps its exp-sum and its log in bf16 and subtracts
+// in two bf16 steps; softmax rounds once.  topk == 1 is the deterministic greedy rule
+// (lowest index among maxima).  The kth-largest value is found exactly with a two-pass
+// radix select over the 16-bit order-preserving keys (256-bin LDS histograms).
+// Tail: writes the code into frame[b][cb] and the embedding row of the FED code
+// (forced[b][cb] if teacher forcing) to emb_out -- the next decoder input
+// (models.py:163,178-180).
+// ---------------------------------------------------------------------------------------
+#define SAMPLE_MAX_ITERS 8   // supports V <= 8*512
+
+struct SampleArgs {
+    const bf16_t* logits;     // [B][ldl]
+    int ldl, V;
+    float temperature;
+    int topk;
+    const bf16_t* noise;      // optional [B][V] Exp(1) draws (bf16)
+    const uint64_t* rng;      // device {seed, step}
+    int codebook;
+    const int* forced;        // optional [B][ncb]
+    int ncb;
+    int* frame;               // [B][ncb]
+    const bf16_t* audio_emb;  // [ncb*audio_vocab][d]
+    int audio_vocab, d;
+    bf16_t* emb_out;          // row b at emb_out + b*emb_stride (elements); may be null
+    long emb_stride;
+};
+
+__device__ __forceinline__ uint32_t order_key(float t) {     // monotone map of a bf16-valued float
+    uint32_t u = __float_as_uint(t) >> 16;
+    if (u == 0x8000u) u = 0;                                   // -0 == +0
+    return (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
+}
+
+// find bin (descending) holding the k-th largest; returns bin and rank remaining inside it
+__device__ __forceinline__ void radix_pick(const int* hist, int k, int lane, int& bin, int& krem) {
+    const int c0 = hist[lane * 4 + 0], c1 = hist[lane * 4 + 1], c2 = hist[lane * 4 + 2], c3 = hist[lane * 4 + 3];
+    const int c4 = c0 + c1 + c2 + c3;
+    int suf = c4;                                             // inclusive suffix sum over lanes >= lane
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_down(suf, off, WAVE);
+        if (lane + off < 64) suf += o;
+    }
+    const unsigned long long bal = __ballot(suf >= k);
+    const int L = 63 - __builtin_clzll(bal);                  // suf is non-increasing in lane
+    int b = 0, kr = 0;
+    if (lane == L) {
+        int above = suf - c4;                                 // keys in bins above this lane's 4
+        if (above + c3 >= k) { b = 3; kr = k - above; }
+        else if (above + c3 + c2 >= k) { b = 2; kr = k - above - c3; }
+        else if (above + c3 + c2 + c1 >= k) { b = 1; kr = k - above - c3 - c2; }
+        else { b = 0; kr = k - above - c3 - c2 - c1; }
+        b += 4 * L;
+    }
+    bin = __shfl(b, L, WAVE);
+    krem = __shfl(kr, L, WAVE);
+}
+
+template <int ITERS>
+__global__ __launch_bounds__(64) void k_sample(const SampleArgs a) {
+    __shared__ int hist[256];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    constexpr int iters = ITERS;
+    float t[ITERS][8];
+    const bf16_t* lg = a.logits + (long)b * a.ldl;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        if (i < iters) {
+            const uint4 v = reinterpret_cast<const uint4*>(lg)[i * 64 + lane];
+            t[i][0] = round_bf(lo2f(v.x) / a.temperature); t[i][1] = round_bf(hi2f(v.x) / a.temperature);
+            t[i][2] = round_bf(lo2f(v.y) / a.temperature); t[i][3] = round_bf(hi2f(v.y) / a.temperature);
+            t[i][4] = round_bf(lo2f(v.z) / a.temperature); t[i][5] = round_bf(hi2f(v.z) / a.temperature);
+            t[i][6] = round_bf(lo2f(v.w) / a.temperature); t[i][7] = round_bf(hi2f(v.w) / a.temperature);
+        }
+    }
+    int best_idx = 0x7fffffff;
+    float best = -INFINITY;
+    if (a.topk <= 1) {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+            if (i < iters)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int idx = i * 512 + lane * 8 + j;
+                    if (idx < a.V && t[i][j] > best) { best = t[i][j]; best_idx = idx; }
+                }
+    } else {
+        const int k = min(a.topk, a.V);
+        // ---- exact kth-largest via 2-pass radix select -------------------------------------
+        for (int x = lane; x < 256; x += 64) hist[x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+            if (i < iters)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (i * 512 + lane * 8 + j < a.V) atomicAdd(&hist[order_key(t[i][j]) >> 8], 1);
+        __syncthreads();
+        int b1, k1;
+        radix_pick(hist, k, lane, b1, k1);
+        __syncthreads();
+        for (int x = lane; x < 256; x += 64) hist[x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+            if (i < iters)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (i * 512 + lane * 8 + j < a.V) {
+                        const uint32_t key = order_key(t[i][j]);
+                        if ((int)(key >> 8) == b1) atomicAdd(&hist[key & 255], 1);
+                    }
+        __syncthreads();
+        int b2, k2;
+        radix_pick(hist, k1, lane, b2, k2);
+        const uint32_t kth = ((uint32_t)b1 << 8) | (uint32_t)b2;
+        // ---- log_softmax over the kept entries ---------------------------------------------
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+            if (i < iters)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool keep = (i * 512 + lane * 8 + j < a.V) && order_key(t[i][j]) >= kth;
+                    if (!keep) t[i][j] = -INFINITY;
+                    mx = fmaxf(mx, t[i][j]);
+                }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+            if (i < iters)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (t[i][j] != -INFINITY) sum += expf(t[i][j] - mx);
+        sum = wave_sum(sum);
+        const float logsum = round_bf(logf(round_bf(sum)));
+        float mx2 = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+            if (i < iters)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (t[i][j] != -INFINITY) {
+                        t[i][j] = round_bf(round_bf(t[i][j] - mx) - logsum);
+                        mx2 = fmaxf(mx2, t[i][j]);
+                    }
+        mx2 = wave_max(mx2);
+        // ---- softmax of the log-probs -------------------------------------------------------
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+            if (i < iters)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                {
+                    if (t[i][j] != -INFINITY) { t[i][j] = expf(t[i][j] - mx2); s2 += t[i][j]; }
+                    else { t[i][j] = 0.f; }
+                }
+        s2 = wave_sum(s2);
+        // ---- argmax(p / q), q ~ Exp(1) -------------------------------------------------------
+        const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+            if (i < iters)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int idx = i * 512 + lane * 8 + j;
+                    if (idx >= a.V) continue;
+                    const float p = round_bf(t[i][j] / s2);
+                    float r = 0.f;
+                    if (p > 0.f) {
+                        float q;
+                        if (a.noise) q = bf2f(a.noise[(long)b * a.V + idx]);
+                        else {
+                            const uint4 rnd = philox4x32(make_uint4((uint32_t)idx, (uint32_t)b, (uint32_t)a.codebook, (uint32_t)step),
+                                                         make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32)));
+                            const float u = ((float)rnd.x + 0.5f) * 2.3283064365386963e-10f;   // (0,1]
+                            q = round_bf(-logf(u));
+                            if (!(q > 0.f)) q = 1e-30f;
+                        }
+                        r = round_bf(p / q);
+                    }
+                    if (r > best) { best = r; best_idx = idx; }
+                }
+    }
+    // wave argmax, lowest index on ties
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, WAVE);
+        const int oi = __shfl_xor(best_idx, off, WAVE);
+        if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
+    }
+    if (best_idx == 0x7fffffff) best_idx = 0;
+    if (lane == 0) a.frame[(long)b * a.ncb + a.codebook] = best_idx;
+    if (a.emb_out) {
+        int fed = a.forced ? a.forced[(long)b * a.ncb + a.codebook] : best_idx;
+        fed = min(max(fed, 0), a.audio_vocab - 1);
+        const uint4* src = reinterpret_cast<const uint4*>(a.audio_emb + ((long)a.codebook * a.audio_vocab + fed) * a.d);
+        uint4* dst = reinterpret_cast<uint4*>(a.emb_out + (long)b * a.emb_stride);
+        for (int c = lane; c < a.d / 8; c += 64) dst[c] = src[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// end-of-frame bookkeeping (generator.py:285-294): history append, EOS flag, next-step inputs
+// [frame, 0] with mask [1 x ncb, 0], pos += 1, rng step += 1.   grid = 1, block = 64.
+// ---------------------------------------------------------------------------------------
+struct AdvanceArgs {
+    const int* frame;     // [B][ncb]
+    int B, ncb, bstride;  // history is [max_frames][bstride][ncb]
+    int* history;
+    int* n_frames;        // device counter
+    int max_frames;
+    int* eos_at;          // [B], -1 until the first all-zero frame
+    int* cur_tokens;      // [B][ncb+1]
+    uint8_t* cur_mask;    // [B][ncb+1]
+    int* cur_pos;         // [B]
+    uint64_t* rng;        // {seed, step}
+    int* out_frame;       // optional user copy [B][ncb]
+    const int* fed;       // optional [B][ncb]: codes fed back instead of frame (teacher forcing)
+    int pos_inc;          // 1 after a backbone step consumed cur_pos, 0 after a prefill
+};
+
+__global__ void k_advance(const AdvanceArgs a) {
+    const int n = *a.n_frames;
+    for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
+        bool allzero = true;
+        for (int c = 0; c < a.ncb; ++c) {
+            const int v = a.frame[b * a.ncb + c];
+            allzero &= (v == 0);
+            if (n < a.max_frames) a.history[((long)n * a.bstride + b) * a.ncb + c] = v;
+            a.cur_tokens[b * (a.ncb + 1) + c] = a.fed ? a.fed[b * a.ncb + c] : v;
+            a.cur_mask[b * (a.ncb + 1) + c] = 1;
+            if (a.out_frame) a.out_frame[b * a.ncb + c] = v;
+        }
+        a.cur_tokens[b * (a.ncb + 1) + a.ncb] = 0;
+        a.cur_mask[b * (a.ncb + 1) + a.ncb] = 0;
+        if (allzero && a.eos_at[b] < 0) a.eos_at[b] = n;
+        a.cur_pos[b] += a.pos_inc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { *a.n_frames = n + 1; a.rng[1] += 1; }
+}
+
+static inline hipError_t launch_sample(const SampleArgs& s, int B, hipStream_t st) {
+    switch ((s.V + 511) / 512) {
+        case 1: hipLaunchKernelGGL(k_sample<1>, dim3(B), dim3(64), 0, st, s); break;
+        case 2: hipLaunchKernelGGL(k_sample<2>, dim3(B), dim3(64), 0, st, s); break;
+        case 3: hipLaunchKernelGGL(k_sample<3>, dim3(B), dim3(64), 0, st, s); break;
+        case 4: hipLaunchKernelGGL(k_sample<4>, dim3(B), dim3(64), 0, st, s); break;
+        case 5: hipLaunchKernelGGL(k_sample<5>, dim3(B), dim3(64), 0, st, s); break;
+        case 6: hipLaunchKernelGGL(k_sample<6>, dim3(B), dim3(64), 0, st, s); break;
+        case 7: hipLaunchKernelGGL(k_sample<7>, dim3(B), dim3(64), 0, st, s); break;
+        case 8: hipLaunchKernelGGL(k_sample<8>, dim3(B), dim3(64), 0, st, s); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

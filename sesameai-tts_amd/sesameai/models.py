@@ -1,0 +1,321 @@
+"""MI355X-native ``Model`` with the reference's surface (reference: sesameai/models.py).
+
+Same names and call semantics as the reference's ``Model`` -- ``setup_caches``,
+``reset_caches``, ``generate_frame(tokens, tokens_mask, input_pos, temperature, topk)`` ->
+``(B, 32) int32`` -- but every op runs in hand-written gfx950 kernels behind the C ABI of
+libcsm_hip.so (include/csm_hip.h).  PyTorch is used only for device memory and streams.
+There is no CPU / eager fallback: without the HIP library or a GPU this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _abi
+from ._abi import lib, check
+
+
+# ----------------------------------------------------------------------------------------
+# shapes (reference: sesameai/models.py:10-45 llama3_2_1B / llama3_2_100M / FLAVORS)
+# ----------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class LlamaFlavor:
+    num_layers: int
+    num_heads: int
+    num_kv_heads: int
+    embed_dim: int
+    intermediate_dim: int
+    max_seq_len: int = 2048
+    norm_eps: float = 1e-5
+    rope_base: float = 500_000.0
+    scale_factor: float = 32.0
+
+    @property
+    def head_dim(self) -> int:
+        return self.embed_dim // self.num_heads
+
+
+FLAVORS: Dict[str, LlamaFlavor] = {
+    "llama-1B": LlamaFlavor(16, 32, 8, 2048, 8192),
+    "llama-100M": LlamaFlavor(4, 8, 2, 1024, 8192),
+    # small stand-ins with the same head dims (64 / 128), used by the test-suite
+    "llama-tiny-bb": LlamaFlavor(2, 8, 2, 512, 1024, max_seq_len=256),
+    "llama-tiny-dec": LlamaFlavor(2, 4, 2, 512, 1024, max_seq_len=256),
+}
+
+
+@dataclass
+class ModelArgs:
+    backbone_flavor: str
+    decoder_flavor: str
+    text_vocab_size: int
+    audio_vocab_size: int
+    audio_num_codebooks: int
+
+
+def csm_1b_args() -> ModelArgs:
+    return ModelArgs("llama-1B", "llama-100M", 128_256, 2051, 32)
+
+
+def csm_tiny_args() -> ModelArgs:
+    return ModelArgs("llama-tiny-bb", "llama-tiny-dec", 1000, 2051, 32)
+
+
+# ----------------------------------------------------------------------------------------
+# host-side tables and weights
+# ----------------------------------------------------------------------------------------
+def llama3_rope_table(f: LlamaFlavor) -> torch.Tensor:
+    """[max_seq][hd/2][2] (cos, sin) of torchtune's Llama3ScaledRoPE (low/high freq factors 1/4,
+    old context 8192), built in fp32 on the host and rounded to bf16 like the reference's
+    ``model.to(dtype=bf16)`` rounds the registered buffer (sesameai/generator.py:343)."""
+    hd = f.head_dim
+    theta = 1.0 / (f.rope_base ** (torch.arange(0, hd, 2)[: hd // 2].float() / hd))
+    old_len, lo, hi = 8192, 1.0, 4.0
+    scaled = []
+    for fr in theta.tolist():
+        wl = 2 * math.pi / fr
+        if wl < old_len / hi:
+            scaled.append(fr)
+        elif wl > old_len / lo:
+            scaled.append(fr / f.scale_factor)
+        else:
+            smooth = (old_len / wl - lo) / (hi - lo)
+            scaled.append((1 - smooth) * fr / f.scale_factor + smooth * fr)
+    theta = torch.tensor(scaled, dtype=theta.dtype)
+    idx = torch.einsum("i,j->ij", torch.arange(f.max_seq_len, dtype=theta.dtype), theta).float()
+    return torch.stack([torch.cos(idx), torch.sin(idx)], dim=-1).to(torch.bfloat16)
+
+
+def state_dict_layout(args: ModelArgs) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Tensor names/shapes of a CSM checkpoint (module tree of sesameai/models.py:110-118 with
+    torchtune attribute names), in a fixed order."""
+    bb, dec = FLAVORS[args.backbone_flavor], FLAVORS[args.decoder_flavor]
+    out: List[Tuple[str, Tuple[int, ...]]] = [
+        ("text_embeddings.weight", (args.text_vocab_size, bb.embed_dim)),
+        ("audio_embeddings.weight", (args.audio_vocab_size * args.audio_num_codebooks, bb.embed_dim)),
+    ]
+    for pfx, s in (("backbone", bb), ("decoder", dec)):
+        hd = s.head_dim
+        for i in range(s.num_layers):
+            L = f"{pfx}.layers.{i}"
+            out += [(f"{L}.attn.q_proj.weight", (s.num_heads * hd, s.embed_dim)),
+                    (f"{L}.attn.k_proj.weight", (s.num_kv_heads * hd, s.embed_dim)),
+                    (f"{L}.attn.v_proj.weight", (s.num_kv_heads * hd, s.embed_dim)),
+                    (f"{L}.attn.output_proj.weight", (s.embed_dim, s.num_heads * hd)),
+                    (f"{L}.mlp.w1.weight", (s.intermediate_dim, s.embed_dim)),
+                    (f"{L}.mlp.w2.weight", (s.embed_dim, s.intermediate_dim)),
+                    (f"{L}.mlp.w3.weight", (s.intermediate_dim, s.embed_dim)),
+                    (f"{L}.sa_norm.scale", (s.embed_dim,)),
+                    (f"{L}.mlp_norm.scale", (s.embed_dim,))]
+        out.append((f"{pfx}.norm.scale", (s.embed_dim,)))
+    out += [("projection.weight", (dec.embed_dim, bb.embed_dim)),
+            ("codebook0_head.weight", (args.audio_vocab_size, bb.embed_dim)),
+            ("audio_head", (args.audio_num_codebooks - 1, dec.embed_dim, args.audio_vocab_size))]
+    return out
+
+
+def synthetic_state_dict(args: ModelArgs, seed: int = 1234, std: float = 0.02) -> Dict[str, torch.Tensor]:
+    """Random-init weights of the true shapes (no checkpoint can be downloaded here):
+    N(0, std^2) fp32 -> bf16 from one seeded CPU generator in ``state_dict_layout`` order,
+    norm scales = 1."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    for name, shp in state_dict_layout(args):
+        if name.endswith(".scale"):
+            t = torch.ones(shp, dtype=torch.float32)
+        else:
+            t = torch.empty(shp, dtype=torch.float32).normal_(0.0, std, generator=g)
+        sd[name] = t.to(torch.bfloat16)
+    return sd
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Model:
+    """Drop-in for the reference ``Model`` (sesameai/models.py:99-203)."""
+
+    def __init__(self, config: ModelArgs, state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 device: str = "cuda", max_frames: int = 2048, max_prefill_rows: int = 2048):
+        if not torch.cuda.is_available():
+            raise RuntimeError("sesameai (MI355X build) needs a ROCm GPU: there is no CPU fallback")
+        self.config = config
+        self.device = torch.device(device)
+        self.bb, self.dec = FLAVORS[config.backbone_flavor], FLAVORS[config.decoder_flavor]
+        if state_dict is None:
+            state_dict = synthetic_state_dict(config)
+        layout = dict(state_dict_layout(config))
+        missing = [k for k in layout if k not in state_dict]
+        if missing:
+            raise KeyError(f"checkpoint is missing tensors: {missing[:4]}...")
+        self._w: Dict[str, torch.Tensor] = {}
+        for name, shp in layout.items():
+            t = state_dict[name]
+            if tuple(t.shape) != tuple(shp):
+                raise ValueError(f"{name}: expected shape {shp}, got {tuple(t.shape)}")
+            self._w[name] = t.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        # device-native layouts: K-major audio_head -> one contiguous row per logit
+        self._w["audio_head_t"] = self._w["audio_head"].transpose(1, 2).contiguous()
+        self._w["bb_rope"] = llama3_rope_table(self.bb).to(self.device).contiguous()
+        self._w["dec_rope"] = llama3_rope_table(self.dec).to(self.device).contiguous()
+        self._max_frames = max_frames
+        self._max_prefill_rows = max_prefill_rows
+        self._h = C.c_void_p(None)
+        self._max_batch = 0
+        self._seeded = False
+
+    # -- reference-compatible construction helpers ------------------------------------------
+    @classmethod
+    def from_pretrained(cls, path: str, device: str = "cuda", **kw) -> "Model":
+        """Loads ``model.safetensors`` of a local ``sesame/csm-1b`` snapshot directory (the
+        reference pulls it from the hub with PyTorchModelHubMixin, sesameai/generator.py:338;
+        there is no network here)."""
+        import os
+        from safetensors.torch import load_file
+        f = path if path.endswith(".safetensors") else os.path.join(path, "model.safetensors")
+        return cls(csm_1b_args(), load_file(f), device=device, **kw)
+
+    def parameters(self):
+        return iter(self._w.values())
+
+    def weight_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._w.values())
+
+    # -- caches ---------------------------------------------------------------------------------
+    def _cfg_struct(self) -> _abi.CsmConfig:
+        def dims(f: LlamaFlavor) -> _abi.CsmLlamaDims:
+            return _abi.CsmLlamaDims(f.num_layers, f.num_heads, f.num_kv_heads, f.embed_dim,
+                                     f.intermediate_dim, f.max_seq_len, f.norm_eps)
+        return _abi.CsmConfig(dims(self.bb), dims(self.dec), self.config.text_vocab_size,
+                              self.config.audio_vocab_size, self.config.audio_num_codebooks)
+
+    def _weights_struct(self) -> _abi.CsmWeights:
+        w = _abi.CsmWeights()
+        p = lambda n: self._w[n].data_ptr()
+        w.text_emb, w.audio_emb = p("text_embeddings.weight"), p("audio_embeddings.weight")
+        for pfx, arr, f in (("backbone", w.bb, self.bb), ("decoder", w.dec, self.dec)):
+            for i in range(f.num_layers):
+                L = f"{pfx}.layers.{i}"
+                arr[i] = _abi.CsmLayerWeights(
+                    p(f"{L}.attn.q_proj.weight"), p(f"{L}.attn.k_proj.weight"), p(f"{L}.attn.v_proj.weight"),
+                    p(f"{L}.attn.output_proj.weight"), p(f"{L}.mlp.w1.weight"), p(f"{L}.mlp.w2.weight"),
+                    p(f"{L}.mlp.w3.weight"), p(f"{L}.sa_norm.scale"), p(f"{L}.mlp_norm.scale"))
+        w.bb_norm, w.dec_norm = p("backbone.norm.scale"), p("decoder.norm.scale")
+        w.projection, w.c0_head = p("projection.weight"), p("codebook0_head.weight")
+        w.audio_head_t, w.bb_rope, w.dec_rope = p("audio_head_t"), p("bb_rope"), p("dec_rope")
+        return w
+
+    def setup_caches(self, max_batch_size: int) -> None:
+        """reference: Model.setup_caches (sesameai/models.py:120-130)."""
+        if self._h:
+            lib.csm_destroy(self._h)
+            self._h = C.c_void_p(None)
+        cfg, w = self._cfg_struct(), self._weights_struct()
+        rows = max(self._max_prefill_rows, 2 * max_batch_size)
+        with torch.cuda.device(self.device):
+            check(lib.csm_create(C.byref(cfg), C.byref(w), max_batch_size, rows, self._max_frames, C.byref(self._h)))
+        self._max_batch = max_batch_size
+
+    def caches_are_enabled(self) -> bool:
+        return bool(self._h)
+
+    def reset_caches(self) -> None:
+        """reference: Model.reset_caches (sesameai/models.py:186-188)."""
+        self._require()
+        check(lib.csm_reset(self._h, _stream_ptr()), self._h)
+
+    def seed(self, seed: int) -> None:
+        self._require()
+        check(lib.csm_seed(self._h, seed, _stream_ptr()), self._h)
+        self._seeded = True
+
+    def _require(self) -> None:
+        assert self._h, "backbone caches are not enabled"     # reference: models.py:153
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib.csm_destroy(self._h)
+        except Exception:
+            pass
+
+    # -- the frame ----------------------------------------------------------------------------
+    def prefill(self, tokens: torch.Tensor, tokens_mask: torch.Tensor, input_pos: torch.Tensor) -> None:
+        self._require()
+        b, s, _ = tokens.shape
+        if b * s > max(self._max_prefill_rows, 2 * self._max_batch):
+            raise ValueError(f"prompt of {b}x{s} rows exceeds max_prefill_rows={self._max_prefill_rows}")
+        t = tokens.to(device=self.device, dtype=torch.int32).contiguous()
+        m = tokens_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        p = input_pos.to(device=self.device, dtype=torch.int32).contiguous()
+        check(lib.csm_prefill(self._h, t.data_ptr(), m.data_ptr(), p.data_ptr(), b, s, _stream_ptr()), self._h)
+
+    def depth(self, batch: int, temperature: float, topk: int, *, forced: Optional[torch.Tensor] = None,
+              noise: Optional[torch.Tensor] = None, want_logits: bool = False, commit: bool = True):
+        """c0 head + 31 decoder steps on the current backbone state -> (B,32) int32 [, logits]."""
+        self._require()
+        out = torch.empty(batch, self.config.audio_num_codebooks, dtype=torch.int32, device=self.device)
+        logits = None
+        if want_logits:
+            logits = torch.empty(self.config.audio_num_codebooks, batch, self.config.audio_vocab_size,
+                                 dtype=torch.bfloat16, device=self.device)
+        f = forced.to(device=self.device, dtype=torch.int32).contiguous() if forced is not None else None
+        n = noise.to(device=self.device, dtype=torch.bfloat16).contiguous() if noise is not None else None
+        check(lib.csm_depth(self._h, batch, float(temperature), int(topk),
+                            f.data_ptr() if f is not None else None, out.data_ptr(),
+                            logits.data_ptr() if logits is not None else None,
+                            n.data_ptr() if n is not None else None, int(commit), _stream_ptr()), self._h)
+        return (out, logits) if want_logits else out
+
+    def step(self, batch: int, temperature: float, topk: int, use_graph: bool = True) -> None:
+        """One continuing frame from on-device state (hipGraph replay); no host sync."""
+        check(lib.csm_frame_step(self._h, batch, float(temperature), int(topk), int(use_graph), _stream_ptr()), self._h)
+
+    def last_frame(self, batch: int) -> torch.Tensor:
+        out = torch.empty(batch, self.config.audio_num_codebooks, dtype=torch.int32, device=self.device)
+        check(lib.csm_copy_frame(self._h, batch, out.data_ptr(), _stream_ptr()), self._h)
+        return out
+
+    def read_frames(self, batch: int, first: int = 0, n: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(frames [n][B][32] int32 CPU, eos_at [B] int32 CPU) -- synchronises."""
+        total = lib.csm_num_frames(self._h)
+        n = total - first if n is None else n
+        frames = torch.empty(max(n, 0), batch, self.config.audio_num_codebooks, dtype=torch.int32)
+        eos = torch.empty(batch, dtype=torch.int32)
+        check(lib.csm_read_frames(self._h, batch, first, max(n, 0), frames.data_ptr() if n > 0 else None,
+                                  eos.data_ptr(), _stream_ptr()), self._h)
+        return frames, eos
+
+    def num_frames(self) -> int:
+        return lib.csm_num_frames(self._h)
+
+    def frames_device_ptr(self) -> int:
+        return lib.csm_frames_dev(self._h)
+
+    @torch.inference_mode()
+    def generate_frame(self, tokens: torch.Tensor, tokens_mask: torch.Tensor, input_pos: torch.Tensor,
+                       temperature: float, topk: int) -> torch.Tensor:
+        """reference: Model.generate_frame (sesameai/models.py:132-184).
+
+        tokens (B,S,33), tokens_mask (B,S,33), input_pos (B,S) -> (B,32) int32 on the device.
+        S > 1 (a prompt) runs prefill + depth; S == 1 stages the caller's row and replays the
+        captured frame-step graph."""
+        self._require()
+        b, s, _ = tokens.size()
+        if s > 1:
+            self.prefill(tokens, tokens_mask, input_pos)
+            return self.depth(b, temperature, topk, commit=True)
+        t = tokens.to(device=self.device, dtype=torch.int32).contiguous()
+        m = tokens_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        p = input_pos.to(device=self.device, dtype=torch.int32).contiguous()
+        check(lib.csm_set_step_inputs(self._h, t.data_ptr(), m.data_ptr(), p.data_ptr(), b, _stream_ptr()), self._h)
+        self.step(b, temperature, topk)
+        return self.last_frame(b)
+
+    def bytes_per_frame(self, batch: int, p_mean: float) -> float:
+        return lib.csm_bytes_per_frame(self._h, batch, float(p_mean))
