@@ -51,26 +51,59 @@ def synthetic_prompt(args, batch, text_vocab, seed0=2025):
     return torch.stack(toks), torch.stack(masks)
 
 
-def cpu_baseline(args, tokens, mask, sample_frames):
-    """The oracle (CPU restatement of the reference's eager `-d cpu` bf16 graph) timed on this
-    host's cores on a bounded sample of the same workload: the S=190 prefill is part of frame 0
-    (as in the reference's first generate_frame call), then sample_frames-1 decode frames."""
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_worker(args):
+    """Child process: the oracle (CPU restatement of the reference's eager `-d cpu` bf16 graph)
+    on the same S=190 prompt; prints one JSON line per completed frame until the budget is spent."""
     from oracle import csm_ref as C
-    torch.set_num_threads(os.cpu_count() or 1)
     shape = C.csm_1b()
     w = C.make_weights(shape, seed=1234)
     m = C.OracleModel(shape, w)
     m.setup_caches(1)
-    g = torch.Generator().manual_seed(0)
+    tokens, mask = synthetic_prompt(args, 1, shape.text_vocab_size)
     torch.manual_seed(0)
+    cur_t, cur_m = tokens, mask
+    pos = torch.arange(tokens.shape[1]).unsqueeze(0)
     t0 = time.time()
-    frames = C.generate_codes(m, tokens[0], mask[0], sample_frames * 80, 0.9, 50)
-    dt = time.time() - t0
-    n = max(1, len(frames))
-    # decode-loop rate excluding the prefill-carrying first frame, if we have more than one
-    return dict(value=n / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle/csm_ref.py (PyTorch-CPU bf16), same S={tokens.shape[1]} prompt, {n} frames incl. prefill, "
-                       f"{dt:.1f}s wall, torch {torch.__version__}")
+    n = 0
+    while time.time() - t0 < args.cpu_budget and n < args.cpu_frames:
+        s = m.generate_frame(cur_t, cur_m, pos, args.temperature, args.topk)
+        n += 1
+        print(json.dumps({"frames": n, "elapsed": time.time() - t0, "threads": torch.get_num_threads()}), flush=True)
+        cur_t = torch.cat([s.long(), torch.zeros(1, 1).long()], dim=1).unsqueeze(1)
+        cur_m = torch.cat([torch.ones_like(s).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
+        pos = pos[:, -1:] + 1
+
+
+def cpu_baseline(args):
+    """Runs cpu_worker in a child with a hard wall-clock limit (killed by PID if it overruns) and
+    turns its last progress line into the cpu_baseline object."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-budget", str(args.cpu_budget),
+           "--cpu-frames", str(args.cpu_frames), "--temperature", str(args.temperature), "--topk", str(args.topk)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(args.cpu_threads))
+    log(f"cpu baseline: oracle on {args.cpu_threads} host threads, budget {args.cpu_budget}s")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+    try:
+        out, _ = proc.communicate(timeout=args.cpu_budget + 120)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        out, _ = proc.communicate()
+    lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    if not lines:
+        return dict(value=None, unit="frames/s", cores=args.cpu_threads, kind="port",
+                    sample="oracle did not finish one frame within the budget")
+    last = lines[-1]
+    first = lines[0]
+    decode = (last["frames"] - 1) / (last["elapsed"] - first["elapsed"]) if last["frames"] > 1 else None
+    return dict(value=round(last["frames"] / last["elapsed"], 3), unit="frames/s", cores=last["threads"], kind="port",
+                decode_only_frames_per_s=round(decode, 3) if decode else None,
+                sample=f"oracle/csm_ref.py (PyTorch-CPU bf16 restatement of the reference -d cpu graph), same S=190 prompt: "
+                       f"frame 0 incl. prefill {first['elapsed']:.2f}s, {last['frames']} frames in {last['elapsed']:.1f}s, "
+                       f"torch {torch.__version__}")
 
 
 def main():
@@ -86,9 +119,15 @@ def main():
     ap.add_argument("--topk", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=12)
+    ap.add_argument("--cpu-frames", type=int, default=24)
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle frames to time")
+    ap.add_argument("--cpu-threads", type=int, default=min(32, os.cpu_count() or 1))
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--tiny", action="store_true", help="tiny shapes (plumbing check only; not a valid bench)")
     args = ap.parse_args()
+    if args.cpu_worker:
+        cpu_worker(args)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -108,6 +147,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from sesameai.models import Model, csm_1b_args, csm_tiny_args, state_dict_layout, synthetic_state_dict
+    log(f"rank {rank}/{world}: building weights")
     margs = csm_tiny_args() if args.tiny else csm_1b_args()
     B = args.batch
     # ---- weights: rank 0 seeds them, the others receive one RCCL broadcast over xGMI --------
@@ -119,6 +159,7 @@ def main():
     model = Model(margs, sd, device=str(dev), max_frames=args.steps + args.warmup + 8,
                   max_prefill_rows=B * (args.ctx_text + args.ctx_frames + 1 + args.gen_text))
     del sd
+    log("weights on device; creating caches")
     model.setup_caches(B)
     model.seed(1234 + rank)
     tokens, mask = synthetic_prompt(args, B, margs.text_vocab_size, seed0=2025 + rank * B)
@@ -141,6 +182,7 @@ def main():
     model.depth(B, args.temperature, args.topk, commit=True)
     torch.cuda.synchronize()
     prefill_ms = (time.perf_counter() - t0) * 1e3
+    log(f"prefill + frame 0: {prefill_ms:.1f} ms; warmup {args.warmup} frames")
     for _ in range(args.warmup):
         model.step(B, args.temperature, args.topk, use_graph)
     # ---- timed region: exactly K frame steps ---------------------------------------------
@@ -154,6 +196,7 @@ def main():
     ev1.record(stream)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    log(f"timed {args.steps} frames: {wall * 1e3:.1f} ms")
     ev_ms = ev0.elapsed_time(ev1)          # HIP events on the stream the frame graph runs on
     if dist is not None:
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
@@ -190,7 +233,7 @@ def main():
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and not args.tiny:
-            out["cpu_baseline"] = cpu_baseline(args, tokens, mask, args.cpu_frames)
+            out["cpu_baseline"] = cpu_baseline(args)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

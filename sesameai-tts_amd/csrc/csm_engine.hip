@@ -55,7 +55,8 @@ struct CsmModel {
     int host_pos_max;                   // host mirror of max position (overflow guard)
     // graph
     hipGraphExec_t gexec; hipGraph_t graph;
-    int g_B, g_topk; float g_temp; hipStream_t g_stream;
+    int g_B, g_topk; float g_temp; hipStream_t cap_stream;   // capture happens on an internal stream:
+                                                             // the caller's may be the legacy NULL stream
     std::string err;
 };
 
@@ -291,7 +292,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     if (max_rows < 2 * max_batch) max_rows = 2 * max_batch;
     m->max_rows = max_rows;
     m->ldl = ((cfg->audio_vocab + 511) / 512) * 512;
-    m->gexec = nullptr; m->graph = nullptr; m->g_B = -1;
+    m->gexec = nullptr; m->graph = nullptr; m->g_B = -1; m->cap_stream = nullptr;
     m->host_frames = 0; m->have_last = false; m->last_S = 1; m->host_pos_max = 0;
     init_stack(m->bb, cfg->backbone, m->w.bb, w->bb_norm, w->bb_rope, cfg->backbone.max_seq, 1);
     init_stack(m->dec, cfg->decoder, m->w.dec, w->dec_norm, w->dec_rope, cfg->n_codebooks, 0);
@@ -344,6 +345,7 @@ extern "C" void csm_destroy(csm_handle m) {
     if (!m) return;
     if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
     if (m->graph) (void)hipGraphDestroy(m->graph);
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     void* ptrs[] = {m->bb.kc, m->bb.vc, m->dec.kc, m->dec.vc, m->h, m->q, m->att, m->act, m->part, m->dec_in, m->dec_in1,
                     m->hdec, m->qd, m->attd, m->actd, m->logits, m->frame, m->cur_tokens, m->cur_mask, m->cur_pos,
                     m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos};
@@ -426,9 +428,10 @@ extern "C" int csm_frame_step(csm_handle m, int B, float temperature, int topk, 
         if (!m->gexec || m->g_B != B || m->g_topk != topk || m->g_temp != temperature) {
             if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }
             if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
-            HIPCHK(m, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            hipError_t e = enqueue_frame(m, B, temperature, topk, st);
-            hipError_t e2 = hipStreamEndCapture(st, &m->graph);
+            if (!m->cap_stream) HIPCHK(m, hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+            HIPCHK(m, hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+            hipError_t e = enqueue_frame(m, B, temperature, topk, m->cap_stream);
+            hipError_t e2 = hipStreamEndCapture(m->cap_stream, &m->graph);
             HIPCHK(m, e);
             HIPCHK(m, e2);
             HIPCHK(m, hipGraphInstantiate(&m->gexec, m->graph, nullptr, nullptr, 0));
