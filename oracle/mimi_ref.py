@@ -57,9 +57,10 @@ def mimi_full() -> MimiShape:
 
 
 def mimi_tiny() -> MimiShape:
-    """Same topology, narrow channels (for second-scale CPU tests); hop stays 1920."""
-    return MimiShape(hidden=64, codebook_size=2048, codebook_dim=32, tr_layers=2, tr_heads=2,
-                     tr_ffn=128, tr_context=6, n_filters=4)
+    """Same topology and SEANet widths, small transformer / RVQ (second-scale CPU tests); hop
+    stays 1920, head_dim stays 64, every channel count stays a multiple of 32."""
+    return MimiShape(hidden=128, codebook_size=2048, codebook_dim=64, tr_layers=2, tr_heads=2,
+                     tr_ffn=256, tr_context=6, n_filters=64)
 
 
 # ----------------------------------------------------------------------------------------

@@ -1,0 +1,466 @@
+// Mimi codec decode on gfx950 (fp32): RVQ gather-sum + output projections, depthwise
+// upsample, 8-layer causal transformer (window 250, interleaved RoPE, LayerScale) and the
+// SEANet conv decoder.  C ABI in include/mimi_hip.h.
+//
+// Replaces moshi 0.2.2 MimiModel.decode as called at sesameai/generator.py:116,299 and
+// tts_service.py:245 (structure: SURVEY.md App. A.3; checked against oracle/mimi_ref.py).
+//
+// Layout: every activation is token-major [time][channels] fp32, so the channel (reduction)
+// axis is contiguous for loads and the output-channel axis is contiguous for stores.  Every
+// linear layer, causal Conv1d and ConvTranspose1d is ONE kernel: a multi-tap GEMM
+//     out[t*phases + p][co] = bias[co] + sum_tap sum_ci act(x[t + shift_tap][ci]) * w[p][tap][co][ci]
+// on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain), one
+// wave per 32(time) x 32(channel) tile, operands straight from L2 in 64-byte contiguous pieces
+// (the K order inside a 32-wide chunk is permuted so each lane reads 16 consecutive floats).
+// A transposed conv with k = 2*stride is `stride` phase-GEMMs with 2 taps each.  Buffers that
+// feed a causal op carry `hist` rows of left context in front of row 0: zero for a stateless
+// decode, the previous call's tail for a stateful stream.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mimi_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+static thread_local std::string g_mimi_err;
+
+#define MAX_TAPS 8
+
+struct GemmArgs {
+    const float* x; long ldx;       // A row for output time t, tap j: x + (t + shift[j]) * ldx
+    int T_in, C_in, C_out;
+    const float* w;                 // [phases][taps][C_out][C_in]
+    const float* bias;
+    int taps, phases;
+    int shift[MAX_TAPS];
+    int elu_in;                     // ELU(alpha=1) applied to A on load
+    int act_out;                    // 1 = exact GELU
+    const float* col_scale;         // optional per-output-channel scale (LayerScale)
+    const float* resid; long ldr;   // optional residual, indexed like out
+    float* out; long ldo;
+};
+
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expf(v) - 1.0f; }
+
+__global__ __launch_bounds__(64) void k_gemm32(const GemmArgs a) {
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 32, p = blockIdx.z;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const bool trow_ok = (t0 + r) < a.T_in;
+    const bool nrow_ok = (n0 + r) < a.C_out;
+    const int trow = trow_ok ? (t0 + r) : (a.T_in - 1);
+    const int nrow = nrow_ok ? (n0 + r) : (a.C_out - 1);
+    for (int j = 0; j < a.taps; ++j) {
+        const float* xa = a.x + (long)(trow + a.shift[j]) * a.ldx + h * 16;
+        const float* wb = a.w + (((long)p * a.taps + j) * a.C_out + nrow) * a.C_in + h * 16;
+        for (int kc = 0; kc < a.C_in; kc += 32) {
+            float4 av[4], bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                av[q] = *reinterpret_cast<const float4*>(xa + kc + q * 4);
+                bv[q] = *reinterpret_cast<const float4*>(wb + kc + q * 4);
+            }
+            float af[16], bf[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                af[q * 4 + 0] = av[q].x; af[q * 4 + 1] = av[q].y; af[q * 4 + 2] = av[q].z; af[q * 4 + 3] = av[q].w;
+                bf[q * 4 + 0] = bv[q].x; bf[q * 4 + 1] = bv[q].y; bf[q * 4 + 2] = bv[q].z; bf[q * 4 + 3] = bv[q].w;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                float va = af[s];
+                if (a.elu_in) va = elu1(va);
+                if (!trow_ok) va = 0.f;
+                const float vb = nrow_ok ? bf[s] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, acc, 0, 0, 0);
+            }
+        }
+    }
+    // C/D map of the 32x32 tile: col = lane & 31 (channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (time)
+    const int ch = n0 + r;
+    if (ch >= a.C_out) return;
+    const float bias = a.bias ? a.bias[ch] : 0.f;
+    const float cs = a.col_scale ? a.col_scale[ch] : 1.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int t = t0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (t >= a.T_in) continue;
+        const long orow = (long)t * a.phases + p;
+        float v = acc[reg] + bias;
+        if (a.act_out == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        if (a.col_scale) v = cs * v;
+        if (a.resid) v = a.resid[orow * a.ldr + ch] + v;
+        a.out[orow * a.ldo + ch] = v;
+    }
+}
+
+// RVQ decode: q_first = emb_0[c0]; q_rest = sum_{k>=1} emb_k[c_k]; out = Wf q_first + Wr q_rest
+__global__ __launch_bounds__(256) void k_rvq(const int* codes, long stride_k, long stride_t, int T, int ncb, int nsem,
+                                             int cbsize, int cbdim, int hidden, const float* books, const float* pf,
+                                             const float* pr, float* out, long ldo) {
+    extern __shared__ float q[];                 // [2][cbdim]
+    const int t = blockIdx.x;
+    for (int d = threadIdx.x; d < cbdim; d += blockDim.x) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < ncb; ++k) {
+            int c = codes[k * stride_k + t * stride_t];
+            c = min(max(c, 0), cbsize - 1);
+            const float v = books[((long)k * cbsize + c) * cbdim + d];
+            if (k < nsem) s1 += v; else s2 += v;
+        }
+        q[d] = s1; q[cbdim + d] = s2;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < hidden; c += blockDim.x) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int d = 0; d < cbdim; ++d) {
+            a1 = fmaf(pf[(long)d * hidden + c], q[d], a1);
+            a2 = fmaf(pr[(long)d * hidden + c], q[cbdim + d], a2);
+        }
+        out[(long)t * ldo + c] = a1 + a2;
+    }
+}
+
+// depthwise ConvTranspose1d k4 s2, causal: out[2t+p][c] = x[t][c] w[p][0][c] + x[t-1][c] w[p][1][c]
+__global__ void k_upsample(const float* x, long ldx, int T, int C, const float* w, float* out, long ldo) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)T * 2 * C) return;
+    const int c = (int)(i % C);
+    const long n = i / C;
+    const long t = n >> 1;
+    const int p = (int)(n & 1);
+    out[n * ldo + c] = x[t * ldx + c] * w[(p * 2 + 0) * C + c] + x[(t - 1) * ldx + c] * w[(p * 2 + 1) * C + c];
+}
+
+__global__ __launch_bounds__(64) void k_layernorm(const float* x, int d, const float* w, const float* b, float eps, float* out) {
+    const long row = blockIdx.x;
+    const float* xr = x + row * d;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < d; i += 64) s += xr[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / d;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < d; i += 64) { const float dlt = xr[i] - mean; v += dlt * dlt; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const float rstd = 1.0f / sqrtf(v / d + eps);
+    for (int i = threadIdx.x; i < d; i += 64) out[row * d + i] = (xr[i] - mean) * rstd * w[i] + b[i];
+}
+
+// qkv [T][3d] -> q [T][d] (RoPE), K/V caches [cap][d] at rows offset+t (K with RoPE); hd = 64
+__global__ void k_rope_split(const float* qkv, int T, int d, int offset, const float* freqs, float* q, float* kc, float* vc) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (t, pair)
+    const int pairs = d / 2;
+    if (i >= (long)T * pairs) return;
+    const int t = (int)(i / pairs), pr = (int)(i % pairs);
+    const int e = pr % 32;                                         // pair index inside the head (hd/2 = 32)
+    const float ang = (float)(offset + t) * freqs[e];
+    const float c = cosf(ang), s = sinf(ang);
+    const float* row = qkv + (long)t * 3 * d;
+    const float q0 = row[2 * pr], q1 = row[2 * pr + 1];
+    const float k0 = row[d + 2 * pr], k1 = row[d + 2 * pr + 1];
+    q[(long)t * d + 2 * pr] = q0 * c - q1 * s;
+    q[(long)t * d + 2 * pr + 1] = q0 * s + q1 * c;
+    kc[(long)(offset + t) * d + 2 * pr] = k0 * c - k1 * s;
+    kc[(long)(offset + t) * d + 2 * pr + 1] = k0 * s + k1 * c;
+    vc[(long)(offset + t) * d + 2 * pr] = row[2 * d + 2 * pr];
+    vc[(long)(offset + t) * d + 2 * pr + 1] = row[2 * d + 2 * pr + 1];
+}
+
+// causal windowed attention, one wave per (query, head); head_dim 64
+__global__ __launch_bounds__(64) void k_mimi_attn(const float* q, const float* kc, const float* vc, int d, int offset,
+                                                  int context, float* out) {
+    __shared__ float pbuf[1024];
+    const int i = blockIdx.x, hh = blockIdx.y, lane = threadIdx.x;
+    const int pi = offset + i;
+    const int lo = max(0, pi - context + 1);
+    const int nk = pi - lo + 1;
+    const float* qr = q + (long)i * d + hh * 64;
+    float qv[64];
+#pragma unroll
+    for (int e = 0; e < 64; e += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(qr + e);
+        qv[e] = v.x; qv[e + 1] = v.y; qv[e + 2] = v.z; qv[e + 3] = v.w;
+    }
+    float mx = -INFINITY;
+    for (int j = lane; j < nk; j += 64) {
+        const float* kr = kc + (long)(lo + j) * d + hh * 64;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 64; e += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(kr + e);
+            s = fmaf(qv[e], v.x, s); s = fmaf(qv[e + 1], v.y, s); s = fmaf(qv[e + 2], v.z, s); s = fmaf(qv[e + 3], v.w, s);
+        }
+        s *= 0.125f;
+        pbuf[j] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int j = lane; j < nk; j += 64) { const float pw = expf(pbuf[j] - mx); pbuf[j] = pw; sum += pw; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    __syncthreads();
+    float o = 0.f;
+    for (int j = 0; j < nk; ++j) o = fmaf(pbuf[j], vc[(long)(lo + j) * d + hh * 64 + lane], o);
+    out[(long)i * d + hh * 64 + lane] = o / sum;
+}
+
+// final Conv1d (taps x C_in -> 1 channel) with ELU on the input; one thread per output sample
+__global__ void k_conv_out(const float* x, long ldx, long T, int C_in, int taps, const float* w /*[taps][1][C_in]*/,
+                           const float* bias, float* pcm) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    float acc = bias ? bias[0] : 0.f;
+    for (int j = 0; j < taps; ++j) {
+        const float* xr = x + (t + j - (taps - 1)) * ldx;
+        const float* wr = w + (long)j * C_in;
+        for (int c = 0; c < C_in; c += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            const float4 u = *reinterpret_cast<const float4*>(wr + c);
+            acc = fmaf(elu1(v.x), u.x, acc); acc = fmaf(elu1(v.y), u.y, acc);
+            acc = fmaf(elu1(v.z), u.z, acc); acc = fmaf(elu1(v.w), u.w, acc);
+        }
+    }
+    pcm[t] = acc;
+}
+
+// slide the left-context window of a [hist + T][C] buffer: new hist rows = last hist rows of (old hist ++ new T rows)
+__global__ void k_slide_hist(float* base /*row -hist*/, int hist, long T, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    for (int r = 0; r < hist; ++r) base[(long)r * C + c] = base[((long)r + T) * C + c];   // ascending r: source is always ahead
+}
+
+// ---------------------------------------------------------------------------------------
+struct HBuf {            // activation buffer with `hist` rows of left context in front of row 0
+    float* base = nullptr;
+    int hist = 0, C = 0;
+    float* row0() const { return base + (long)hist * C; }
+};
+
+struct MimiDecoder {
+    MimiConfig cfg;
+    MimiWeights w;
+    int max_frames;
+    long cap_tokens;                    // transformer KV capacity (tokens)
+    int offset;                         // tokens already in the KV caches (stateful stream)
+    HBuf rvq, a0, s0;                   // rvq out (hist 1), transformer out (hist kernel-1), conv_in out (hist 1)
+    HBuf u[MIMI_MAX_STAGES], xj[MIMI_MAX_STAGES];
+    float *r1[MIMI_MAX_STAGES];
+    float *tok, *ln, *qkv, *q, *att, *ffn, *kc, *vc;
+    std::string err;
+};
+
+#define MCHK(h, x)                                                                                     \
+    do {                                                                                               \
+        hipError_t e_ = (x);                                                                           \
+        if (e_ != hipSuccess) {                                                                        \
+            char b_[256];                                                                              \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            if (h) (h)->err = b_; else g_mimi_err = b_;                                                \
+            return -2;                                                                                 \
+        }                                                                                              \
+    } while (0)
+
+static int mfail(MimiDecoder* h, const char* msg) {
+    if (h) h->err = msg; else g_mimi_err = msg;
+    return -1;
+}
+
+static hipError_t alloc_hbuf(HBuf& b, int hist, long rows, int C) {
+    b.hist = hist; b.C = C;
+    hipError_t e = hipMalloc((void**)&b.base, (size_t)(hist + rows) * C * 4);
+    if (e != hipSuccess) return e;
+    return hipMemset(b.base, 0, (size_t)(hist + rows) * C * 4);
+}
+
+extern "C" int mimi_create(const MimiConfig* cfg, const MimiWeights* w, int max_frames, int reserved, mimi_handle* out) {
+    (void)reserved;
+    if (!cfg || !w || !out || max_frames < 1) return mfail(nullptr, "mimi_create: null/invalid argument");
+    if (cfg->hidden % 32 || cfg->codebook_dim % 4 || cfg->tr_ffn % 32 || cfg->hidden / cfg->tr_heads != 64)
+        return mfail(nullptr, "mimi_create: hidden%32, tr_ffn%32 and head_dim==64 required");
+    if (cfg->n_stages < 1 || cfg->n_stages > MIMI_MAX_STAGES || cfg->tr_layers > MIMI_MAX_TR_LAYERS || cfg->tr_context > 1024)
+        return mfail(nullptr, "mimi_create: too many stages/layers or context > 1024");
+    if (cfg->kernel > MAX_TAPS || cfg->res_kernel > MAX_TAPS) return mfail(nullptr, "mimi_create: kernel too wide");
+    int c = cfg->n_filters << cfg->n_stages;
+    for (int j = 0; j < cfg->n_stages; ++j) { c /= 2; if ((c / 2) % 32) return mfail(nullptr, "mimi_create: SEANet channels must stay multiples of 32"); }
+    MimiDecoder* m = new MimiDecoder();
+    m->cfg = *cfg; m->w = *w; m->max_frames = max_frames; m->offset = 0;
+    const int d = cfg->hidden;
+    const long T2 = 2L * max_frames;
+    m->cap_tokens = T2;
+    MCHK((MimiDecoder*)nullptr, alloc_hbuf(m->rvq, 1, max_frames, d));
+    MCHK((MimiDecoder*)nullptr, alloc_hbuf(m->a0, cfg->kernel - 1, T2, d));
+    int C = cfg->n_filters << cfg->n_stages;
+    MCHK((MimiDecoder*)nullptr, alloc_hbuf(m->s0, 1, T2, C));
+    long Tj = T2;
+    for (int j = 0; j < cfg->n_stages; ++j) {
+        Tj *= cfg->ratios[j]; C /= 2;
+        MCHK((MimiDecoder*)nullptr, alloc_hbuf(m->u[j], cfg->res_kernel - 1, Tj, C));
+        MCHK((MimiDecoder*)nullptr, hipMalloc((void**)&m->r1[j], (size_t)Tj * (C / 2) * 4));
+        const int nh = (j + 1 < cfg->n_stages) ? 1 : cfg->last_kernel - 1;
+        MCHK((MimiDecoder*)nullptr, alloc_hbuf(m->xj[j], nh, Tj, C));
+    }
+#define A4(p, n) MCHK((MimiDecoder*)nullptr, hipMalloc((void**)&(p), (size_t)(n) * 4))
+    A4(m->tok, T2 * d); A4(m->ln, T2 * d); A4(m->qkv, T2 * 3 * d); A4(m->q, T2 * d); A4(m->att, T2 * d);
+    A4(m->ffn, T2 * cfg->tr_ffn);
+    A4(m->kc, (long)cfg->tr_layers * m->cap_tokens * d); A4(m->vc, (long)cfg->tr_layers * m->cap_tokens * d);
+#undef A4
+    MCHK((MimiDecoder*)nullptr, hipDeviceSynchronize());
+    *out = m;
+    return 0;
+}
+
+extern "C" void mimi_destroy(mimi_handle m) {
+    if (!m) return;
+    (void)hipFree(m->rvq.base); (void)hipFree(m->a0.base); (void)hipFree(m->s0.base);
+    for (int j = 0; j < m->cfg.n_stages; ++j) { (void)hipFree(m->u[j].base); (void)hipFree(m->xj[j].base); (void)hipFree(m->r1[j]); }
+    void* ps[] = {m->tok, m->ln, m->qkv, m->q, m->att, m->ffn, m->kc, m->vc};
+    for (void* p : ps) (void)hipFree(p);
+    delete m;
+}
+
+extern "C" const char* mimi_last_error(mimi_handle m) { return m ? m->err.c_str() : g_mimi_err.c_str(); }
+
+static hipError_t zero_hist(const HBuf& b, hipStream_t st) {
+    return b.hist ? hipMemsetAsync(b.base, 0, (size_t)b.hist * b.C * 4, st) : hipSuccess;
+}
+
+extern "C" int mimi_reset_stream(mimi_handle m, void* stream) {
+    if (!m) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    MCHK(m, zero_hist(m->rvq, st)); MCHK(m, zero_hist(m->a0, st)); MCHK(m, zero_hist(m->s0, st));
+    for (int j = 0; j < m->cfg.n_stages; ++j) { MCHK(m, zero_hist(m->u[j], st)); MCHK(m, zero_hist(m->xj[j], st)); }
+    m->offset = 0;
+    return 0;
+}
+
+static hipError_t gemm(hipStream_t st, const float* x, long ldx, long T_in, const float* w, const float* bias, int C_in,
+                       int C_out, int taps, int phases, const int* shifts, int elu_in, int act_out, const float* col_scale,
+                       const float* resid, long ldr, float* out, long ldo) {
+    GemmArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x; a.ldx = ldx; a.T_in = (int)T_in; a.C_in = C_in; a.C_out = C_out; a.w = w; a.bias = bias; a.taps = taps;
+    a.phases = phases;
+    for (int j = 0; j < taps; ++j) a.shift[j] = shifts[j];
+    a.elu_in = elu_in; a.act_out = act_out; a.col_scale = col_scale; a.resid = resid; a.ldr = ldr; a.out = out; a.ldo = ldo;
+    dim3 grid((unsigned)((T_in + 31) / 32), (unsigned)((C_out + 31) / 32), (unsigned)phases);
+    hipLaunchKernelGGL(k_gemm32, grid, dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+static hipError_t slide(const HBuf& b, long T, hipStream_t st) {
+    if (!b.hist) return hipSuccess;
+    hipLaunchKernelGGL(k_slide_hist, dim3((b.C + 255) / 256), dim3(256), 0, st, b.base, b.hist, T, b.C);
+    return hipGetLastError();
+}
+
+static int decode_one(MimiDecoder* m, const int32_t* codes, long stride_k, long stride_t, int T, float* pcm, hipStream_t st) {
+    const MimiConfig& c = m->cfg;
+    const int d = c.hidden;
+    const long T2 = 2L * T;
+    const int zero = 0;
+    // 1. RVQ lookup-sum + output projections -> rvq [T][d]
+    hipLaunchKernelGGL(k_rvq, dim3(T), dim3(256), (size_t)2 * c.codebook_dim * 4, st, codes, stride_k, stride_t, T, c.n_codebooks,
+                       c.n_semantic, c.codebook_size, c.codebook_dim, d, m->w.codebooks, m->w.proj_first, m->w.proj_rest,
+                       m->rvq.row0(), (long)d);
+    MCHK(m, hipGetLastError());
+    // 2. depthwise transposed conv x2 -> tok [2T][d]
+    {
+        const long n = T2 * d;
+        hipLaunchKernelGGL(k_upsample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->rvq.row0(), (long)d, T, d,
+                           m->w.upsample, m->tok, (long)d);
+        MCHK(m, hipGetLastError());
+    }
+    // 3. transformer
+    for (int l = 0; l < c.tr_layers; ++l) {
+        const MimiTrLayer& L = m->w.tr[l];
+        float* kc = m->kc + (long)l * m->cap_tokens * d;
+        float* vc = m->vc + (long)l * m->cap_tokens * d;
+        hipLaunchKernelGGL(k_layernorm, dim3((unsigned)T2), dim3(64), 0, st, m->tok, d, L.ln1_w, L.ln1_b, c.norm_eps, m->ln);
+        MCHK(m, gemm(st, m->ln, d, T2, L.in_proj, nullptr, d, 3 * d, 1, 1, &zero, 0, 0, nullptr, nullptr, 0, m->qkv, 3 * d));
+        {
+            const long n = T2 * (d / 2);
+            hipLaunchKernelGGL(k_rope_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->qkv, (int)T2, d, m->offset,
+                               m->w.rope_freqs, m->q, kc, vc);
+        }
+        hipLaunchKernelGGL(k_mimi_attn, dim3((unsigned)T2, c.tr_heads), dim3(64), 0, st, m->q, kc, vc, d, m->offset, c.tr_context, m->att);
+        MCHK(m, gemm(st, m->att, d, T2, L.out_proj, nullptr, d, d, 1, 1, &zero, 0, 0, L.ls1, m->tok, d, m->tok, d));
+        hipLaunchKernelGGL(k_layernorm, dim3((unsigned)T2), dim3(64), 0, st, m->tok, d, L.ln2_w, L.ln2_b, c.norm_eps, m->ln);
+        MCHK(m, gemm(st, m->ln, d, T2, L.lin1, nullptr, d, c.tr_ffn, 1, 1, &zero, 0, 1, nullptr, nullptr, 0, m->ffn, c.tr_ffn));
+        float* dst = (l + 1 < c.tr_layers) ? m->tok : m->a0.row0();
+        MCHK(m, gemm(st, m->ffn, c.tr_ffn, T2, L.lin2, nullptr, c.tr_ffn, d, 1, 1, &zero, 0, 0, L.ls2, m->tok, d, dst, d));
+        MCHK(m, hipGetLastError());
+    }
+    // 4. SEANet decoder
+    int shifts[MAX_TAPS];
+    for (int j = 0; j < c.kernel; ++j) shifts[j] = j - (c.kernel - 1);
+    const MimiConv& ci = m->w.conv_in;
+    MCHK(m, gemm(st, m->a0.row0(), d, T2, ci.w, ci.bias, ci.c_in, ci.c_out, ci.taps, 1, shifts, 0, 0, nullptr, nullptr, 0,
+                 m->s0.row0(), ci.c_out));
+    const float* xin = m->s0.row0();
+    int Cin = ci.c_out;
+    long Tj = T2;
+    for (int j = 0; j < c.n_stages; ++j) {
+        const MimiConv &up = m->w.up[j], &r1 = m->w.res1[j], &r2 = m->w.res2[j];
+        const int tshift[2] = {0, -1};
+        // ELU -> ConvTranspose1d (stride phases, 2 taps each)
+        MCHK(m, gemm(st, xin, Cin, Tj, up.w, up.bias, up.c_in, up.c_out, 2, up.phases, tshift, 1, 0, nullptr, nullptr, 0,
+                     m->u[j].row0(), up.c_out));
+        Tj *= up.phases;
+        // residual block: u + conv_k1(ELU(conv_k3(ELU(u))))
+        for (int k = 0; k < r1.taps; ++k) shifts[k] = k - (r1.taps - 1);
+        MCHK(m, gemm(st, m->u[j].row0(), up.c_out, Tj, r1.w, r1.bias, r1.c_in, r1.c_out, r1.taps, 1, shifts, 1, 0, nullptr, nullptr,
+                     0, m->r1[j], r1.c_out));
+        MCHK(m, gemm(st, m->r1[j], r1.c_out, Tj, r2.w, r2.bias, r2.c_in, r2.c_out, 1, 1, &zero, 1, 0, nullptr, m->u[j].row0(),
+                     up.c_out, m->xj[j].row0(), r2.c_out));
+        xin = m->xj[j].row0(); Cin = r2.c_out;
+    }
+    const MimiConv& co = m->w.conv_out;
+    hipLaunchKernelGGL(k_conv_out, dim3((unsigned)((Tj + 255) / 256)), dim3(256), 0, st, xin, (long)Cin, Tj, co.c_in, co.taps, co.w,
+                       co.bias, pcm);
+    MCHK(m, hipGetLastError());
+    return 0;
+}
+
+static int slide_all(MimiDecoder* m, int T, hipStream_t st) {
+    const MimiConfig& c = m->cfg;
+    long Tj = 2L * T;
+    MCHK(m, slide(m->rvq, T, st)); MCHK(m, slide(m->a0, Tj, st)); MCHK(m, slide(m->s0, Tj, st));
+    for (int j = 0; j < c.n_stages; ++j) {
+        Tj *= c.ratios[j];
+        MCHK(m, slide(m->u[j], Tj, st)); MCHK(m, slide(m->xj[j], Tj, st));
+    }
+    return 0;
+}
+
+extern "C" int mimi_decode_strided(mimi_handle m, const int32_t* codes, int B, int T, long stride_b, long stride_k, long stride_t,
+                                   void* pcm, int stateful, void* stream) {
+    if (!m || !codes || !pcm || B < 1 || T < 1) return mfail(m, "mimi_decode: bad argument");
+    if (T > m->max_frames) return mfail(m, "mimi_decode: T exceeds max_frames given to mimi_create");
+    if (stateful && B != 1) return mfail(m, "mimi_decode: stateful streaming needs B == 1");
+    hipStream_t st = (hipStream_t)stream;
+    long hop = 2;
+    for (int j = 0; j < m->cfg.n_stages; ++j) hop *= m->cfg.ratios[j];
+    for (int b = 0; b < B; ++b) {
+        if (!stateful) { int rc = mimi_reset_stream(m, stream); if (rc) return rc; }
+        if (m->offset + 2L * T > m->cap_tokens) return mfail(m, "mimi_decode: stream longer than max_frames; call mimi_reset_stream");
+        int rc = decode_one(m, codes + (long)b * stride_b, stride_k, stride_t, T, (float*)pcm + (long)b * hop * T, st);
+        if (rc) return rc;
+        if (stateful) { rc = slide_all(m, T, st); if (rc) return rc; m->offset += 2 * T; }
+    }
+    return 0;
+}
+
+extern "C" int mimi_decode(mimi_handle m, const int32_t* codes, int B, int T, long stride_b, long stride_k, void* pcm,
+                           int stateful, void* stream) {
+    return mimi_decode_strided(m, codes, B, T, stride_b, stride_k, 1, pcm, stateful, stream);
+}

@@ -76,158 +76,141 @@ __device__ __forceinline__ uint32_t order_key(float t) {     // monotone map of 
     return (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
 }
 
-// find bin (descending) holding the k-th largest; returns bin and rank remaining inside it
-__device__ __forceinline__ void radix_pick(const int* hist, int k, int lane, int& bin, int& krem) {
-    const int c0 = hist[lane * 4 + 0], c1 = hist[lane * 4 + 1], c2 = hist[lane * 4 + 2], c3 = hist[lane * 4 + 3];
-    const int c4 = c0 + c1 + c2 + c3;
-    int suf = c4;                                             // inclusive suffix sum over lanes >= lane
+// k-th largest of a wave-distributed key list (each lane holds NC keys, 0 = empty slot):
+// the largest X with count(key >= X) >= k, by bisection on the 16 key bits with ballots.
+template <int NC>
+__device__ __forceinline__ uint32_t kth_largest_key(const uint32_t (&key)[NC], int k) {
+    uint32_t prefix = 0;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_down(suf, off, WAVE);
-        if (lane + off < 64) suf += o;
+    for (int bit = 15; bit >= 0; --bit) {
+        const uint32_t cand = prefix | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) cnt += __popcll(__ballot(key[c] >= cand));
+        if (cnt >= k) prefix = cand;
     }
-    const unsigned long long bal = __ballot(suf >= k);
-    const int L = 63 - __builtin_clzll(bal);                  // suf is non-increasing in lane
-    int b = 0, kr = 0;
-    if (lane == L) {
-        int above = suf - c4;                                 // keys in bins above this lane's 4
-        if (above + c3 >= k) { b = 3; kr = k - above; }
-        else if (above + c3 + c2 >= k) { b = 2; kr = k - above - c3; }
-        else if (above + c3 + c2 + c1 >= k) { b = 1; kr = k - above - c3 - c2; }
-        else { b = 0; kr = k - above - c3 - c2 - c1; }
-        b += 4 * L;
-    }
-    bin = __shfl(b, L, WAVE);
-    krem = __shfl(kr, L, WAVE);
+    return prefix;
 }
 
 template <int ITERS>
 __global__ __launch_bounds__(64) void k_sample(const SampleArgs a) {
-    __shared__ int hist[256];
+    // candidate list (values kept as fp32 copies of bf16 numbers)
+    __shared__ float cand_t[SAMPLE_MAX_ITERS * 512];
+    __shared__ int cand_i[SAMPLE_MAX_ITERS * 512];
     const int b = blockIdx.x, lane = threadIdx.x;
-    constexpr int iters = ITERS;
     float t[ITERS][8];
     const bf16_t* lg = a.logits + (long)b * a.ldl;
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
-        if (i < iters) {
-            const uint4 v = reinterpret_cast<const uint4*>(lg)[i * 64 + lane];
-            t[i][0] = round_bf(lo2f(v.x) / a.temperature); t[i][1] = round_bf(hi2f(v.x) / a.temperature);
-            t[i][2] = round_bf(lo2f(v.y) / a.temperature); t[i][3] = round_bf(hi2f(v.y) / a.temperature);
-            t[i][4] = round_bf(lo2f(v.z) / a.temperature); t[i][5] = round_bf(hi2f(v.z) / a.temperature);
-            t[i][6] = round_bf(lo2f(v.w) / a.temperature); t[i][7] = round_bf(hi2f(v.w) / a.temperature);
-        }
+        const uint4 v = reinterpret_cast<const uint4*>(lg)[i * 64 + lane];
+        t[i][0] = round_bf(lo2f(v.x) / a.temperature); t[i][1] = round_bf(hi2f(v.x) / a.temperature);
+        t[i][2] = round_bf(lo2f(v.y) / a.temperature); t[i][3] = round_bf(hi2f(v.y) / a.temperature);
+        t[i][4] = round_bf(lo2f(v.z) / a.temperature); t[i][5] = round_bf(hi2f(v.z) / a.temperature);
+        t[i][6] = round_bf(lo2f(v.w) / a.temperature); t[i][7] = round_bf(hi2f(v.w) / a.temperature);
     }
     int best_idx = 0x7fffffff;
     float best = -INFINITY;
     if (a.topk <= 1) {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i)
-            if (i < iters)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int idx = i * 512 + lane * 8 + j;
-                    if (idx < a.V && t[i][j] > best) { best = t[i][j]; best_idx = idx; }
-                }
+            for (int j = 0; j < 8; ++j) {
+                const int idx = i * 512 + lane * 8 + j;
+                if (idx < a.V && t[i][j] > best) { best = t[i][j]; best_idx = idx; }
+            }
     } else {
         const int k = min(a.topk, a.V);
-        // ---- exact kth-largest via 2-pass radix select -------------------------------------
-        for (int x = lane; x < 256; x += 64) hist[x] = 0;
-        __syncthreads();
+        // ---- 1. cheap lower bound L <= kth-largest: the kth largest of the 64 per-lane maxima
+        //         (k distinct elements are >= it).  For k > 64 every element is a candidate.
+        uint32_t L = 0;
+        if (k <= 64) {
+            uint32_t lmax[1] = {0};
 #pragma unroll
-        for (int i = 0; i < ITERS; ++i)
-            if (i < iters)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (i * 512 + lane * 8 + j < a.V) atomicAdd(&hist[order_key(t[i][j]) >> 8], 1);
-        __syncthreads();
-        int b1, k1;
-        radix_pick(hist, k, lane, b1, k1);
-        __syncthreads();
-        for (int x = lane; x < 256; x += 64) hist[x] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < ITERS; ++i)
-            if (i < iters)
+            for (int i = 0; i < ITERS; ++i)
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (i * 512 + lane * 8 + j < a.V) {
-                        const uint32_t key = order_key(t[i][j]);
-                        if ((int)(key >> 8) == b1) atomicAdd(&hist[key & 255], 1);
-                    }
-        __syncthreads();
-        int b2, k2;
-        radix_pick(hist, k1, lane, b2, k2);
-        const uint32_t kth = ((uint32_t)b1 << 8) | (uint32_t)b2;
-        // ---- log_softmax over the kept entries ---------------------------------------------
-        float mx = -INFINITY;
+                    if (i * 512 + lane * 8 + j < a.V) lmax[0] = max(lmax[0], order_key(t[i][j]));
+            L = kth_largest_key<1>(lmax, k);
+        }
+        // ---- 2. compact the candidates (key >= L) into LDS, in index order ---------------------
+        int n = 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
         for (int i = 0; i < ITERS; ++i)
-            if (i < iters)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool keep = (i * 512 + lane * 8 + j < a.V) && order_key(t[i][j]) >= kth;
-                    if (!keep) t[i][j] = -INFINITY;
-                    mx = fmaxf(mx, t[i][j]);
+            for (int j = 0; j < 8; ++j) {
+                const int idx = i * 512 + lane * 8 + j;
+                const bool pred = idx < a.V && order_key(t[i][j]) >= L && t[i][j] == t[i][j];
+                const unsigned long long m = __ballot(pred);
+                if (pred) {
+                    const int o = n + __popcll(m & lt);
+                    cand_t[o] = t[i][j];
+                    cand_i[o] = idx;
                 }
+                n += __popcll(m);
+            }
+        __syncthreads();
+        // ---- 3. exact kth-largest among the candidates -> keep t >= kth (ties kept) -----------
+        uint32_t kth = L;
+        if (n > k) {
+            if (n <= 256) {
+                uint32_t ck[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ck[c] = (c * 64 + lane < n) ? order_key(cand_t[c * 64 + lane]) : 0u;
+                kth = kth_largest_key<4>(ck, k);
+            } else {                                   // rare (k > 64 or massive ties): generic loop
+                uint32_t prefix = 0;
+                for (int bit = 15; bit >= 0; --bit) {
+                    const uint32_t cnd = prefix | (1u << bit);
+                    int cnt = 0;
+                    for (int c = lane; c < ((n + 63) & ~63); c += 64)
+                        cnt += __popcll(__ballot(c < n && order_key(cand_t[c]) >= cnd));
+                    if (cnt >= k) prefix = cnd;
+                }
+                kth = prefix;
+            }
+        }
+        // ---- 4. log_softmax (torch-CPU bf16 rounding points) over the kept candidates ---------
+        float mx = -INFINITY;
+        for (int c = lane; c < n; c += 64) {
+            const float v = cand_t[c];
+            if (order_key(v) >= kth) mx = fmaxf(mx, v);
+        }
         mx = wave_max(mx);
         float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < ITERS; ++i)
-            if (i < iters)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (t[i][j] != -INFINITY) sum += expf(t[i][j] - mx);
+        for (int c = lane; c < n; c += 64) {
+            const float v = cand_t[c];
+            if (order_key(v) >= kth) sum += expf(v - mx);
+        }
         sum = wave_sum(sum);
         const float logsum = round_bf(logf(round_bf(sum)));
-        float mx2 = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < ITERS; ++i)
-            if (i < iters)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (t[i][j] != -INFINITY) {
-                        t[i][j] = round_bf(round_bf(t[i][j] - mx) - logsum);
-                        mx2 = fmaxf(mx2, t[i][j]);
-                    }
-        mx2 = wave_max(mx2);
-        // ---- softmax of the log-probs -------------------------------------------------------
+        const float mx2 = round_bf(0.f - logsum);          // log-prob of the max element: bf16(bf16(mx-mx) - logsum)
         float s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < ITERS; ++i)
-            if (i < iters)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                {
-                    if (t[i][j] != -INFINITY) { t[i][j] = expf(t[i][j] - mx2); s2 += t[i][j]; }
-                    else { t[i][j] = 0.f; }
-                }
+        for (int c = lane; c < n; c += 64) {
+            const float v = cand_t[c];
+            if (order_key(v) >= kth) s2 += expf(round_bf(round_bf(v - mx) - logsum) - mx2);
+        }
         s2 = wave_sum(s2);
-        // ---- argmax(p / q), q ~ Exp(1) -------------------------------------------------------
+        // ---- 5. argmax(p / q), q ~ Exp(1); first index wins ties -------------------------------
         const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
-#pragma unroll
-        for (int i = 0; i < ITERS; ++i)
-            if (i < iters)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int idx = i * 512 + lane * 8 + j;
-                    if (idx >= a.V) continue;
-                    const float p = round_bf(t[i][j] / s2);
-                    float r = 0.f;
-                    if (p > 0.f) {
-                        float q;
-                        if (a.noise) q = bf2f(a.noise[(long)b * a.V + idx]);
-                        else {
-                            const uint4 rnd = philox4x32(make_uint4((uint32_t)idx, (uint32_t)b, (uint32_t)a.codebook, (uint32_t)step),
-                                                         make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32)));
-                            const float u = ((float)rnd.x + 0.5f) * 2.3283064365386963e-10f;   // (0,1]
-                            q = round_bf(-logf(u));
-                            if (!(q > 0.f)) q = 1e-30f;
-                        }
-                        r = round_bf(p / q);
-                    }
-                    if (r > best) { best = r; best_idx = idx; }
-                }
+        for (int c = lane; c < n; c += 64) {
+            const float v = cand_t[c];
+            if (order_key(v) < kth) continue;
+            const int idx = cand_i[c];
+            const float p = round_bf(expf(round_bf(round_bf(v - mx) - logsum) - mx2) / s2);
+            if (!(p > 0.f)) continue;
+            float q;
+            if (a.noise) q = bf2f(a.noise[(long)b * a.V + idx]);
+            else {
+                const uint4 rnd = philox4x32(make_uint4((uint32_t)idx, (uint32_t)b, (uint32_t)a.codebook, (uint32_t)step),
+                                             make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32)));
+                const float u = ((float)rnd.x + 0.5f) * 2.3283064365386963e-10f;   // (0,1]
+                q = round_bf(-logf(u));
+                if (!(q > 0.f)) q = 1e-30f;
+            }
+            const float r = round_bf(p / q);
+            if (r > best || (r == best && idx < best_idx)) { best = r; best_idx = idx; }
+        }
     }
     // wave argmax, lowest index on ties
 #pragma unroll

@@ -79,6 +79,7 @@ MIMI_SIGNATURES = {
     "mimi_destroy": (None, [_vp]),
     "mimi_last_error": (C.c_char_p, [_vp]),
     "mimi_decode": (_i, [_vp, _vp, _i, _i, _l, _l, _vp, _i, _vp]),
+    "mimi_decode_strided": (_i, [_vp, _vp, _i, _i, _l, _l, _l, _vp, _i, _vp]),
     "mimi_reset_stream": (_i, [_vp, _vp]),
 }
 

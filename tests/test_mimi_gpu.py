@@ -1,0 +1,118 @@
+"""Mimi decode parity: HIP path (sesameai.mimi.MimiCodec -> include/mimi_hip.h) vs the oracle
+(oracle/mimi_ref.py) and the committed golden PCM.  fp32 both sides; the only freedom is the
+fp32 summation order inside a dot product, so the tolerance is 2e-4 of the clip's peak."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REL_TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def tiny_codec():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import mimi_ref as M
+    from sesameai.mimi import MimiCodec, mimi_tiny_args, synthetic_state_dict
+    s = M.mimi_tiny()
+    w = M.make_weights(s, seed=4321)
+    sd = synthetic_state_dict(mimi_tiny_args(), seed=4321)
+    assert set(w) == set(sd) and all(torch.equal(w[k], sd[k]) for k in w), "product and oracle synthetic Mimi weights differ"
+    return s, w, MimiCodec(mimi_tiny_args(), sd, max_frames=64)
+
+
+def _close(got, want, what):
+    got, want = got.detach().cpu().float(), want.detach().cpu().float()
+    assert got.shape == want.shape, f"{what}: {tuple(got.shape)} vs {tuple(want.shape)}"
+    peak = want.abs().max().item()
+    err = (got - want).abs().max().item()
+    print(f"{what}: max|d|={err:.3g} peak={peak:.3g} rel={err / peak:.2g}")
+    assert err <= REL_TOL * peak, f"{what}: max abs err {err} vs peak {peak}"
+
+
+def test_tiny_decode_vs_oracle_and_golden(tiny_codec):
+    from oracle import mimi_ref as M
+    s, w, codec = tiny_codec
+    gold = torch.load(os.path.join(GOLD, "mimi_tiny.pt"))
+    pcm = codec.decode(gold["codes"])
+    assert pcm.shape == (1, 1, 1920 * gold["codes"].shape[-1]) and pcm.dtype == torch.float32
+    _close(pcm, gold["pcm"], "tiny whole decode vs golden")
+    codes = torch.randint(0, 2048, (3, 32, 7), generator=torch.Generator().manual_seed(4))
+    _close(codec.decode(codes), M.decode(s, w, codes), "tiny batch-3 decode vs oracle")
+
+
+def test_stateless_chunks_match_reference_stream_semantics(tiny_codec):
+    """generate_stream decodes every 10-frame buffer independently (generator.py:111-117)."""
+    s, w, codec = tiny_codec
+    gold = torch.load(os.path.join(GOLD, "mimi_tiny.pt"))
+    codes = gold["codes"]
+    got = torch.cat([codec.decode(codes[..., t:t + 10]) for t in range(0, codes.shape[-1], 10)], dim=-1)
+    _close(got[..., ::16], gold["chunks_stride16"], "stateless 10-frame chunks vs golden")
+
+
+def test_stateful_stream_equals_whole_decode(tiny_codec):
+    """property: Mimi decode is strictly causal, so a stateful stream in ragged chunks
+    (1, 2, 10, 3, ... frames) reproduces the whole-utterance decode."""
+    s, w, codec = tiny_codec
+    codes = torch.randint(0, 2048, (1, 32, 23), generator=torch.Generator().manual_seed(6))
+    whole = codec.decode(codes)
+    codec.reset_stream()
+    outs, t = [], 0
+    for n in (1, 2, 10, 3, 1, 6):
+        outs.append(codec.decode_stream(codes[..., t:t + n])); t += n
+    stream = torch.cat(outs, dim=-1)
+    err = (stream - whole).abs().max().item()
+    print(f"stateful stream vs whole: max|d|={err:.3g}")
+    assert err <= 1e-5 * whole.abs().max().item()
+
+
+def test_codes_beyond_codebook_are_clamped(tiny_codec):
+    """CSM's audio vocab is 2051 but Mimi's codebooks hold 2048 entries: the reference would
+    raise inside F.embedding; the HIP path clamps (documented in include/mimi_hip.h)."""
+    s, w, codec = tiny_codec
+    codes = torch.randint(0, 2048, (1, 32, 4), generator=torch.Generator().manual_seed(8))
+    hi = codes.clone(); hi[0, 5, 2] = 2050
+    cl = codes.clone(); cl[0, 5, 2] = 2047
+    assert torch.equal(codec.decode(hi), codec.decode(cl))
+
+
+def test_full_size_decode_vs_golden():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sesameai.mimi import MimiArgs, MimiCodec, synthetic_state_dict
+    gold = torch.load(os.path.join(GOLD, "mimi_full.pt"))
+    codec = MimiCodec(MimiArgs(), synthetic_state_dict(MimiArgs(), seed=int(gold["weight_seed"])), max_frames=32)
+    pcm = codec.decode(gold["codes"])
+    _close(pcm[..., ::16], gold["pcm_stride16"], "full-size decode vs golden (every 16th sample)")
+    _close(pcm[..., :4096], gold["pcm_head"], "full-size head")
+    _close(pcm[..., -4096:], gold["pcm_tail"], "full-size tail")
+    got = torch.cat([codec.decode(gold["codes"][..., t:t + 10]) for t in range(0, gold["codes"].shape[-1], 10)], dim=-1)
+    _close(got[..., ::16], gold["chunks_stride16"], "full-size stateless chunks")
+
+
+def test_generator_end_to_end_tiny(tiny_codec):
+    """Generator.generate / generate_stream keep the reference's shapes: (n*1920,) fp32 audio."""
+    from sesameai.generator import Generator, Segment
+    from sesameai.models import Model, csm_tiny_args
+    s, w, codec = tiny_codec
+    model = Model(csm_tiny_args(), None, max_frames=64, max_prefill_rows=128)
+    gen = Generator(model, audio_tokenizer=codec)
+    g = torch.Generator().manual_seed(1)
+    ctx = [Segment(speaker=1, text=torch.randint(0, 1000, (5,), generator=g).tolist(),
+                   audio_codes=torch.randint(0, 2048, (32, 6), generator=g))]
+    text = torch.randint(0, 1000, (4,), generator=g).tolist()
+    model.seed(3)
+    audio = gen.generate(text, 1, ctx, max_audio_length_ms=960, temperature=0.9, topk=50)
+    assert audio.dim() == 1 and audio.shape[0] == 12 * 1920 and audio.dtype == torch.float32
+    assert torch.isfinite(audio).all() and gen.sample_rate == 24000
+    model.seed(3)
+    chunks = list(gen.generate_stream(text, 1, ctx, max_audio_length_ms=960, temperature=0.9, topk=50))
+    assert [c.shape[0] for c in chunks] == [19200, 2 * 1920]
+    # same seed -> same codes; first chunk of the stream == first 10 frames decoded statelessly
+    first = codec.decode(gen._model.read_frames(1)[0][:10].permute(1, 2, 0).contiguous())
+    assert torch.allclose(chunks[0], first.reshape(-1).to(chunks[0].device))
+    with pytest.raises(ValueError, match="Inputs too long"):
+        gen.generate(list(range(300)), 1, [], max_audio_length_ms=150_000)
