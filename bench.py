@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--topk", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=24)
+    ap.add_argument("--cpu-frames", type=int, default=64)
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle frames to time")
     ap.add_argument("--cpu-threads", type=int, default=min(32, os.cpu_count() or 1))
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)

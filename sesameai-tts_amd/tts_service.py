@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""CLI with the reference's surface (reference: tts_service.py): class ``TTS`` with
+``load_model / list_voices / load_voice / generate_with_context / generate_audio_segment /
+export_wav`` and the flags ``-d/--device  -v/--voice  text  --output  --temp  --topk``.
+
+Only the hot path is re-implemented: generation runs on the MI355X kernels through
+``sesameai.generator``.  Host-side audio post-processing that the reference does with pydub
+(peak-normalise -> int16, 500 ms lead / 100 ms tail silence, 50 ms fades, tts_service.py:288-306)
+is done with NumPy and the stdlib ``wave`` module; playback, watermarking and the WAV/resample
+loading of voice prompts are out of scope -- voices are loaded from
+pre-tokenised prompt files (``<voice>.pt`` holding ``[(text | token ids, codes[32,T]), ...]``).
+"""
+import argparse
+import os
+import re
+import sys
+import time
+import wave
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+from sesameai.generator import Segment, load_csm_1b  # noqa: E402  (same import line as the reference, tts_service.py:22)
+
+
+def discover_voices(voice_dir: str) -> dict:
+    if not os.path.isdir(voice_dir):
+        return {}
+    return {os.path.splitext(f)[0]: os.path.join(voice_dir, f) for f in sorted(os.listdir(voice_dir)) if f.endswith(".pt")}
+
+
+class TTS:
+    """reference: tts_service.py:44-525."""
+
+    voice_name = None
+    voice_data = None
+
+    def __init__(self, device: str = "cuda", model_repo: str = "sesame/csm-1b", voice_dir: Optional[str] = None) -> None:
+        self.device = device
+        self.model_repo = model_repo
+        self.generator = None
+        self.cached_context_tokens: List[torch.Tensor] = []
+        self.cached_context_masks: List[torch.Tensor] = []
+        self.voices = discover_voices(voice_dir or os.environ.get("CSM_VOICE_DIR", os.path.join(HERE, "voices")))
+
+    def load_model(self) -> None:
+        print("Open Sesame...")
+        self.generator = load_csm_1b(self.device)
+
+    def list_voices(self) -> list:
+        return list(self.voices.keys())
+
+    def load_voice(self, voice_name: str) -> None:
+        if voice_name not in self.voices:
+            raise ValueError(f"Voice '{voice_name}' not found. Available voices: {list(self.voices.keys())}")
+        if not self.generator:
+            raise ValueError("Model not loaded. Call load_model() first.")
+        self.cached_context_tokens, self.cached_context_masks = [], []
+        self.voice_name = voice_name
+        self.voice_data = torch.load(self.voices[voice_name])
+        for text, codes in self.voice_data:                    # reference: _prepare_context :121-139
+            tokens, masks = self.generator._tokenize_segment(Segment(speaker=1, text=text, audio_codes=codes))
+            self.cached_context_tokens.append(tokens)
+            self.cached_context_masks.append(masks)
+        self.generate_audio_segment("I'm getting all warmed up for our chatting to begin.")   # warm-up, :119
+
+    @torch.inference_mode()
+    def generate_with_context(self, prompt, speaker: int = 1, max_audio_length_ms: float = 60_000,
+                              temperature: float = 0.9, topk: int = 50) -> torch.Tensor:
+        """reference: tts_service.py:170-258 (minus the watermark)."""
+        g = self.generator
+        gen_tokens, gen_masks = g._tokenize_text_segment(prompt, speaker)
+        prompt_tokens = torch.cat(self.cached_context_tokens + [gen_tokens], dim=0).long().to(g.device)
+        prompt_mask = torch.cat(self.cached_context_masks + [gen_masks], dim=0).bool().to(g.device)
+        max_audio_frames = int(max_audio_length_ms / 80)
+        max_seq_len = 2048 - max_audio_frames
+        if prompt_tokens.size(0) >= max_seq_len:
+            raise ValueError(f"Input too long ({prompt_tokens.size(0)} tokens). Maximum is {max_seq_len} tokens.")
+        frames = g.generate_codes(prompt_tokens, prompt_mask, max_audio_frames, temperature, topk)
+        return g._decode_frames(frames)
+
+    def generate_audio_segment(self, prompt, fade_duration: int = 50, start_silence_duration: int = 500,
+                               end_silence_duration: int = 100, temperature: float = 0.8, topk: int = 40) -> np.ndarray:
+        """-> int16 mono PCM @ generator.sample_rate (the reference returns a pydub AudioSegment
+        holding the same samples, tts_service.py:260-308)."""
+        audio = self.generate_with_context(prompt, speaker=1, max_audio_length_ms=30_000, temperature=temperature, topk=topk)
+        audio = audio.to(torch.float32).reshape(-1)
+        audio = audio / max(float(audio.abs().max()) if audio.numel() else 0.0, 1e-6)
+        pcm = (audio.cpu().numpy() * 32767).astype("int16")
+        sr = self.generator.sample_rate
+        pcm = np.concatenate([np.zeros(sr * start_silence_duration // 1000, np.int16), pcm,
+                              np.zeros(sr * end_silence_duration // 1000, np.int16)])
+        n = min(sr * fade_duration // 1000, len(pcm) // 2)
+        if n > 0:
+            ramp = np.linspace(0.0, 1.0, n, dtype=np.float32)
+            pcm[:n] = (pcm[:n] * ramp).astype(np.int16)
+            pcm[-n:] = (pcm[-n:] * ramp[::-1]).astype(np.int16)
+        return pcm
+
+    def export_wav(self, text: str, output_filename: str, fallback_duration: int = 1000, max_retries: int = 2,
+                   temperature: float = 0.8, topk: int = 40) -> None:
+        """reference: tts_service.py:472-525."""
+        sentences = [s for s in re.split(r"(?<=[.!?])\s+", text) if s.strip()]
+        sr = self.generator.sample_rate
+        segments = []
+        t0 = time.time()
+        for sentence in sentences:
+            seg, retries = None, 0
+            while retries <= max_retries:
+                try:
+                    print(f"Export: Generating audio for sentence: {sentence} (Attempt {retries + 1})")
+                    seg = self.generate_audio_segment(sentence, temperature=temperature, topk=topk)
+                    break
+                except Exception as e:  # noqa: BLE001 -- same retry policy as the reference
+                    retries += 1
+                    print(f"Export: Error for sentence: {sentence} (Attempt {retries}): {e}")
+            if seg is None:
+                print(f"Export: Using fallback for sentence: {sentence}")
+                seg = np.zeros(sr * fallback_duration // 1000, np.int16)
+            segments.append(seg)
+        if not segments:
+            print("No audio segments to export")
+            return
+        combined = np.concatenate(segments)
+        with wave.open(output_filename, "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(sr)
+            f.writeframes(combined.tobytes())
+        secs = len(combined) / sr
+        print(f"Export complete: {secs:.2f} seconds of audio, RTF {secs / max(time.time() - t0, 1e-9):.2f}x")
+
+
+def main():
+    parser = argparse.ArgumentParser(description="SesameAI CSM-1B Text-to-Speech (MI355X build)")
+    parser.add_argument("-d", "--device", type=str, default="cuda", help="Device to run on (cuda)")
+    parser.add_argument("-v", "--voice", type=str, default=None, help="Voice to use (a <voice>.pt prompt file in the voice dir)")
+    parser.add_argument("text", type=str, nargs="?", help="Text to synthesize")
+    parser.add_argument("--output", type=str, default="output.wav", help="Output filename")
+    parser.add_argument("--temp", "--temperature", type=float, default=0.8, dest="temp")
+    parser.add_argument("--topk", type=int, default=40)
+    args = parser.parse_args()
+    if args.device == "cpu":
+        parser.error("this build runs the hot path on MI355X only; there is no -d cpu path (use the reference)")
+    tts = TTS(device=args.device)
+    tts.load_model()
+    if args.voice:
+        tts.load_voice(args.voice)
+    if not args.text:
+        parser.error("interactive playback mode is out of scope; pass the text to synthesize")
+    tts.export_wav(args.text, args.output, temperature=args.temp, topk=args.topk)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,6 @@
 """Mimi decode parity: HIP path (sesameai.mimi.MimiCodec -> include/mimi_hip.h) vs the oracle
 (oracle/mimi_ref.py) and the committed golden PCM.  fp32 both sides; the only freedom is the
-fp32 summation order inside a dot product, so the tolerance is 2e-4 of the clip's peak."""
+fp32 summation order inside a dot product, so the tolerance is 2e-5 of the clip's peak."""
 import os
 
 import pytest
@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-REL_TOL = 2e-4
+REL_TOL = 2e-5
 
 
 @pytest.fixture(scope="module")
