@@ -26,6 +26,13 @@ int csm_op_gemv(int kind, int M, int K, int N, const void* x, long x_row_stride,
 int csm_op_attn(int M, int rows_per_seq, int H, int KV, int head_dim, int smax, int nsplit, const void* q,
                 const void* kcache, const void* vcache, const int32_t* pos, void* out, float* part, void* stream);
 
+/* Depth-decoder layer step "attention + output projection + residual" as ONE kernel (head_dim
+ * 128, <= 32 cached keys): out[m] = resid[m] + Wo . SDPA(q[m], K[0..pos[m]], V[0..pos[m]]).
+ * wo [N][H*128], resid/out [M][N] (may alias).                                               */
+int csm_op_attn_oproj(int M, int rows_per_seq, int H, int KV, int smax, const void* q, const void* kcache,
+                      const void* vcache, const int32_t* pos, const void* wo, int N, const void* resid, void* out,
+                      void* stream);
+
 /* masked 33-slot embedding sum (sesameai/models.py:155-157,193-203). */
 int csm_op_embed_sum(int M, int ncb, int d, int audio_vocab, int text_vocab, const int32_t* tokens,
                      const uint8_t* mask, const void* text_emb, const void* audio_emb, void* h, void* stream);

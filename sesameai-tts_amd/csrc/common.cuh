@@ -36,15 +36,32 @@ __device__ __forceinline__ float dot8(const uint4& a, const uint4& b, float acc)
     return acc;
 }
 
+// Wave64 reductions on the DPP network (no LDS round trip like ds_bpermute): butterflies inside
+// each row of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror), then row_bcast:15 /
+// row_bcast:31 carry the row sums upward, so the total lands in row 3 and is broadcast from
+// lane 63 through an SGPR.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    v += dpp_f<0xB1, 0xF>(0.f, v);       // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E, 0xF>(0.f, v);       // quad_perm [2,3,0,1]
+    v += dpp_f<0x141, 0xF>(0.f, v);      // row_half_mirror
+    v += dpp_f<0x140, 0xF>(0.f, v);      // row_mirror
+    v += dpp_f<0x142, 0xA>(0.f, v);      // row_bcast:15 -> rows 1,3
+    v += dpp_f<0x143, 0xC>(0.f, v);      // row_bcast:31 -> rows 2,3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
-    return v;
+    v = fmaxf(v, dpp_f<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_f<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_f<0x141, 0xF>(v, v));
+    v = fmaxf(v, dpp_f<0x140, 0xF>(v, v));
+    v = fmaxf(v, dpp_f<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_f<0x143, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // streamed-once weight load: non-temporal keeps the 1.9 GB backbone stream from evicting

@@ -7,6 +7,7 @@
 // (sesameai/generator.py:283-294).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -30,7 +31,7 @@ struct Stack {
     int hd, nq, nkv, cache_len;
     bf16_t *kc, *vc;            // [L][B][KV][cache_len][hd]
     long layer_stride;          // elements per layer
-    int nt;                     // stream weights non-temporally
+    int nt_attn, nt_mlp;        // cache policy of the q/k/v/o and of the gate/up/down weight streams
 };
 
 struct CsmModel {
@@ -50,6 +51,7 @@ struct CsmModel {
     uint64_t* rng;
     int *pf_tokens, *pf_pos;            // staging for csm_prefill inputs is the caller's memory
     int host_frames;                    // frames launched since reset (host mirror)
+    int fuse_dec_attn;                  // depth-decoder attention fused into the O-projection (env CSM_FUSE_DEC_ATTN=0 disables)
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
     int last_S;                         // rows per sequence of the h buffer feeding csm_depth
     int host_pos_max;                   // host mirror of max position (overflow guard)
@@ -84,7 +86,7 @@ static hipError_t launch_gemv_mt(const GemvArgs& a, int units, hipStream_t st) {
     const int blocks = (units + 3) / 4;
     int mt = a.M >= 3 ? 4 : (a.M == 2 ? 2 : 1);
     if (KITERS >= 16 && mt > 2) mt = 2;                     // keep the x tile <= 32 KB of LDS
-    const size_t smem = (size_t)mt * KITERS * 512 * 2 + 64;
+    const size_t smem = (size_t)mt * KITERS * 512 * 2 + 64 + (PRO == PRO_ATTN ? 4 * 64 * 4 : 0);
     switch (mt) {
         case 1: hipLaunchKernelGGL((k_gemv<1, KITERS, R, PRO, EPI, HD>), dim3(blocks), dim3(256), smem, st, a); break;
         case 2: hipLaunchKernelGGL((k_gemv<2, KITERS, R, PRO, EPI, HD>), dim3(blocks), dim3(256), smem, st, a); break;
@@ -93,7 +95,8 @@ static hipError_t launch_gemv_mt(const GemvArgs& a, int units, hipStream_t st) {
     return hipGetLastError();
 }
 
-// kind: 0 = plain store, 1 = plain + residual, 2 = norm + store (head), 3 = norm + qkv/rope, 4 = norm + swiglu
+// kind: 0 = plain store, 1 = plain + residual, 2 = norm + store (head), 3 = norm + qkv/rope, 4 = norm + swiglu,
+//       5 = fused depth-decoder attention + residual (hd 128, <= 32 keys)
 static hipError_t launch_gemv(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
     if (K % 512 != 0) return hipErrorInvalidValue;
     const int ki = K / 512;
@@ -106,6 +109,7 @@ static hipError_t launch_gemv(int kind, int K, int hd, const GemvArgs& a, hipStr
             case 3: return hd == 64 ? launch_gemv_mt<KI, 2, PRO_NORM, EPI_QKV_ROPE, 64>(a, (a.N + 1) / 2, st)   \
                                     : launch_gemv_mt<KI, 2, PRO_NORM, EPI_QKV_ROPE, 128>(a, (a.N + 1) / 2, st); \
             case 4: return launch_gemv_mt<KI, RG, PRO_NORM, EPI_SWIGLU, 64>(a, (a.N + RG / 2 - 1) / (RG / 2), st); \
+            case 5: return launch_gemv_mt<KI, RS, PRO_ATTN, EPI_RESID, 64>(a, (a.N + RS - 1) / RS, st);        \
         }                                                                                                       \
         return hipErrorInvalidValue;
     switch (ki) {
@@ -134,7 +138,7 @@ static hipError_t launch_attn(int hd, const AttnArgs& a, hipStream_t st) {
 // one Llama stack over M token rows (in place on h)
 // ---------------------------------------------------------------------------------------
 static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t* att, bf16_t* act,
-                            int M, int rows_per_seq, const int* pos, hipStream_t st) {
+                            int M, int rows_per_seq, const int* pos, int pos_base, hipStream_t st) {
     const int d = S.d.dim;
     int nsplit = 1;
     if (&S == &m->bb && M <= PART_ROWS) {
@@ -148,36 +152,43 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
         bf16_t* vc = S.vc + (long)l * S.layer_stride;
         GemvArgs a;
         memset(&a, 0, sizeof a);
-        a.nt = S.nt;
+        a.nt = S.nt_attn;
         // (1) RMSNorm -> q/k/v projections -> RoPE -> KV append
         a.x = h; a.x_row_stride = d; a.M = M;
         a.norm_scale = (const bf16_t*)w.sa_norm; a.eps = S.d.norm_eps;
         a.w0 = (const bf16_t*)w.wq; a.w1 = (const bf16_t*)w.wk; a.w2 = (const bf16_t*)w.wv;
         a.N = S.nq + 2 * S.nkv; a.out = q; a.ldo = S.nq;
         a.nq = S.nq; a.nkv = S.nkv; a.smax = S.cache_len; a.rows_per_seq = rows_per_seq; a.kv_heads = S.d.n_kv_heads;
-        a.pos = pos; a.rope = S.rope; a.kcache = kc; a.vcache = vc;
+        a.pos = pos; a.pos_base = pos_base; a.rope = S.rope; a.kcache = kc; a.vcache = vc;
         if ((e = launch_gemv(3, d, S.hd, a, st)) != hipSuccess) return e;
-        // (2) attention over keys [0, pos]
-        AttnArgs t;
-        t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
-        t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = nsplit;
-        t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
-        if ((e = launch_attn(S.hd, t, st)) != hipSuccess) return e;
-        // (3) output projection + residual
+        const bool fuse_attn = S.hd == 128 && S.cache_len <= 32 && m->fuse_dec_attn && (S.d.n_heads / S.d.n_kv_heads) % 2 == 0;
+        if (!fuse_attn) {
+            // (2) attention over keys [0, pos]
+            AttnArgs t;
+            t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
+            t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = nsplit;
+            t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
+            if ((e = launch_attn(S.hd, t, st)) != hipSuccess) return e;
+        }
+        // (3) output projection + residual (depth decoder: attention fused into its prologue)
         memset(&a, 0, sizeof a);
-        a.nt = S.nt;
+        a.nt = S.nt_attn;
         a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)w.wo; a.N = d;
         a.out = h; a.ldo = d; a.resid = h;
-        if ((e = launch_gemv(1, S.nq, S.hd, a, st)) != hipSuccess) return e;
+        if (fuse_attn) {
+            a.aq = q; a.aH = S.d.n_heads; a.ascale = 1.0f / sqrtf((float)S.hd); a.kcache = kc; a.vcache = vc;
+            a.pos = pos; a.pos_base = pos_base; a.smax = S.cache_len; a.rows_per_seq = rows_per_seq; a.kv_heads = S.d.n_kv_heads;
+        }
+        if ((e = launch_gemv(fuse_attn ? 5 : 1, S.nq, S.hd, a, st)) != hipSuccess) return e;
         // (4) RMSNorm -> gate/up -> SiLU*up
         memset(&a, 0, sizeof a);
-        a.nt = S.nt;
+        a.nt = S.nt_mlp;
         a.x = h; a.x_row_stride = d; a.M = M; a.norm_scale = (const bf16_t*)w.mlp_norm; a.eps = S.d.norm_eps;
         a.w0 = (const bf16_t*)w.w1; a.w1 = (const bf16_t*)w.w3; a.N = S.d.ffn; a.out = act; a.ldo = S.d.ffn;
         if ((e = launch_gemv(4, d, S.hd, a, st)) != hipSuccess) return e;
         // (5) down projection + residual
         memset(&a, 0, sizeof a);
-        a.nt = S.nt;
+        a.nt = S.nt_mlp;
         a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)w.w2; a.N = d;
         a.out = h; a.ldo = d; a.resid = h;
         if ((e = launch_gemv(1, S.d.ffn, S.hd, a, st)) != hipSuccess) return e;
@@ -207,8 +218,9 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             a.x = cb == 1 ? m->dec_in : m->dec_in1; a.x_row_stride = dbb; a.M = rows;
             a.w0 = (const bf16_t*)m->w.projection; a.N = dd; a.out = m->hdec; a.ldo = dd; a.nt = 0;
             if ((e = launch_gemv(0, dbb, 0, a, st)) != hipSuccess) return e;
-            const int* pos = m->dec_pos + (long)(cb == 1 ? 0 : cb) * 2 * m->max_batch;
-            if ((e = run_stack(m, m->dec, m->hdec, m->qd, m->attd, m->actd, rows, cb == 1 ? 2 : 1, pos, st)) != hipSuccess) return e;
+            // decoder positions are static per step: rows (0,1) on the first call, then cb
+            const int* pos = m->fuse_dec_attn ? nullptr : m->dec_pos + (long)(cb == 1 ? 0 : cb) * 2 * m->max_batch;
+            if ((e = run_stack(m, m->dec, m->hdec, m->qd, m->attd, m->actd, rows, cb == 1 ? 2 : 1, pos, cb == 1 ? 0 : cb, st)) != hipSuccess) return e;
         }
         // final RMSNorm + head -> logits (bf16, padded rows)
         memset(&a, 0, sizeof a);
@@ -268,9 +280,9 @@ __global__ void k_copy_step_inputs(const int* tokens, const uint8_t* mask, const
 // C ABI
 // ---------------------------------------------------------------------------------------
 static void init_stack(Stack& S, const CsmLlamaDims& d, const CsmLayerWeights* lw, const void* norm, const void* rope,
-                       int cache_len, int nt) {
+                       int cache_len, int nt_attn, int nt_mlp) {
     S.d = d; S.lw = lw; S.final_norm = (const bf16_t*)norm; S.rope = (const bf16_t*)rope;
-    S.hd = d.dim / d.n_heads; S.nq = d.n_heads * S.hd; S.nkv = d.n_kv_heads * S.hd; S.cache_len = cache_len; S.nt = nt;
+    S.hd = d.dim / d.n_heads; S.nq = d.n_heads * S.hd; S.nkv = d.n_kv_heads * S.hd; S.cache_len = cache_len; S.nt_attn = nt_attn; S.nt_mlp = nt_mlp;
 }
 
 extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_batch, int max_rows, int max_frames,
@@ -294,8 +306,19 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     m->ldl = ((cfg->audio_vocab + 511) / 512) * 512;
     m->gexec = nullptr; m->graph = nullptr; m->g_B = -1; m->cap_stream = nullptr;
     m->host_frames = 0; m->have_last = false; m->last_S = 1; m->host_pos_max = 0;
-    init_stack(m->bb, cfg->backbone, m->w.bb, w->bb_norm, w->bb_rope, cfg->backbone.max_seq, 1);
-    init_stack(m->dec, cfg->decoder, m->w.dec, w->dec_norm, w->dec_rope, cfg->n_codebooks, 0);
+    { const char* ev = getenv("CSM_FUSE_DEC_ATTN"); m->fuse_dec_attn = !(ev && ev[0] == '0'); }
+    // Cache policy (measured, tools/microbench/gemv_bench.hip): a depth-decoder step touches
+    // ~230 MB, about the size of the 256 MB Infinity Cache, so with default-policy loads the
+    // 31-step cycle thrashes it and even the 2-3 MB q/k/v/o streams come from HBM (4.9 us per
+    // launch vs 3.3 us when resident).  Stream everything that is large or used once per frame
+    // non-temporally (backbone, decoder gate/up/down, heads) and keep only the small
+    // latency-critical decoder attention weights + the projection resident.
+    {
+        const char* ev = getenv("CSM_DEC_MLP_NT");
+        const int dec_mlp_nt = (ev && ev[0] == '1');   // measured: default policy is faster for the decoder MLP (4.24 vs 4.41 ms/frame)
+        init_stack(m->bb, cfg->backbone, m->w.bb, w->bb_norm, w->bb_rope, cfg->backbone.max_seq, 1, 1);
+        init_stack(m->dec, cfg->decoder, m->w.dec, w->dec_norm, w->dec_rope, cfg->n_codebooks, 0, dec_mlp_nt);
+    }
     const int ncb = cfg->n_codebooks, dbb = cfg->backbone.dim, dd = cfg->decoder.dim;
 #define ALLOC(ptr, bytes) HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&(ptr), (bytes)))
     m->bb.layer_stride = (long)max_batch * cfg->backbone.n_kv_heads * m->bb.cache_len * m->bb.hd;
@@ -380,7 +403,7 @@ extern "C" int csm_prefill(csm_handle m, const int32_t* tokens, const uint8_t* m
         return fail(m, CSM_E_INVALID, "csm_prefill: B/S outside the limits given to csm_create");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(m, launch_embed(m, tokens, mask, B * S, st));
-    HIPCHK(m, run_stack(m, m->bb, m->h, m->q, m->att, m->act, B * S, S, pos, st));
+    HIPCHK(m, run_stack(m, m->bb, m->h, m->q, m->att, m->act, B * S, S, pos, 0, st));
     hipLaunchKernelGGL(k_set_prefill_state, dim3(1), dim3(64), 0, st, pos, B, S, m->cur_pos);
     HIPCHK(m, hipGetLastError());
     m->have_last = true; m->last_S = S;
@@ -412,7 +435,7 @@ extern "C" int csm_copy_frame(csm_handle m, int B, int32_t* out_frame, void* str
 static hipError_t enqueue_frame(CsmModel* m, int B, float temperature, int topk, hipStream_t st) {
     hipError_t e;
     if ((e = launch_embed(m, m->cur_tokens, m->cur_mask, B, st)) != hipSuccess) return e;
-    if ((e = run_stack(m, m->bb, m->h, m->q, m->att, m->act, B, 1, m->cur_pos, st)) != hipSuccess) return e;
+    if ((e = run_stack(m, m->bb, m->h, m->q, m->att, m->act, B, 1, m->cur_pos, 0, st)) != hipSuccess) return e;
     if ((e = run_depth(m, B, 1, temperature, topk, nullptr, nullptr, nullptr, st)) != hipSuccess) return e;
     return launch_advance(m, B, nullptr, 1, st);
 }
@@ -514,6 +537,20 @@ extern "C" int csm_op_attn(int M, int rows_per_seq, int H, int KV, int head_dim,
     t.scale = 1.0f / sqrtf((float)head_dim); t.out = (bf16_t*)out; t.part = part;
     hipError_t e = launch_attn(head_dim, t, (hipStream_t)stream);
     if (e != hipSuccess) { g_create_err = std::string("csm_op_attn: ") + hipGetErrorString(e); return CSM_E_HIP; }
+    return CSM_OK;
+}
+
+extern "C" int csm_op_attn_oproj(int M, int rows_per_seq, int H, int KV, int smax, const void* q, const void* kcache,
+                                 const void* vcache, const int32_t* pos, const void* wo, int N, const void* resid, void* out,
+                                 void* stream) {
+    if (smax > 32) return CSM_E_INVALID;
+    GemvArgs a;
+    memset(&a, 0, sizeof a);
+    a.M = M; a.w0 = (const bf16_t*)wo; a.N = N; a.out = (bf16_t*)out; a.ldo = N; a.resid = (const bf16_t*)resid;
+    a.aq = (const bf16_t*)q; a.aH = H; a.ascale = 1.0f / sqrtf(128.f); a.kcache = (bf16_t*)kcache; a.vcache = (bf16_t*)vcache;
+    a.pos = pos; a.smax = smax; a.rows_per_seq = rows_per_seq; a.kv_heads = KV;
+    hipError_t e = launch_gemv(5, H * 128, 128, a, (hipStream_t)stream);
+    if (e != hipSuccess) { g_create_err = std::string("csm_op_attn_oproj: ") + hipGetErrorString(e); return CSM_E_HIP; }
     return CSM_OK;
 }
 

@@ -15,7 +15,7 @@
 #pragma once
 #include "common.cuh"
 
-enum { PRO_PLAIN = 0, PRO_NORM = 1 };
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_ATTN = 2 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV_ROPE = 2, EPI_SWIGLU = 3 };
 
 struct GemvArgs {
@@ -44,53 +44,185 @@ struct GemvArgs {
     const bf16_t* rope;         // [max_seq][HD/2][2]
     bf16_t* kcache;             // [B][KV][smax][HD] (this layer)
     bf16_t* vcache;
+    // PRO_ATTN (depth decoder: hd 128, <= 32 keys): the activation row IS the attention output of
+    // q [M][aH*128] over keys [0,pos[m]] of kcache/vcache, computed in the prologue
+    const bf16_t* aq;
+    int aH;
+    float ascale;
+    int pos_base;               // used when pos == nullptr
 };
+
+// Depth-decoder attention fused into the output projection's prologue (hd = 128, at most 32
+// keys: the decoder cache holds one frame's codebooks, sesameai/models.py:127).  Replaces a
+// separate launch per layer per decoder step (124 per frame).  Every block recomputes the
+// <= 32 KB of K/V reads from L2; wave w handles heads w, w+4, ...  Two lanes per key for
+// q.k (64 elements each), the softmax over the 32 key slots is a wave reduction, then each
+// lane accumulates two output elements over the keys.  Rounded to bf16 once, like SDPA.
+__device__ __forceinline__ int row_pos(const GemvArgs& a, long mrow) {
+    // decoder positions are compile-time per step: pos == nullptr -> pos_base + row-in-sequence,
+    // which removes a dependent global load from the critical path
+    int p = a.pos ? a.pos[mrow] : a.pos_base + (int)(mrow % a.rows_per_seq);
+    return p < 0 ? 0 : (p >= a.smax ? a.smax - 1 : p);
+}
+
+// sum over the 16 lanes of a DPP row (result in every lane of the row)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1, 0xF>(0.f, v);
+    v += dpp_f<0x4E, 0xF>(0.f, v);
+    v += dpp_f<0x141, 0xF>(0.f, v);
+    v += dpp_f<0x140, 0xF>(0.f, v);
+    return v;
+}
+
+// Layout (all loads coalesced and issued up front): the KV head's K tile (32 keys x 128 = 8 KB,
+// contiguous in the cache) is fetched as 8 x 1 KB wave loads, so lane l holds 16-byte pieces of
+// keys 4i + l/16 (i = 0..7) at element offset 8*(l%16); with the matching 8 elements of q the
+// q.k dot is 8 partials per lane, each finished by a 4-step DPP row reduction.  The softmax
+// runs on those 8 scores per lane (every key replicated over 16 lanes).  P then goes through
+// LDS (32 floats per head) and each lane accumulates two output columns over the keys from
+// contiguous 256-byte V rows.  Two heads of one KV group are processed together.
+template <int MT, int KITERS>
+__device__ __forceinline__ void stage_attn(bf16_t* xs, float* ps /*[4 waves][2][32]*/, const GemvArgs& a, int m0) {
+    constexpr int K = KITERS * 512;
+    constexpr int HD = 128;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 4, sub = lane & 15;
+    const int G = a.aH / a.kv_heads;                   // even (4 for both CSM stacks): a pair of heads shares one KV head
+    float* myps = ps + wave * 64;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mrow = m0 + m;
+        if (mrow >= a.M) {
+            for (int c = threadIdx.x; c < K / 8; c += 256) reinterpret_cast<uint4*>(xs + m * K)[c] = make_uint4(0, 0, 0, 0);
+            continue;
+        }
+        const int p = row_pos(a, mrow);
+        const int nk = min(p + 1, 32);
+        const int b = mrow / a.rows_per_seq;
+        for (int h = wave * 2; h < a.aH; h += 8) {
+            const int kvh = h / G;
+            const bf16_t* kb = a.kcache + ((long)b * a.kv_heads + kvh) * a.smax * HD;
+            const bf16_t* vb = a.vcache + ((long)b * a.kv_heads + kvh) * a.smax * HD;
+            const uint4 qa = *reinterpret_cast<const uint4*>(a.aq + ((long)mrow * a.aH + h) * HD + sub * 8);
+            const uint4 qb = *reinterpret_cast<const uint4*>(a.aq + ((long)mrow * a.aH + h + 1) * HD + sub * 8);
+            uint4 kv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)                 // keys beyond the cache's written part are masked below
+                kv[i] = reinterpret_cast<const uint4*>(kb)[i * 64 + lane];
+            uint32_t vv[32];
+#pragma unroll
+            for (int t = 0; t < 32; ++t) vv[t] = reinterpret_cast<const uint32_t*>(vb + (long)t * HD)[lane];
+            float s0[8], s1[8], mx0 = -INFINITY, mx1 = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool live = (4 * i + grp) < nk;
+                s0[i] = live ? row16_sum(dot8(qa, kv[i], 0.f)) * a.ascale : -INFINITY;
+                s1[i] = live ? row16_sum(dot8(qb, kv[i], 0.f)) * a.ascale : -INFINITY;
+                mx0 = fmaxf(mx0, s0[i]); mx1 = fmaxf(mx1, s1[i]);
+            }
+            mx0 = wave_max(mx0); mx1 = wave_max(mx1);
+            float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s0[i] = (s0[i] == -INFINITY) ? 0.f : __expf(s0[i] - mx0);
+                s1[i] = (s1[i] == -INFINITY) ? 0.f : __expf(s1[i] - mx1);
+                l0 += s0[i]; l1 += s1[i];
+                if (sub == 0) { myps[4 * i + grp] = s0[i]; myps[32 + 4 * i + grp] = s1[i]; }
+            }
+            l0 = wave_sum(l0) * (1.0f / 16.0f);          // every key is replicated over the 16 lanes of its row
+            l1 = wave_sum(l1) * (1.0f / 16.0f);
+            float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+#pragma unroll
+            for (int t4 = 0; t4 < 8; ++t4) {            // same-address LDS reads broadcast
+                const float4 pa = *reinterpret_cast<const float4*>(myps + 4 * t4);
+                const float4 pb = *reinterpret_cast<const float4*>(myps + 32 + 4 * t4);
+                const float pav[4] = {pa.x, pa.y, pa.z, pa.w}, pbv[4] = {pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    // rows beyond nk hold stale cache data: p is exactly 0 there, but guard NaN/Inf bit patterns
+                    const uint32_t raw = (4 * t4 + u) < nk ? vv[4 * t4 + u] : 0u;
+                    const float v0 = lo2f(raw), v1 = hi2f(raw);
+                    o00 += pav[u] * v0; o01 += pav[u] * v1;
+                    o10 += pbv[u] * v0; o11 += pbv[u] * v1;
+                }
+            }
+            const float i0 = 1.0f / l0, i1 = 1.0f / l1;
+            reinterpret_cast<uint32_t*>(xs + m * K + h * HD)[lane] = pack_bf(o00 * i0, o01 * i0);
+            reinterpret_cast<uint32_t*>(xs + m * K + (h + 1) * HD)[lane] = pack_bf(o10 * i1, o11 * i1);
+        }
+    }
+    __syncthreads();
+}
 
 template <int MT, int KITERS, bool NORM>
 __device__ __forceinline__ void stage_x(bf16_t* xs, float* red, const GemvArgs& a, int m0) {
     constexpr int K = KITERS * 512;
     constexpr int CHUNKS = K / 8;               // 16-byte chunks per row
+    constexpr int CPT = (CHUNKS + 255) / 256;   // chunks per thread
     const int tid = threadIdx.x;
-    float ss[MT];
+    if constexpr (!NORM) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        ss[m] = 0.f;
-        const bool live = (m0 + m) < a.M;
-        const uint4* src = reinterpret_cast<const uint4*>(a.x + (long)(m0 + m) * a.x_row_stride + a.x_row_offset);
-        for (int c = tid; c < CHUNKS; c += 256) {
-            uint4 v = live ? src[c] : make_uint4(0, 0, 0, 0);
-            if (NORM) {
+        for (int m = 0; m < MT; ++m) {
+            const bool live = (m0 + m) < a.M;
+            const uint4* src = reinterpret_cast<const uint4*>(a.x + (long)(m0 + m) * a.x_row_stride + a.x_row_offset);
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int c = tid + i * 256;
+                if (c < CHUNKS) reinterpret_cast<uint4*>(xs + m * K)[c] = live ? src[c] : make_uint4(0, 0, 0, 0);
+            }
+        }
+    } else {
+        // all global loads (activation chunks AND the norm scale) are issued before the
+        // reduction; the chunks stay in registers across it, so LDS is written exactly once
+        uint4 xv[MT][CPT], g[CPT];
+        float ss[MT];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + i * 256;
+            g[i] = c < CHUNKS ? reinterpret_cast<const uint4*>(a.norm_scale)[c] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bool live = (m0 + m) < a.M;
+            const uint4* src = reinterpret_cast<const uint4*>(a.x + (long)(m0 + m) * a.x_row_stride + a.x_row_offset);
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int c = tid + i * 256;
+                xv[m][i] = (live && c < CHUNKS) ? src[c] : make_uint4(0, 0, 0, 0);
+            }
+        }
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ss[m] = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const uint4 v = xv[m][i];
                 float f;
                 f = lo2f(v.x); ss[m] += f * f; f = hi2f(v.x); ss[m] += f * f;
                 f = lo2f(v.y); ss[m] += f * f; f = hi2f(v.y); ss[m] += f * f;
                 f = lo2f(v.z); ss[m] += f * f; f = hi2f(v.z); ss[m] += f * f;
                 f = lo2f(v.w); ss[m] += f * f; f = hi2f(v.w); ss[m] += f * f;
             }
-            reinterpret_cast<uint4*>(xs + m * K)[c] = v;
-        }
-    }
-    if (NORM) {
-        const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            float s = wave_sum(ss[m]);
-            if (lane == 0) red[m * 4 + wave] = s;
+            const float sw = wave_sum(ss[m]);
+            if (lane == 0) red[m * 4 + wave] = sw;
         }
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const float tot = red[m * 4 + 0] + red[m * 4 + 1] + red[m * 4 + 2] + red[m * 4 + 3];
             const float r = 1.0f / sqrtf(tot / (float)K + a.eps);
-            const uint4* sc = reinterpret_cast<const uint4*>(a.norm_scale);
-            for (int c = tid; c < CHUNKS; c += 256) {      // each thread re-reads only its own chunks
-                uint4 v = reinterpret_cast<uint4*>(xs + m * K)[c];
-                uint4 g = sc[c];
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int c = tid + i * 256;
+                if (c >= CHUNKS) continue;
+                const uint4 v = xv[m][i];
                 uint4 o;
                 // x32 * rsqrt -> bf16 (type_as) -> * scale (bf16 * bf16 -> bf16)
-                o.x = pack_bf(round_bf(lo2f(v.x) * r) * lo2f(g.x), round_bf(hi2f(v.x) * r) * hi2f(g.x));
-                o.y = pack_bf(round_bf(lo2f(v.y) * r) * lo2f(g.y), round_bf(hi2f(v.y) * r) * hi2f(g.y));
-                o.z = pack_bf(round_bf(lo2f(v.z) * r) * lo2f(g.z), round_bf(hi2f(v.z) * r) * hi2f(g.z));
-                o.w = pack_bf(round_bf(lo2f(v.w) * r) * lo2f(g.w), round_bf(hi2f(v.w) * r) * hi2f(g.w));
+                o.x = pack_bf(round_bf(lo2f(v.x) * r) * lo2f(g[i].x), round_bf(hi2f(v.x) * r) * hi2f(g[i].x));
+                o.y = pack_bf(round_bf(lo2f(v.y) * r) * lo2f(g[i].y), round_bf(hi2f(v.y) * r) * hi2f(g[i].y));
+                o.z = pack_bf(round_bf(lo2f(v.z) * r) * lo2f(g[i].z), round_bf(hi2f(v.z) * r) * hi2f(g[i].z));
+                o.w = pack_bf(round_bf(lo2f(v.w) * r) * lo2f(g[i].w), round_bf(hi2f(v.w) * r) * hi2f(g[i].w));
                 reinterpret_cast<uint4*>(xs + m * K)[c] = o;
                 if (a.normed_out != nullptr && blockIdx.x == 0 && (m0 + m) < a.M)
                     reinterpret_cast<uint4*>(a.normed_out + (long)(m0 + m) * a.normed_stride)[c] = o;
@@ -161,9 +293,30 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
                                    : make_uint4(0, 0, 0, 0);
     }
 
+    // ---- prefetch the epilogue's operands for the first M tile (lane m finishes row m): the
+    //      residual values / the RoPE table entry would otherwise be dependent loads at the very end
+    float rpre[R];
+    uint32_t cspre = 0;
+    int ppre = 0;
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            rpre[r] = (lane < MT && lane < a.M && orow[r] < a.N) ? bf2f(a.resid[(long)lane * a.ldo + orow[r]]) : 0.f;
+    }
+    if constexpr (EPI == EPI_QKV_ROPE) {
+        if (lane < MT && lane < a.M) {
+            ppre = row_pos(a, lane);
+            if (orow[0] < a.nq + a.nkv) {
+                const int e = (orow[0] < a.nq ? orow[0] : orow[0] - a.nq) % HD;
+                cspre = reinterpret_cast<const uint32_t*>(a.rope)[(long)ppre * (HD / 2) + e / 2];
+            }
+        }
+    }
+
     for (int m0 = 0; m0 < a.M; m0 += MT) {
         if (m0 > 0) __syncthreads();
-        stage_x<MT, KITERS, PRO == PRO_NORM>(xs, red, a, m0);
+        if constexpr (PRO == PRO_ATTN) stage_attn<MT, KITERS>(xs, red + 16, a, m0);
+        else stage_x<MT, KITERS, PRO == PRO_NORM>(xs, red, a, m0);
 
         float acc[MT][R];
 #pragma unroll
@@ -196,7 +349,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
                 for (int r = 0; r < R; ++r) {
                     if (orow[r] >= a.N) continue;
                     float y = round_bf(acc[m][r]);
-                    if (EPI == EPI_RESID) y = y + bf2f(a.resid[mrow * a.ldo + orow[r]]);
+                    if (EPI == EPI_RESID) y = y + (m0 == 0 ? rpre[r] : bf2f(a.resid[mrow * a.ldo + orow[r]]));
                     a.out[mrow * a.ldo + orow[r]] = f2bf(y);
                 }
             } else if constexpr (EPI == EPI_SWIGLU) {
@@ -213,12 +366,11 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
                 const int row = orow[0];
                 if (row >= a.N) continue;
                 float v0 = round_bf(acc[m][0]), v1 = round_bf(acc[m][1]);
-                int p = a.pos[mrow];
-                p = p < 0 ? 0 : (p >= a.smax ? a.smax - 1 : p);     // memory safety; the host guards length
+                const int p = m0 == 0 ? ppre : row_pos(a, mrow);    // clamped: the host guards length
                 const int b = (int)(mrow / a.rows_per_seq);
                 if (row < a.nq + a.nkv) {                 // q or k: interleaved Llama3-scaled RoPE
                     const int e = (row < a.nq ? row : row - a.nq) % HD;
-                    const uint32_t cs = reinterpret_cast<const uint32_t*>(a.rope)[(long)p * (HD / 2) + e / 2];
+                    const uint32_t cs = m0 == 0 ? cspre : reinterpret_cast<const uint32_t*>(a.rope)[(long)p * (HD / 2) + e / 2];
                     const float c = lo2f(cs), s = hi2f(cs);
                     const float o0 = v0 * c - v1 * s;
                     const float o1 = v1 * c + v0 * s;

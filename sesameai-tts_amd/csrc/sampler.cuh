@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_embed_sum(const int* tokens /*[M][33]*/
 // ---------------------------------------------------------------------------------------
 // sample_topk (sesameai/models.py:72-87), one wave per sequence, everything in registers:
 //   t = bf16(logit / T); drop t < kth-largest (ties kept); log_softmax; softmax;
-//   argmax(p / Exp(1)) with the first index winning ties.
+//   argmax(p / Exp(1)) with the first index winning ties.  (Algorithm: see k_sample.)
 // The bf16 rounding points are those of torch-CPU's reduced-precision kernels (verified by
 // probe): the log-softmax keeps its exp-sum and its log in bf16 and subtracts
 // in two bf16 steps; softmax rounds once.  topk == 1 is the deterministic greedy rule
@@ -92,21 +92,37 @@ __device__ __forceinline__ uint32_t kth_largest_key(const uint32_t (&key)[NC], i
     return prefix;
 }
 
+// raw bf16 bits -> order-preserving 16-bit key (no float conversion)
+__device__ __forceinline__ uint32_t raw_key(uint32_t bits) {
+    if (bits == 0x8000u) bits = 0;
+    return (bits & 0x8000u) ? (~bits & 0xffffu) : (bits | 0x8000u);
+}
+
+// One block of 4 waves per sequence.  Thread t owns logits [8t, 8t+8) (+ [2048+8t, ..) for V > 2048).
+//  1. per-thread max of the RAW bf16 keys -> LDS; the kth largest of those 256 maxima is a lower
+//     bound L of the kth-largest logit (k distinct elements are >= it);
+//  2. every element with raw key >= L - margin is a candidate: only candidates are divided by the
+//     temperature (t = bf16(l/T) is monotone in l, and at most 2*ceil(T)+2 neighbouring bf16 inputs
+//     can round to one output, hence the margin) and appended to an LDS list (~k..3k entries);
+//  3. wave 0 finds the exact kth-largest t among the candidates by 16-bit bisection (ties kept),
+//     then log-softmax / softmax / Exp(1) race exactly as torch-CPU rounds them, one element per lane;
+//  4. all 256 threads copy the embedding row of the fed-back code.
 template <int ITERS>
-__global__ __launch_bounds__(64) void k_sample(const SampleArgs a) {
-    // candidate list (values kept as fp32 copies of bf16 numbers)
+__global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
     __shared__ float cand_t[SAMPLE_MAX_ITERS * 512];
     __shared__ int cand_i[SAMPLE_MAX_ITERS * 512];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    float t[ITERS][8];
+    __shared__ __attribute__((aligned(16))) uint32_t s_max[256];
+    __shared__ float s_bv[4];
+    __shared__ int s_bi[4];
+    __shared__ int s_n, s_tok, s_wtot[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16_t* lg = a.logits + (long)b * a.ldl;
+    uint32_t w[ITERS][4];
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
-        const uint4 v = reinterpret_cast<const uint4*>(lg)[i * 64 + lane];
-        t[i][0] = round_bf(lo2f(v.x) / a.temperature); t[i][1] = round_bf(hi2f(v.x) / a.temperature);
-        t[i][2] = round_bf(lo2f(v.y) / a.temperature); t[i][3] = round_bf(hi2f(v.y) / a.temperature);
-        t[i][4] = round_bf(lo2f(v.z) / a.temperature); t[i][5] = round_bf(hi2f(v.z) / a.temperature);
-        t[i][6] = round_bf(lo2f(v.w) / a.temperature); t[i][7] = round_bf(hi2f(v.w) / a.temperature);
+        const bool in = (i * 2048 + tid * 8) < a.ldl;
+        const uint4 v = in ? reinterpret_cast<const uint4*>(lg + i * 2048)[tid] : make_uint4(0, 0, 0, 0);
+        w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
     }
     int best_idx = 0x7fffffff;
     float best = -INFINITY;
@@ -115,118 +131,158 @@ __global__ __launch_bounds__(64) void k_sample(const SampleArgs a) {
         for (int i = 0; i < ITERS; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int idx = i * 512 + lane * 8 + j;
-                if (idx < a.V && t[i][j] > best) { best = t[i][j]; best_idx = idx; }
+                const int idx = i * 2048 + tid * 8 + j;
+                const uint32_t bits = (j & 1) ? (w[i][j >> 1] >> 16) : (w[i][j >> 1] & 0xffffu);
+                const float t = round_bf(__uint_as_float(bits << 16) / a.temperature);
+                if (idx < a.V && t > best) { best = t; best_idx = idx; }
             }
     } else {
         const int k = min(a.topk, a.V);
-        // ---- 1. cheap lower bound L <= kth-largest: the kth largest of the 64 per-lane maxima
-        //         (k distinct elements are >= it).  For k > 64 every element is a candidate.
-        uint32_t L = 0;
-        if (k <= 64) {
-            uint32_t lmax[1] = {0};
-#pragma unroll
-            for (int i = 0; i < ITERS; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (i * 512 + lane * 8 + j < a.V) lmax[0] = max(lmax[0], order_key(t[i][j]));
-            L = kth_largest_key<1>(lmax, k);
-        }
-        // ---- 2. compact the candidates (key >= L) into LDS, in index order ---------------------
-        int n = 0;
-        const unsigned long long lt = (1ull << lane) - 1ull;
+        uint32_t lmax = 0;
 #pragma unroll
         for (int i = 0; i < ITERS; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int idx = i * 512 + lane * 8 + j;
-                const bool pred = idx < a.V && order_key(t[i][j]) >= L && t[i][j] == t[i][j];
-                const unsigned long long m = __ballot(pred);
-                if (pred) {
-                    const int o = n + __popcll(m & lt);
-                    cand_t[o] = t[i][j];
+                const int idx = i * 2048 + tid * 8 + j;
+                const uint32_t bits = (j & 1) ? (w[i][j >> 1] >> 16) : (w[i][j >> 1] & 0xffffu);
+                const bool nan = (bits & 0x7fffu) > 0x7f80u;
+                if (idx < a.V && !nan) lmax = max(lmax, raw_key(bits));
+            }
+        s_max[tid] = lmax;
+        __syncthreads();
+        uint32_t L = 0;
+        if (k <= 256) {
+            const uint4 mv = reinterpret_cast<const uint4*>(s_max)[lane];
+            const uint32_t mk[4] = {mv.x, mv.y, mv.z, mv.w};
+            L = kth_largest_key<4>(mk, k);
+        }
+        const uint32_t margin = 2u * (uint32_t)ceilf(fmaxf(a.temperature, 1.0f)) + 2u;
+        const uint32_t Lm = L > margin ? L - margin : 0u;
+        // deterministic compaction in index order: per-thread count -> wave scan -> wave bases
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = i * 2048 + tid * 8 + j;
+                const uint32_t bits = (j & 1) ? (w[i][j >> 1] >> 16) : (w[i][j >> 1] & 0xffffu);
+                const bool nan = (bits & 0x7fffu) > 0x7f80u;
+                cnt += (idx < a.V && !nan && raw_key(bits) >= Lm) ? 1 : 0;
+            }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, WAVE);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        int o = incl - cnt;
+        for (int x = 0; x < wave; ++x) o += s_wtot[x];
+        if (tid == 255) s_n = o + cnt;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = i * 2048 + tid * 8 + j;
+                const uint32_t bits = (j & 1) ? (w[i][j >> 1] >> 16) : (w[i][j >> 1] & 0xffffu);
+                const bool nan = (bits & 0x7fffu) > 0x7f80u;
+                if (idx < a.V && !nan && raw_key(bits) >= Lm) {
+                    cand_t[o] = round_bf(__uint_as_float(bits << 16) / a.temperature);
                     cand_i[o] = idx;
+                    ++o;
                 }
-                n += __popcll(m);
             }
         __syncthreads();
-        // ---- 3. exact kth-largest among the candidates -> keep t >= kth (ties kept) -----------
-        uint32_t kth = L;
-        if (n > k) {
-            if (n <= 256) {
-                uint32_t ck[4];
+        const int n = s_n;
+        if (wave == 0) {
+            // ---- exact kth-largest t among the candidates -> keep t >= kth (ties kept) ---------
+            uint32_t kth = 0;
+            if (n > k) {
+                if (n <= 256) {
+                    uint32_t ck[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) ck[c] = (c * 64 + lane < n) ? order_key(cand_t[c * 64 + lane]) : 0u;
-                kth = kth_largest_key<4>(ck, k);
-            } else {                                   // rare (k > 64 or massive ties): generic loop
-                uint32_t prefix = 0;
-                for (int bit = 15; bit >= 0; --bit) {
-                    const uint32_t cnd = prefix | (1u << bit);
-                    int cnt = 0;
-                    for (int c = lane; c < ((n + 63) & ~63); c += 64)
-                        cnt += __popcll(__ballot(c < n && order_key(cand_t[c]) >= cnd));
-                    if (cnt >= k) prefix = cnd;
+                    for (int c = 0; c < 4; ++c) ck[c] = (c * 64 + lane < n) ? order_key(cand_t[c * 64 + lane]) : 0u;
+                    kth = kth_largest_key<4>(ck, k);
+                } else {                               // rare (k > 256 or massive ties): generic loop
+                    uint32_t prefix = 0;
+                    for (int bit = 15; bit >= 0; --bit) {
+                        const uint32_t cnd = prefix | (1u << bit);
+                        int cnt = 0;
+                        for (int c = lane; c < ((n + 63) & ~63); c += 64)
+                            cnt += __popcll(__ballot(c < n && order_key(cand_t[c]) >= cnd));
+                        if (cnt >= k) prefix = cnd;
+                    }
+                    kth = prefix;
                 }
-                kth = prefix;
             }
-        }
-        // ---- 4. log_softmax (torch-CPU bf16 rounding points) over the kept candidates ---------
-        float mx = -INFINITY;
-        for (int c = lane; c < n; c += 64) {
-            const float v = cand_t[c];
-            if (order_key(v) >= kth) mx = fmaxf(mx, v);
-        }
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int c = lane; c < n; c += 64) {
-            const float v = cand_t[c];
-            if (order_key(v) >= kth) sum += expf(v - mx);
-        }
-        sum = wave_sum(sum);
-        const float logsum = round_bf(logf(round_bf(sum)));
-        const float mx2 = round_bf(0.f - logsum);          // log-prob of the max element: bf16(bf16(mx-mx) - logsum)
-        float s2 = 0.f;
-        for (int c = lane; c < n; c += 64) {
-            const float v = cand_t[c];
-            if (order_key(v) >= kth) s2 += expf(round_bf(round_bf(v - mx) - logsum) - mx2);
-        }
-        s2 = wave_sum(s2);
-        // ---- 5. argmax(p / q), q ~ Exp(1); first index wins ties -------------------------------
-        const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
-        for (int c = lane; c < n; c += 64) {
-            const float v = cand_t[c];
-            if (order_key(v) < kth) continue;
-            const int idx = cand_i[c];
-            const float p = round_bf(expf(round_bf(round_bf(v - mx) - logsum) - mx2) / s2);
-            if (!(p > 0.f)) continue;
-            float q;
-            if (a.noise) q = bf2f(a.noise[(long)b * a.V + idx]);
-            else {
-                const uint4 rnd = philox4x32(make_uint4((uint32_t)idx, (uint32_t)b, (uint32_t)a.codebook, (uint32_t)step),
-                                             make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32)));
-                const float u = ((float)rnd.x + 0.5f) * 2.3283064365386963e-10f;   // (0,1]
-                q = round_bf(-logf(u));
-                if (!(q > 0.f)) q = 1e-30f;
+            // ---- log_softmax (torch-CPU bf16 rounding points) over the kept candidates ---------
+            float mx = -INFINITY;
+            for (int c = lane; c < n; c += 64) {
+                const float v = cand_t[c];
+                if (order_key(v) >= kth) mx = fmaxf(mx, v);
             }
-            const float r = round_bf(p / q);
-            if (r > best || (r == best && idx < best_idx)) { best = r; best_idx = idx; }
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int c = lane; c < n; c += 64) {
+                const float v = cand_t[c];
+                if (order_key(v) >= kth) sum += expf(v - mx);
+            }
+            sum = wave_sum(sum);
+            const float logsum = round_bf(logf(round_bf(sum)));
+            const float mx2 = round_bf(0.f - logsum);      // log-prob of the max element
+            float s2 = 0.f;
+            for (int c = lane; c < n; c += 64) {
+                const float v = cand_t[c];
+                if (order_key(v) >= kth) s2 += expf(round_bf(round_bf(v - mx) - logsum) - mx2);
+            }
+            s2 = wave_sum(s2);
+            // ---- argmax(p / q), q ~ Exp(1); first index wins ties ----------------------------------
+            const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
+            for (int c = lane; c < n; c += 64) {
+                const float v = cand_t[c];
+                if (order_key(v) < kth) continue;
+                const int idx = cand_i[c];
+                const float p = round_bf(expf(round_bf(round_bf(v - mx) - logsum) - mx2) / s2);
+                if (!(p > 0.f)) continue;
+                float q;
+                if (a.noise) q = bf2f(a.noise[(long)b * a.V + idx]);
+                else {
+                    const uint4 rnd = philox4x32(make_uint4((uint32_t)idx, (uint32_t)b, (uint32_t)a.codebook, (uint32_t)step),
+                                                 make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32)));
+                    const float u = ((float)rnd.x + 0.5f) * 2.3283064365386963e-10f;   // (0,1]
+                    q = round_bf(-logf(u));
+                    if (!(q > 0.f)) q = 1e-30f;
+                }
+                const float r = round_bf(p / q);
+                if (r > best || (r == best && idx < best_idx)) { best = r; best_idx = idx; }
+            }
         }
     }
-    // wave argmax, lowest index on ties
+    // argmax over the wave (lowest index on ties), then over the 4 waves
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float ob = __shfl_xor(best, off, WAVE);
         const int oi = __shfl_xor(best_idx, off, WAVE);
         if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
     }
-    if (best_idx == 0x7fffffff) best_idx = 0;
-    if (lane == 0) a.frame[(long)b * a.ncb + a.codebook] = best_idx;
+    if (lane == 0) { s_bv[wave] = best; s_bi[wave] = best_idx; }
+    __syncthreads();
+    if (tid == 0) {
+        float bv = s_bv[0]; int bi = s_bi[0];
+        for (int x = 1; x < 4; ++x)
+            if (s_bv[x] > bv || (s_bv[x] == bv && s_bi[x] < bi)) { bv = s_bv[x]; bi = s_bi[x]; }
+        if (bi == 0x7fffffff) bi = 0;
+        s_tok = bi;
+        a.frame[(long)b * a.ncb + a.codebook] = bi;
+    }
+    __syncthreads();
     if (a.emb_out) {
-        int fed = a.forced ? a.forced[(long)b * a.ncb + a.codebook] : best_idx;
+        int fed = a.forced ? a.forced[(long)b * a.ncb + a.codebook] : s_tok;
         fed = min(max(fed, 0), a.audio_vocab - 1);
         const uint4* src = reinterpret_cast<const uint4*>(a.audio_emb + ((long)a.codebook * a.audio_vocab + fed) * a.d);
         uint4* dst = reinterpret_cast<uint4*>(a.emb_out + (long)b * a.emb_stride);
-        for (int c = lane; c < a.d / 8; c += 64) dst[c] = src[c];
+        for (int c = tid; c < a.d / 8; c += 256) dst[c] = src[c];
     }
 }
 
@@ -272,15 +328,9 @@ __global__ void k_advance(const AdvanceArgs a) {
 }
 
 static inline hipError_t launch_sample(const SampleArgs& s, int B, hipStream_t st) {
-    switch ((s.V + 511) / 512) {
-        case 1: hipLaunchKernelGGL(k_sample<1>, dim3(B), dim3(64), 0, st, s); break;
-        case 2: hipLaunchKernelGGL(k_sample<2>, dim3(B), dim3(64), 0, st, s); break;
-        case 3: hipLaunchKernelGGL(k_sample<3>, dim3(B), dim3(64), 0, st, s); break;
-        case 4: hipLaunchKernelGGL(k_sample<4>, dim3(B), dim3(64), 0, st, s); break;
-        case 5: hipLaunchKernelGGL(k_sample<5>, dim3(B), dim3(64), 0, st, s); break;
-        case 6: hipLaunchKernelGGL(k_sample<6>, dim3(B), dim3(64), 0, st, s); break;
-        case 7: hipLaunchKernelGGL(k_sample<7>, dim3(B), dim3(64), 0, st, s); break;
-        case 8: hipLaunchKernelGGL(k_sample<8>, dim3(B), dim3(64), 0, st, s); break;
+    switch ((s.V + 2047) / 2048) {
+        case 1: hipLaunchKernelGGL(k_sample<1>, dim3(B), dim3(256), 0, st, s); break;
+        case 2: hipLaunchKernelGGL(k_sample<2>, dim3(B), dim3(256), 0, st, s); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

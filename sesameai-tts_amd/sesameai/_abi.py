@@ -69,6 +69,7 @@ SIGNATURES = {
     "csm_op_gemv": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _f, _vp, _vp, _vp, _vp, _vp, _l, _vp, _l, _i,
                          _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "csm_op_attn": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "csm_op_attn_oproj": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "csm_op_embed_sum": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csm_op_sample": (_i, [_i, _i, _i, _vp, _f, _i, _vp, _vp, _i, _i, _vp, _vp]),
 }
