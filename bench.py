@@ -213,6 +213,12 @@ def main():
     bytes_frame = model.bytes_per_frame(B, p_mean)
     t_frame = ev_ms * 1e-3 / args.steps
     achieved = bytes_frame / t_frame / 1e9
+    # HBM/fabric bytes per frame-step launch from the PMC counters (FETCH_SIZE, x2 gfx950 correction), collected
+    # with a separate `rocprofv3 --pmc FETCH_SIZE` pass of this same command and committed under profiles/
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    if os.path.exists(pmc) and B == 1 and not args.tiny:
+        traffic = json.load(open(pmc)).get("traffic_bytes_per_frame")
     out = {
         "metric": "audio frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -226,7 +232,7 @@ def main():
         "rtf": round(value / 12.5, 2), "rtf_per_stream": round(value / 12.5 / (world * B), 2),
         "prefill_plus_frame0_ms": round(prefill_ms, 2),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "frame step (1 backbone + 31 depth-decoder steps, unique weights + KV)",
                      "bytes_per_launch": bytes_frame, "launch_ms": round(t_frame * 1e3, 4),
                      "streamed_GBps": round((bytes_frame + 30 * 2 * 111.15e6 + 30 * 2 * 2.1e6) / t_frame / 1e9, 1)},

@@ -43,7 +43,8 @@ struct CsmModel {
     bf16_t *h, *q, *att, *act;          // backbone rows [max_rows][..]
     float* part;                        // [PART_ROWS][H][NSPLIT][hd+2]
     bf16_t *dec_in;                     // [B][2][d_bb]   row0 = last_h, row1 = c0 embedding
-    bf16_t *dec_in1;                    // [B][d_bb]      embedding of c_{i-1}, i >= 2
+    bf16_t *proj_emb;                   // [n_codebooks*audio_vocab][d_dec] = projection(audio_embeddings), built once at create:
+                                        // the decoder input of steps >= 2 is a 2 KB row gather instead of a 4.2 MB GEMV
     bf16_t *hdec, *qd, *attd, *actd;    // decoder rows [2B][..]
     bf16_t* logits;                     // [B][ldl]
     int *frame, *cur_tokens, *cur_pos, *history, *n_frames, *eos_at, *dec_pos;
@@ -97,6 +98,7 @@ static hipError_t launch_gemv_mt(const GemvArgs& a, int units, hipStream_t st) {
 
 // kind: 0 = plain store, 1 = plain + residual, 2 = norm + store (head), 3 = norm + qkv/rope, 4 = norm + swiglu,
 //       5 = fused depth-decoder attention + residual (hd 128, <= 32 keys)
+//       6 = fused split-K attention merge + residual (hd 64)
 static hipError_t launch_gemv(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
     if (K % 512 != 0) return hipErrorInvalidValue;
     const int ki = K / 512;
@@ -110,6 +112,7 @@ static hipError_t launch_gemv(int kind, int K, int hd, const GemvArgs& a, hipStr
                                     : launch_gemv_mt<KI, 2, PRO_NORM, EPI_QKV_ROPE, 128>(a, (a.N + 1) / 2, st); \
             case 4: return launch_gemv_mt<KI, RG, PRO_NORM, EPI_SWIGLU, 64>(a, (a.N + RG / 2 - 1) / (RG / 2), st); \
             case 5: return launch_gemv_mt<KI, RS, PRO_ATTN, EPI_RESID, 64>(a, (a.N + RS - 1) / RS, st);        \
+            case 6: return launch_gemv_mt<KI, RS, PRO_COMBINE, EPI_RESID, 64>(a, (a.N + RS - 1) / RS, st);     \
         }                                                                                                       \
         return hipErrorInvalidValue;
     switch (ki) {
@@ -122,12 +125,12 @@ static hipError_t launch_gemv(int kind, int K, int hd, const GemvArgs& a, hipStr
     return hipErrorInvalidValue;
 }
 
-static hipError_t launch_attn(int hd, const AttnArgs& a, hipStream_t st) {
+static hipError_t launch_attn(int hd, const AttnArgs& a, hipStream_t st, bool combine = true) {
     dim3 grid(a.M, a.KV, a.nsplit);
     if (hd == 64) hipLaunchKernelGGL((k_attn<64>), grid, dim3(256), 0, st, a);
     else if (hd == 128) hipLaunchKernelGGL((k_attn<128>), grid, dim3(256), 0, st, a);
     else return hipErrorInvalidValue;
-    if (a.nsplit > 1) {
+    if (a.nsplit > 1 && combine) {
         if (hd == 64) hipLaunchKernelGGL((k_attn_combine<64>), dim3(a.M, a.H), dim3(64), 0, st, a.part, a.nsplit, a.out, a.H);
         else hipLaunchKernelGGL((k_attn_combine<128>), dim3(a.M, a.H), dim3(128), 0, st, a.part, a.nsplit, a.out, a.H);
     }
@@ -161,6 +164,7 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
         a.nq = S.nq; a.nkv = S.nkv; a.smax = S.cache_len; a.rows_per_seq = rows_per_seq; a.kv_heads = S.d.n_kv_heads;
         a.pos = pos; a.pos_base = pos_base; a.rope = S.rope; a.kcache = kc; a.vcache = vc;
         if ((e = launch_gemv(3, d, S.hd, a, st)) != hipSuccess) return e;
+        bool fuse_comb = false;
         const bool fuse_attn = S.hd == 128 && S.cache_len <= 32 && m->fuse_dec_attn && (S.d.n_heads / S.d.n_kv_heads) % 2 == 0;
         if (!fuse_attn) {
             // (2) attention over keys [0, pos]
@@ -168,7 +172,8 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
             t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
             t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = nsplit;
             t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
-            if ((e = launch_attn(S.hd, t, st)) != hipSuccess) return e;
+            fuse_comb = nsplit > 1 && S.hd == 64;
+            if ((e = launch_attn(S.hd, t, st, !fuse_comb)) != hipSuccess) return e;
         }
         // (3) output projection + residual (depth decoder: attention fused into its prologue)
         memset(&a, 0, sizeof a);
@@ -179,7 +184,8 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
             a.aq = q; a.aH = S.d.n_heads; a.ascale = 1.0f / sqrtf((float)S.hd); a.kcache = kc; a.vcache = vc;
             a.pos = pos; a.pos_base = pos_base; a.smax = S.cache_len; a.rows_per_seq = rows_per_seq; a.kv_heads = S.d.n_kv_heads;
         }
-        if ((e = launch_gemv(fuse_attn ? 5 : 1, S.nq, S.hd, a, st)) != hipSuccess) return e;
+        if (fuse_comb) { a.part = m->part; a.nsplit = nsplit; a.aH = S.d.n_heads; }
+        if ((e = launch_gemv(fuse_attn ? 5 : (fuse_comb ? 6 : 1), S.nq, S.hd, a, st)) != hipSuccess) return e;
         // (4) RMSNorm -> gate/up -> SiLU*up
         memset(&a, 0, sizeof a);
         a.nt = S.nt_mlp;
@@ -212,12 +218,15 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
     for (int cb = 0; cb < ncb; ++cb) {
         GemvArgs a;
         if (cb >= 1) {
-            // projection of [last_h, emb(c0)] (cb == 1, two rows per sequence) or emb(c_{cb-1})
             const int rows = cb == 1 ? 2 * B : B;
-            memset(&a, 0, sizeof a);
-            a.x = cb == 1 ? m->dec_in : m->dec_in1; a.x_row_stride = dbb; a.M = rows;
-            a.w0 = (const bf16_t*)m->w.projection; a.N = dd; a.out = m->hdec; a.ldo = dd; a.nt = 0;
-            if ((e = launch_gemv(0, dbb, 0, a, st)) != hipSuccess) return e;
+            if (cb == 1) {
+                // first decoder call: rows (last_h, emb(c0)) per sequence.  Row 1 was gathered from the
+                // projected-embedding table by the c0 sampler; row 0 = projection(last_h) is the one GEMV.
+                memset(&a, 0, sizeof a);
+                a.x = m->dec_in; a.x_row_stride = 2L * dbb; a.M = B;
+                a.w0 = (const bf16_t*)m->w.projection; a.N = dd; a.out = m->hdec; a.ldo = 2L * dd; a.nt = 0;
+                if ((e = launch_gemv(0, dbb, 0, a, st)) != hipSuccess) return e;
+            }
             // decoder positions are static per step: rows (0,1) on the first call, then cb
             const int* pos = m->fuse_dec_attn ? nullptr : m->dec_pos + (long)(cb == 1 ? 0 : cb) * 2 * m->max_batch;
             if ((e = run_stack(m, m->dec, m->hdec, m->qd, m->attd, m->actd, rows, cb == 1 ? 2 : 1, pos, cb == 1 ? 0 : cb, st)) != hipSuccess) return e;
@@ -247,9 +256,10 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
         s.logits = m->logits; s.ldl = m->ldl; s.V = V; s.temperature = temperature; s.topk = topk;
         s.noise = noise ? (const bf16_t*)noise + (size_t)cb * B * V : nullptr;
         s.rng = m->rng; s.codebook = cb; s.forced = forced; s.ncb = ncb; s.frame = m->frame;
-        s.audio_emb = (const bf16_t*)m->w.audio_emb; s.audio_vocab = V; s.d = dbb;
-        if (cb == 0) { s.emb_out = m->dec_in + dbb; s.emb_stride = 2L * dbb; }
-        else if (cb < ncb - 1) { s.emb_out = m->dec_in1; s.emb_stride = dbb; }
+        // next decoder input = projection(embedding of the fed code) = one row of the table
+        s.audio_emb = m->proj_emb; s.audio_vocab = V; s.d = dd;
+        if (cb == 0) { s.emb_out = m->hdec + dd; s.emb_stride = 2L * dd; }
+        else if (cb < ncb - 1) { s.emb_out = m->hdec; s.emb_stride = dd; }
         if ((e = launch_sample(s, B, st)) != hipSuccess) return e;
     }
     return hipSuccess;
@@ -333,7 +343,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     ALLOC(m->act, (size_t)max_rows * cfg->backbone.ffn * 2);
     ALLOC(m->part, (size_t)PART_ROWS * cfg->backbone.n_heads * BB_NSPLIT_MAX * (m->bb.hd + 4) * 4);
     ALLOC(m->dec_in, (size_t)max_batch * 2 * dbb * 2);
-    ALLOC(m->dec_in1, (size_t)max_batch * dbb * 2);
+    ALLOC(m->proj_emb, (size_t)ncb * cfg->audio_vocab * dd * 2);
     ALLOC(m->hdec, (size_t)2 * max_batch * dd * 2);
     ALLOC(m->qd, (size_t)2 * max_batch * m->dec.nq * 2);
     ALLOC(m->attd, (size_t)2 * max_batch * m->dec.nq * 2);
@@ -359,6 +369,13 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     HIPCHK((CsmModel*)nullptr, hipMemset(m->n_frames, 0, 16));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->cur_pos, 0, (size_t)max_batch * 4));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->eos_at, 0xff, (size_t)max_batch * 4));
+    {   // proj_emb = Linear(projection)(audio_embeddings), with the production GEMV kernel (same rounding as at run time)
+        GemvArgs a;
+        memset(&a, 0, sizeof a);
+        a.x = (const bf16_t*)w->audio_emb; a.x_row_stride = dbb; a.M = ncb * cfg->audio_vocab;
+        a.w0 = (const bf16_t*)w->projection; a.N = dd; a.out = m->proj_emb; a.ldo = dd; a.nt = 0;
+        HIPCHK((CsmModel*)nullptr, launch_gemv(0, dbb, 0, a, nullptr));
+    }
     HIPCHK((CsmModel*)nullptr, hipDeviceSynchronize());
     *out = m;
     return CSM_OK;
@@ -369,7 +386,7 @@ extern "C" void csm_destroy(csm_handle m) {
     if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
     if (m->graph) (void)hipGraphDestroy(m->graph);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
-    void* ptrs[] = {m->bb.kc, m->bb.vc, m->dec.kc, m->dec.vc, m->h, m->q, m->att, m->act, m->part, m->dec_in, m->dec_in1,
+    void* ptrs[] = {m->bb.kc, m->bb.vc, m->dec.kc, m->dec.vc, m->h, m->q, m->att, m->act, m->part, m->dec_in, m->proj_emb,
                     m->hdec, m->qd, m->attd, m->actd, m->logits, m->frame, m->cur_tokens, m->cur_mask, m->cur_pos,
                     m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos};
     for (void* p : ptrs) (void)hipFree(p);

@@ -15,7 +15,7 @@
 #pragma once
 #include "common.cuh"
 
-enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_ATTN = 2 };
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_ATTN = 2, PRO_COMBINE = 3 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV_ROPE = 2, EPI_SWIGLU = 3 };
 
 struct GemvArgs {
@@ -50,6 +50,9 @@ struct GemvArgs {
     int aH;
     float ascale;
     int pos_base;               // used when pos == nullptr
+    // PRO_COMBINE (backbone split-K attention): activation row = merged partial softmax states
+    const float* part;          // [M][aH][nsplit][64 + 4]: o[64], m, l, pad
+    int nsplit;
 };
 
 // Depth-decoder attention fused into the output projection's prologue (hd = 128, at most 32
@@ -149,6 +152,45 @@ __device__ __forceinline__ void stage_attn(bf16_t* xs, float* ps /*[4 waves][2][
             const float i0 = 1.0f / l0, i1 = 1.0f / l1;
             reinterpret_cast<uint32_t*>(xs + m * K + h * HD)[lane] = pack_bf(o00 * i0, o01 * i0);
             reinterpret_cast<uint32_t*>(xs + m * K + (h + 1) * HD)[lane] = pack_bf(o10 * i1, o11 * i1);
+        }
+    }
+    __syncthreads();
+}
+
+// Merge of the split-K attention partials (k_attn with nsplit > 1) fused into the output
+// projection's prologue: thread t owns one 16-byte chunk (8 columns) of one head (hd = 64).
+template <int MT, int KITERS>
+__device__ __forceinline__ void stage_combine(bf16_t* xs, const GemvArgs& a, int m0) {
+    constexpr int K = KITERS * 512;
+    constexpr int HD = 64, PS = HD + 4;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mrow = m0 + m;
+        for (int c = tid; c < K / 8; c += 256) {
+            uint4 o = make_uint4(0, 0, 0, 0);
+            if (mrow < a.M) {
+                const int h = c / (HD / 8), e0 = (c % (HD / 8)) * 8;
+                const float* src = a.part + ((long)mrow * a.aH + h) * a.nsplit * PS;
+                float mx = -INFINITY;
+                for (int sp = 0; sp < a.nsplit; ++sp) mx = fmaxf(mx, src[sp * PS + HD]);
+                float num[8], den = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) num[i] = 0.f;
+                for (int sp = 0; sp < a.nsplit; ++sp) {
+                    const float ms = src[sp * PS + HD];
+                    const float wgt = (ms == -INFINITY) ? 0.f : __expf(ms - mx);
+                    const float4 v0 = *reinterpret_cast<const float4*>(src + sp * PS + e0);
+                    const float4 v1 = *reinterpret_cast<const float4*>(src + sp * PS + e0 + 4);
+                    num[0] += wgt * v0.x; num[1] += wgt * v0.y; num[2] += wgt * v0.z; num[3] += wgt * v0.w;
+                    num[4] += wgt * v1.x; num[5] += wgt * v1.y; num[6] += wgt * v1.z; num[7] += wgt * v1.w;
+                    den += wgt * src[sp * PS + HD + 1];
+                }
+                const float inv = 1.0f / den;
+                o.x = pack_bf(num[0] * inv, num[1] * inv); o.y = pack_bf(num[2] * inv, num[3] * inv);
+                o.z = pack_bf(num[4] * inv, num[5] * inv); o.w = pack_bf(num[6] * inv, num[7] * inv);
+            }
+            reinterpret_cast<uint4*>(xs + m * K)[c] = o;
         }
     }
     __syncthreads();
@@ -316,6 +358,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     for (int m0 = 0; m0 < a.M; m0 += MT) {
         if (m0 > 0) __syncthreads();
         if constexpr (PRO == PRO_ATTN) stage_attn<MT, KITERS>(xs, red + 16, a, m0);
+        else if constexpr (PRO == PRO_COMBINE) stage_combine<MT, KITERS>(xs, a, m0);
         else stage_x<MT, KITERS, PRO == PRO_NORM>(xs, red, a, m0);
 
         float acc[MT][R];

@@ -34,30 +34,44 @@ int main(int argc, char** argv) {
         {"dec qkv  3.1MB x124 sets (HBM)", 3, 3145728, 124}, {"head 2051x1024 4.2MB x31 sets", 2, 4200448, 31},
         {"proj 1024x2048 plain 4.2MB x1", 0, 4194304, 1},
     };
-    // ---- mixed chain: the real decoder layer order qkv -> oproj -> gateup -> down over 4 layers' weights ----
-    for (int variant = 0; variant < 4; ++variant) {
-        const int mlp_nt = variant & 1, big_arena = variant >> 1;
+    // ---- mixed chain: the real depth-decoder step: proj, 4 x (qkv, oproj, gateup, down), head; 31 steps ----
+    // weights: 4 layer sets (58 MB each) + proj 4.2 MB + 31 heads x 4.2 MB, like the real frame
+    for (int variant = 0; variant < 6; ++variant) {
+        const int gu_nt = (variant == 1 || variant == 2 || variant == 5), dn_nt = (variant == 2), head_nt = (variant != 3 && variant != 5) ? 1 : 0;
+        const int attn_nt = 0;
         hipGraph_t g; hipGraphExec_t ge;
         const int steps = 31, layers = 4;
+        const size_t head0 = (size_t)(4 * 58 + 8) << 20;      // byte offset of the heads region
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         int i = 0;
-        for (int sidx = 0; sidx < steps; ++sidx)
+        for (int sidx = 0; sidx < steps; ++sidx) {
+            {   // projection 1024x2048 (default policy)
+                GemvArgs a; memset(&a, 0, sizeof a);
+                a.x = (i & 1) ? y : x; a.M = 1; bf16_t* out = (i & 1) ? x : y; ++i;
+                a.x_row_stride = 2048; a.w0 = w + ((size_t)(4 * 58) << 20) / 2; a.N = 1024; a.out = out; a.ldo = 1024;
+                launch<4, 2, PRO_PLAIN, EPI_STORE, 64>(a, 512, st);
+            }
             for (int l = 0; l < layers; ++l) {
-                // per-layer weight block: qkv 3.1MB | o 2.1MB | gate+up 33.5MB | down 16.8MB  (~56 MB)
-                const size_t lay = (size_t)(big_arena ? (sidx * layers + l) % 10 : l) * (58u << 20) / 2;
-                const bf16_t* wl = w + lay;
+                const bf16_t* wl = w + (size_t)l * (58u << 20) / 2;
                 for (int op = 0; op < 4; ++op, ++i) {
                     GemvArgs a; memset(&a, 0, sizeof a);
                     a.x = (i & 1) ? y : x; a.M = 1; a.norm_scale = scale; a.eps = 1e-5f;
                     bf16_t* out = (i & 1) ? x : y;
-                    if (op == 0) { a.x_row_stride = 1024; a.w0 = wl; a.w1 = wl + 1024 * 1024; a.w2 = wl + 1280 * 1024; a.N = 1536; a.out = out; a.ldo = 1024;
+                    if (op == 0) { a.nt = attn_nt; a.x_row_stride = 1024; a.w0 = wl; a.w1 = wl + 1024 * 1024; a.w2 = wl + 1280 * 1024; a.N = 1536; a.out = out; a.ldo = 1024;
                         a.nq = 1024; a.nkv = 256; a.smax = 32; a.rows_per_seq = 1; a.kv_heads = 2; a.pos_base = 5; a.rope = rope; a.kcache = kc; a.vcache = vc;
                         launch<2, 2, PRO_NORM, EPI_QKV_ROPE, 128>(a, 768, st); }
-                    else if (op == 1) { a.x_row_stride = 1024; a.w0 = wl + (2u << 20); a.N = 1024; a.out = out; a.ldo = 1024; a.resid = out; launch<2, 2, PRO_PLAIN, EPI_RESID, 64>(a, 512, st); }
-                    else if (op == 2) { a.nt = mlp_nt; a.x_row_stride = 1024; a.w0 = wl + (3u << 20); a.w1 = a.w0 + 8192 * 1024; a.N = 8192; a.out = out; a.ldo = 8192; launch<2, 4, PRO_NORM, EPI_SWIGLU, 64>(a, 4096, st); }
-                    else { a.nt = mlp_nt; a.x_row_stride = 8192; a.w0 = wl + (20u << 20); a.N = 1024; a.out = out; a.ldo = 1024; a.resid = out; launch<16, 1, PRO_PLAIN, EPI_RESID, 64>(a, 1024, st); }
+                    else if (op == 1) { a.nt = attn_nt; a.x_row_stride = 1024; a.w0 = wl + (2u << 20); a.N = 1024; a.out = out; a.ldo = 1024; a.resid = out; launch<2, 2, PRO_PLAIN, EPI_RESID, 64>(a, 512, st); }
+                    else if (op == 2) { a.nt = gu_nt; a.x_row_stride = 1024; a.w0 = wl + (3u << 20); a.w1 = a.w0 + 8192 * 1024; a.N = 8192; a.out = out; a.ldo = 8192; launch<2, 4, PRO_NORM, EPI_SWIGLU, 64>(a, 4096, st); }
+                    else { a.nt = dn_nt; a.x_row_stride = 8192; a.w0 = wl + (20u << 20); a.N = 1024; a.out = out; a.ldo = 1024; a.resid = out; launch<16, 1, PRO_PLAIN, EPI_RESID, 64>(a, 1024, st); }
                 }
             }
+            {   // head 2051x1024, a different one every step
+                GemvArgs a; memset(&a, 0, sizeof a);
+                a.x = (i & 1) ? y : x; a.M = 1; a.norm_scale = scale; a.eps = 1e-5f; bf16_t* out = (i & 1) ? x : y; ++i;
+                a.nt = head_nt; a.x_row_stride = 1024; a.w0 = w + (head0 + (size_t)sidx * (5u << 20)) / 2; a.N = 2051; a.out = out; a.ldo = 2560;
+                launch<2, 2, PRO_NORM, EPI_STORE, 64>(a, 1026, st);
+            }
+        }
         CK(hipStreamEndCapture(st, &g));
         CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         for (int r = 0; r < 3; ++r) CK(hipGraphLaunch(ge, st));
@@ -68,8 +82,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, st));
         CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("mixed decoder layer chain (mlp nt=%d, %s): %7.2f us/layer (4 kernels)\n", mlp_nt, big_arena ? "10 layer sets = 580MB" : "4 layer sets = 232MB",
-               ms * 1e3 / (reps * steps * layers));
+        printf("decoder-step chain: gateup nt=%d down nt=%d head nt=%d : %7.2f us/step (18 kernels)\n", gu_nt, dn_nt, head_nt, ms * 1e3 / (reps * steps));
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
     for (auto& c : cases) {
