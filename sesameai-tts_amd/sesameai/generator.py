@@ -124,10 +124,9 @@ class Generator:
             raise ValueError(f"Inputs too long, must be below max_seq_len - max_generation_len: {max_context_len}")
         m = self._model
         m.reset_caches()
-        pos = torch.arange(0, S, device=self.device).unsqueeze(0).repeat(B, 1)
         if max_generation_len <= 0:
             return torch.empty(0, B, 32, dtype=torch.int32)
-        m.prefill(prompt_tokens, prompt_mask, pos)
+        m.prefill_prompt(prompt_tokens, prompt_mask)        # reuses the cached KV of a shared voice-prompt prefix
         m.depth(B, temperature, topk, commit=True)
         poll = poll or self._eos_poll
         done, launched, delivered = False, 1, 0

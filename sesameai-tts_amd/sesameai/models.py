@@ -168,6 +168,12 @@ class Model:
         self._h = C.c_void_p(None)
         self._max_batch = 0
         self._seeded = False
+        # prefix-KV reuse: the reference re-runs the whole 900-1550-row voice prompt
+        # for every sentence (tts_service.py:191-207); here the backbone KV of the previous prompt is
+        # kept and only the rows after the longest common prefix are prefilled again.
+        self.prefix_reuse = True
+        self._kv_prompt: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self.last_prefill_rows = 0
 
     # -- reference-compatible construction helpers ------------------------------------------
     @classmethod
@@ -220,6 +226,7 @@ class Model:
         with torch.cuda.device(self.device):
             check(lib.csm_create(C.byref(cfg), C.byref(w), max_batch_size, rows, self._max_frames, C.byref(self._h)))
         self._max_batch = max_batch_size
+        self._kv_prompt = None
 
     def caches_are_enabled(self) -> bool:
         return bool(self._h)
@@ -245,8 +252,11 @@ class Model:
             pass
 
     # -- the frame ----------------------------------------------------------------------------
-    def prefill(self, tokens: torch.Tensor, tokens_mask: torch.Tensor, input_pos: torch.Tensor) -> None:
+    def prefill(self, tokens: torch.Tensor, tokens_mask: torch.Tensor, input_pos: torch.Tensor,
+                _keeps_prompt_prefix: bool = False) -> None:
         self._require()
+        if not _keeps_prompt_prefix:
+            self._kv_prompt = None          # rows written at caller-chosen positions: the cached prefix is unknown
         b, s, _ = tokens.shape
         if b * s > max(self._max_prefill_rows, 2 * self._max_batch):
             raise ValueError(f"prompt of {b}x{s} rows exceeds max_prefill_rows={self._max_prefill_rows}")
@@ -254,6 +264,28 @@ class Model:
         m = tokens_mask.to(device=self.device, dtype=torch.uint8).contiguous()
         p = input_pos.to(device=self.device, dtype=torch.int32).contiguous()
         check(lib.csm_prefill(self._h, t.data_ptr(), m.data_ptr(), p.data_ptr(), b, s, _stream_ptr()), self._h)
+
+    def prefill_prompt(self, tokens: torch.Tensor, tokens_mask: torch.Tensor) -> int:
+        """Prefill a prompt that starts at position 0 (B,S,33), reusing the cached backbone KV of the
+        longest common row prefix with the previous prompt.  Returns the number of rows actually run.
+        The KV entries of the reused rows were produced by the same deterministic kernels from the
+        same inputs at the same positions, so the result is bit-identical to a full prefill."""
+        b, s, _ = tokens.shape
+        t = tokens.to(device=self.device, dtype=torch.int32)
+        m = tokens_mask.to(device=self.device, dtype=torch.bool)
+        t = torch.where(m, t, torch.zeros_like(t))                    # masked slots do not matter
+        start = 0
+        if self.prefix_reuse and self._kv_prompt is not None and self._kv_prompt[0].shape[0] == b:
+            ot, om = self._kv_prompt
+            n = min(ot.shape[1], s)
+            same = ((t[:, :n] == ot[:, :n]) & (m[:, :n] == om[:, :n])).all(dim=2).all(dim=0)
+            start = int(same.to(torch.int32).cumprod(0).sum().item())
+            start = min(start, s - 1)                                 # at least the last row runs (it yields last_h)
+        pos = torch.arange(start, s, device=self.device, dtype=torch.int32).unsqueeze(0).repeat(b, 1)
+        self.prefill(t[:, start:], m[:, start:], pos, _keeps_prompt_prefix=True)
+        self._kv_prompt = (t, m)
+        self.last_prefill_rows = s - start
+        return s - start
 
     def depth(self, batch: int, temperature: float, topk: int, *, forced: Optional[torch.Tensor] = None,
               noise: Optional[torch.Tensor] = None, want_logits: bool = False, commit: bool = True):
@@ -308,8 +340,14 @@ class Model:
         self._require()
         b, s, _ = tokens.size()
         if s > 1:
-            self.prefill(tokens, tokens_mask, input_pos)
+            ar = torch.arange(s, device=input_pos.device, dtype=input_pos.dtype)
+            if bool((input_pos == ar.unsqueeze(0)).all()):
+                self.prefill_prompt(tokens, tokens_mask)
+            else:
+                self._kv_prompt = None
+                self.prefill(tokens, tokens_mask, input_pos)
             return self.depth(b, temperature, topk, commit=True)
+        # S == 1 steps append beyond the prompt (the reference loop), so the cached prefix stays valid
         t = tokens.to(device=self.device, dtype=torch.int32).contiguous()
         m = tokens_mask.to(device=self.device, dtype=torch.uint8).contiguous()
         p = input_pos.to(device=self.device, dtype=torch.int32).contiguous()

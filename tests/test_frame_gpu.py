@@ -142,6 +142,40 @@ def test_generate_frame_surface_matches_reference_loop(tiny):
     assert torch.equal(got, fr[:, 0])
 
 
+def test_prefix_kv_reuse_is_bit_identical(tiny):
+    """second sentence with the same voice-prompt context: only the rows after the common prefix
+    are prefilled, and the generated frames equal those of a cold full prefill."""
+    from sesameai.generator import Generator
+    shape, w, m = tiny
+    gen = Generator.__new__(Generator)
+    gen._model, gen.device, gen._eos_poll, gen._audio_tokenizer, gen._text_tokenizer = m, m.device, 4, None, None
+    g = torch.Generator().manual_seed(21)
+    ctx_t = torch.zeros(40, 33, dtype=torch.long); ctx_m = torch.zeros(40, 33, dtype=torch.bool)
+    ctx_t[:10, 32] = torch.randint(0, 1000, (10,), generator=g); ctx_m[:10, 32] = True
+    ctx_t[10:, :32] = torch.randint(0, 2048, (30, 32), generator=g); ctx_m[10:, :32] = True
+
+    def prompt(n_text, seed):
+        t = torch.zeros(n_text, 33, dtype=torch.long); mk = torch.zeros(n_text, 33, dtype=torch.bool)
+        t[:, 32] = torch.randint(0, 1000, (n_text,), generator=torch.Generator().manual_seed(seed)); mk[:, 32] = True
+        return torch.cat([ctx_t, t]), torch.cat([ctx_m, mk])
+
+    p1, p2 = prompt(5, 1), prompt(7, 2)
+    m.prefix_reuse = True
+    m._kv_prompt = None
+    gen.generate_codes(*p1, 6, 1.0, 1)
+    assert m.last_prefill_rows == 45
+    warm = gen.generate_codes(*p2, 6, 1.0, 1)
+    assert m.last_prefill_rows == 7, "only the new text rows should have been prefilled"
+    m.prefix_reuse = False
+    cold = gen.generate_codes(*p2, 6, 1.0, 1)
+    assert m.last_prefill_rows == 47
+    m.prefix_reuse = True
+    assert torch.equal(warm, cold)
+    # identical prompt again: one row (the last) still runs to produce last_h
+    again = gen.generate_codes(*p2, 6, 1.0, 1)
+    assert m.last_prefill_rows == 1 and torch.equal(again, cold)
+
+
 def test_prompt_too_long_raises(tiny):
     from sesameai.generator import Generator
     shape, w, m = tiny
