@@ -92,9 +92,12 @@ int csm_seed(csm_handle h, uint64_t seed, void* stream);
 /* The backbone half of Model.generate_frame (models.py:153-160) on B sequences x S rows:
  * masked embedding sum -> 16 layers with KV append at pos -> final norm of each sequence's
  * last row (kept in the handle as last_h).  tokens [B][S][33] i32, mask [B][S][33] u8,
- * pos [B][S] i32, all dev.  After it the internal position of sequence b is pos[b][S-1]+1. */
+ * pos [B][S] i32, all dev.  After it the internal position of sequence b is pos[b][S-1]+1.
+ * prompt_mode != 0: always take the matrix-core (wide-M) kernels, so that a prompt row's result
+ * does not depend on how many rows share the call (needed for bit-identical prefix-KV reuse);
+ * 0: fewer than 16 rows run on the weight-stationary GEMV kernels of the decode step.       */
 int csm_prefill(csm_handle h, const int32_t* tokens, const uint8_t* mask, const int32_t* pos,
-                int B, int S, void* stream);
+                int B, int S, int prompt_mode, void* stream);
 
 /* The depth half of Model.generate_frame (models.py:160-184): c0 head + sample, then 31
  * decoder steps.  Consumes last_h; writes the frame into out_frame [B][32] i32 (dev, may be

@@ -16,10 +16,12 @@
 #include "../../include/csm_hip_ops.h"
 #include "attn.cuh"
 #include "gemv.cuh"
+#include "mm.cuh"
 #include "sampler.cuh"
 
 #define BB_NSPLIT_MAX 8
 #define PART_ROWS 32
+#define WIDE_MIN_ROWS 16      // M >= this: MFMA path (mm.cuh) instead of the weight-stationary GEMV
 
 static thread_local std::string g_create_err;
 
@@ -52,6 +54,7 @@ struct CsmModel {
     uint64_t* rng;
     int *pf_tokens, *pf_pos;            // staging for csm_prefill inputs is the caller's memory
     int host_frames;                    // frames launched since reset (host mirror)
+    int wide_path;                      // MFMA path for M >= WIDE_MIN_ROWS (env CSM_WIDE=0 disables)
     int fuse_dec_attn;                  // depth-decoder attention fused into the O-projection (env CSM_FUSE_DEC_ATTN=0 disables)
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
     int last_S;                         // rows per sequence of the h buffer feeding csm_depth
@@ -125,6 +128,28 @@ static hipError_t launch_gemv(int kind, int K, int hd, const GemvArgs& a, hipStr
     return hipErrorInvalidValue;
 }
 
+// wide-M projections on the matrix cores; kind as in launch_gemv (0 store, 1 +residual, 3 qkv/rope, 4 swiglu)
+static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
+    if (K % 256 != 0) return hipErrorInvalidValue;
+    dim3 grid((a.N + 31) / 32, (a.M + 31) / 32);
+    switch (kind) {
+        case 0: hipLaunchKernelGGL((k_mm32<EPI_STORE, 64>), grid, dim3(256), 0, st, a, K); break;
+        case 1: hipLaunchKernelGGL((k_mm32<EPI_RESID, 64>), grid, dim3(256), 0, st, a, K); break;
+        case 3: if (hd == 64) hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 64>), grid, dim3(256), 0, st, a, K);
+                else hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 128>), grid, dim3(256), 0, st, a, K);
+                break;
+        case 4: hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64>), grid, dim3(256), 0, st, a, K); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+static hipError_t launch_rmsnorm_rows(const bf16_t* x, long stride, long offset, int M, int K, const bf16_t* scale, float eps,
+                                      bf16_t* out, long out_stride, hipStream_t st) {
+    hipLaunchKernelGGL(k_rmsnorm_rows, dim3((M + 3) / 4), dim3(256), 0, st, x, stride, offset, M, K, scale, eps, out, out_stride);
+    return hipGetLastError();
+}
+
 static hipError_t launch_attn(int hd, const AttnArgs& a, hipStream_t st, bool combine = true) {
     dim3 grid(a.M, a.KV, a.nsplit);
     if (hd == 64) hipLaunchKernelGGL((k_attn<64>), grid, dim3(256), 0, st, a);
@@ -140,8 +165,52 @@ static hipError_t launch_attn(int hd, const AttnArgs& a, hipStream_t st, bool co
 // ---------------------------------------------------------------------------------------
 // one Llama stack over M token rows (in place on h)
 // ---------------------------------------------------------------------------------------
+static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t* att, bf16_t* act,
+                                 int M, int rows_per_seq, const int* pos, hipStream_t st) {
+    // unfused wide-M layer: norm -> MFMA qkv(+rope, KV append) -> attention -> MFMA o-proj(+res) ->
+    // norm -> MFMA gate/up(SiLU*up) -> MFMA down(+res).  `att` doubles as the normalised-activation buffer.
+    const int d = S.d.dim;
+    hipError_t e;
+    for (int l = 0; l < S.d.n_layers; ++l) {
+        const CsmLayerWeights& w = S.lw[l];
+        bf16_t* kc = S.kc + (long)l * S.layer_stride;
+        bf16_t* vc = S.vc + (long)l * S.layer_stride;
+        GemvArgs a;
+        if ((e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+        memset(&a, 0, sizeof a);
+        a.x = att; a.x_row_stride = d; a.M = M;
+        a.w0 = (const bf16_t*)w.wq; a.w1 = (const bf16_t*)w.wk; a.w2 = (const bf16_t*)w.wv;
+        a.N = S.nq + 2 * S.nkv; a.out = q; a.ldo = S.nq;
+        a.nq = S.nq; a.nkv = S.nkv; a.smax = S.cache_len; a.rows_per_seq = rows_per_seq; a.kv_heads = S.d.n_kv_heads;
+        a.pos = pos; a.rope = S.rope; a.kcache = kc; a.vcache = vc;
+        if ((e = launch_mm(3, d, S.hd, a, st)) != hipSuccess) return e;
+        AttnArgs t;
+        t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
+        t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = 1;
+        t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
+        if ((e = launch_attn(S.hd, t, st)) != hipSuccess) return e;
+        memset(&a, 0, sizeof a);
+        a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)w.wo; a.N = d; a.out = h; a.ldo = d; a.resid = h;
+        if ((e = launch_mm(1, S.nq, S.hd, a, st)) != hipSuccess) return e;
+        if ((e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+        memset(&a, 0, sizeof a);
+        a.x = att; a.x_row_stride = d; a.M = M; a.w0 = (const bf16_t*)w.w1; a.w1 = (const bf16_t*)w.w3; a.N = S.d.ffn;
+        a.out = act; a.ldo = S.d.ffn;
+        if ((e = launch_mm(4, d, S.hd, a, st)) != hipSuccess) return e;
+        memset(&a, 0, sizeof a);
+        a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)w.w2; a.N = d; a.out = h; a.ldo = d; a.resid = h;
+        if ((e = launch_mm(1, S.d.ffn, S.hd, a, st)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// pos: per-row positions (always valid); pos_const >= 0: all rows of a sequence sit at pos_const + row-in-sequence
+// (depth decoder), which lets the narrow path drop the dependent position load
 static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t* att, bf16_t* act,
-                            int M, int rows_per_seq, const int* pos, int pos_base, hipStream_t st) {
+                            int M, int rows_per_seq, const int* pos_arr, int pos_const, hipStream_t st, bool force_wide = false) {
+    if ((M >= WIDE_MIN_ROWS || force_wide) && m->wide_path) return run_stack_wide(m, S, h, q, att, act, M, rows_per_seq, pos_arr, st);
+    const int* pos = pos_const >= 0 ? nullptr : pos_arr;
+    const int pos_base = pos_const >= 0 ? pos_const : 0;
     const int d = S.d.dim;
     int nsplit = 1;
     if (&S == &m->bb && M <= PART_ROWS) {
@@ -225,10 +294,10 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
                 memset(&a, 0, sizeof a);
                 a.x = m->dec_in; a.x_row_stride = 2L * dbb; a.M = B;
                 a.w0 = (const bf16_t*)m->w.projection; a.N = dd; a.out = m->hdec; a.ldo = 2L * dd; a.nt = 0;
-                if ((e = launch_gemv(0, dbb, 0, a, st)) != hipSuccess) return e;
+                if ((e = (B >= WIDE_MIN_ROWS && m->wide_path) ? launch_mm(0, dbb, 0, a, st) : launch_gemv(0, dbb, 0, a, st)) != hipSuccess) return e;
             }
             // decoder positions are static per step: rows (0,1) on the first call, then cb
-            const int* pos = m->fuse_dec_attn ? nullptr : m->dec_pos + (long)(cb == 1 ? 0 : cb) * 2 * m->max_batch;
+            const int* pos = m->dec_pos + (long)(cb == 1 ? 0 : cb) * 2 * m->max_batch;
             if ((e = run_stack(m, m->dec, m->hdec, m->qd, m->attd, m->actd, rows, cb == 1 ? 2 : 1, pos, cb == 1 ? 0 : cb, st)) != hipSuccess) return e;
         }
         // final RMSNorm + head -> logits (bf16, padded rows)
@@ -245,7 +314,15 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             a.w0 = (const bf16_t*)m->w.audio_head_t + (long)(cb - 1) * V * dd; a.nt = 1;
         }
         a.M = B; a.N = V; a.out = m->logits; a.ldo = m->ldl;
-        if ((e = launch_gemv(2, cb == 0 ? dbb : dd, 0, a, st)) != hipSuccess) return e;
+        if (B >= WIDE_MIN_ROWS && m->wide_path) {
+            // norm of each sequence's last row (side output = last_h for cb == 0), then the MFMA head
+            const int Kh = cb == 0 ? dbb : dd;
+            bf16_t* xn = cb == 0 ? m->dec_in : m->attd;
+            const long xs = cb == 0 ? 2L * dbb : (long)dd;
+            if ((e = launch_rmsnorm_rows(a.x, a.x_row_stride, a.x_row_offset, B, Kh, a.norm_scale, a.eps, xn, xs, st)) != hipSuccess) return e;
+            a.x = xn; a.x_row_stride = xs; a.x_row_offset = 0;
+            if ((e = launch_mm(0, Kh, 0, a, st)) != hipSuccess) return e;
+        } else if ((e = launch_gemv(2, cb == 0 ? dbb : dd, 0, a, st)) != hipSuccess) return e;
         if (logits_out) {
             e = hipMemcpy2DAsync((char*)logits_out + (size_t)cb * B * V * 2, (size_t)V * 2, m->logits, (size_t)m->ldl * 2,
                                  (size_t)V * 2, B, hipMemcpyDeviceToDevice, st);
@@ -317,6 +394,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     m->gexec = nullptr; m->graph = nullptr; m->g_B = -1; m->cap_stream = nullptr;
     m->host_frames = 0; m->have_last = false; m->last_S = 1; m->host_pos_max = 0;
     { const char* ev = getenv("CSM_FUSE_DEC_ATTN"); m->fuse_dec_attn = !(ev && ev[0] == '0'); }
+    { const char* ev = getenv("CSM_WIDE"); m->wide_path = !(ev && ev[0] == '0'); }
     // Cache policy (measured, tools/microbench/gemv_bench.hip): a depth-decoder step touches
     // ~230 MB, about the size of the 256 MB Infinity Cache, so with default-policy loads the
     // 31-step cycle thrashes it and even the 2-3 MB q/k/v/o streams come from HBM (4.9 us per
@@ -414,13 +492,13 @@ extern "C" int csm_seed(csm_handle m, uint64_t seed, void* stream) {
 }
 
 extern "C" int csm_prefill(csm_handle m, const int32_t* tokens, const uint8_t* mask, const int32_t* pos, int B, int S,
-                           void* stream) {
+                           int prompt_mode, void* stream) {
     if (!m || !tokens || !mask || !pos) return fail(m, CSM_E_INVALID, "csm_prefill: null argument");
     if (B < 1 || B > m->max_batch || S < 1 || (long)B * S > m->max_rows)
         return fail(m, CSM_E_INVALID, "csm_prefill: B/S outside the limits given to csm_create");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(m, launch_embed(m, tokens, mask, B * S, st));
-    HIPCHK(m, run_stack(m, m->bb, m->h, m->q, m->att, m->act, B * S, S, pos, 0, st));
+    HIPCHK(m, run_stack(m, m->bb, m->h, m->q, m->att, m->act, B * S, S, pos, -1, st, prompt_mode != 0));
     hipLaunchKernelGGL(k_set_prefill_state, dim3(1), dim3(64), 0, st, pos, B, S, m->cur_pos);
     HIPCHK(m, hipGetLastError());
     m->have_last = true; m->last_S = S;
@@ -452,7 +530,7 @@ extern "C" int csm_copy_frame(csm_handle m, int B, int32_t* out_frame, void* str
 static hipError_t enqueue_frame(CsmModel* m, int B, float temperature, int topk, hipStream_t st) {
     hipError_t e;
     if ((e = launch_embed(m, m->cur_tokens, m->cur_mask, B, st)) != hipSuccess) return e;
-    if ((e = run_stack(m, m->bb, m->h, m->q, m->att, m->act, B, 1, m->cur_pos, 0, st)) != hipSuccess) return e;
+    if ((e = run_stack(m, m->bb, m->h, m->q, m->att, m->act, B, 1, m->cur_pos, -1, st)) != hipSuccess) return e;
     if ((e = run_depth(m, B, 1, temperature, topk, nullptr, nullptr, nullptr, st)) != hipSuccess) return e;
     return launch_advance(m, B, nullptr, 1, st);
 }
@@ -541,7 +619,9 @@ extern "C" int csm_op_gemv(int kind, int M, int K, int N, const void* x, long x_
     a.out = (bf16_t*)out; a.ldo = ldo; a.nt = nt; a.resid = (const bf16_t*)resid;
     a.nq = nq; a.nkv = nkv; a.smax = smax; a.rows_per_seq = rows_per_seq; a.kv_heads = kv_heads; a.pos = pos;
     a.rope = (const bf16_t*)rope; a.kcache = (bf16_t*)kcache; a.vcache = (bf16_t*)vcache;
-    hipError_t e = launch_gemv(kind, K, head_dim, a, (hipStream_t)stream);
+    // kinds 10/11/13/14: the wide-M matrix-core path (mm.cuh) of kinds 0/1/3/4 (x already normalised)
+    hipError_t e = kind >= 10 ? launch_mm(kind - 10, K, head_dim, a, (hipStream_t)stream)
+                              : launch_gemv(kind, K, head_dim, a, (hipStream_t)stream);
     if (e != hipSuccess) { g_create_err = std::string("csm_op_gemv: ") + hipGetErrorString(e); return e == hipErrorInvalidValue ? CSM_E_INVALID : CSM_E_HIP; }
     return CSM_OK;
 }

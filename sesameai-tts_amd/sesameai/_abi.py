@@ -55,7 +55,7 @@ SIGNATURES = {
     "csm_last_error": (C.c_char_p, [_vp]),
     "csm_reset": (_i, [_vp, _vp]),
     "csm_seed": (_i, [_vp, _u64, _vp]),
-    "csm_prefill": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "csm_prefill": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "csm_depth": (_i, [_vp, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "csm_frame_step": (_i, [_vp, _i, _f, _i, _i, _vp]),
     "csm_copy_frame": (_i, [_vp, _i, _vp, _vp]),

@@ -263,7 +263,7 @@ class Model:
         t = tokens.to(device=self.device, dtype=torch.int32).contiguous()
         m = tokens_mask.to(device=self.device, dtype=torch.uint8).contiguous()
         p = input_pos.to(device=self.device, dtype=torch.int32).contiguous()
-        check(lib.csm_prefill(self._h, t.data_ptr(), m.data_ptr(), p.data_ptr(), b, s, _stream_ptr()), self._h)
+        check(lib.csm_prefill(self._h, t.data_ptr(), m.data_ptr(), p.data_ptr(), b, s, int(_keeps_prompt_prefix), _stream_ptr()), self._h)
 
     def prefill_prompt(self, tokens: torch.Tensor, tokens_mask: torch.Tensor) -> int:
         """Prefill a prompt that starts at position 0 (B,S,33), reusing the cached backbone KV of the

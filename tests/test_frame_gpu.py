@@ -82,6 +82,38 @@ def test_tiny_batch_rows_independent(tiny):
     assert torch.equal(outs[0][:, 0], outs[1][:, 0])
 
 
+def test_wide_batch_decode_matches_single_stream():
+    """B = 16 identical prompts run the matrix-core (wide-M) decode path; every row must agree
+    with the others bit-for-bit and with the B = 1 GEMV path / the golden logits within the
+    rounding-noise floor (the two paths sum in different orders)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sesameai.models import Model, csm_tiny_args, synthetic_state_dict
+    gold = torch.load(os.path.join(GOLD, "tiny_frames.pt"))
+    tok, msk = gold["prompt_tokens"], gold["prompt_mask"]
+    S = tok.shape[0]
+    m = Model(csm_tiny_args(), synthetic_state_dict(csm_tiny_args(), seed=1234), max_frames=16, max_prefill_rows=16 * S)
+    m.setup_caches(16)
+    res = {}
+    for B in (1, 16):
+        m.reset_caches()
+        m.prefill(tok.unsqueeze(0).repeat(B, 1, 1), msk.unsqueeze(0).repeat(B, 1, 1), torch.arange(S).unsqueeze(0).repeat(B, 1))
+        forced = gold["codes"][0].unsqueeze(0).repeat(B, 1)
+        out, logits = m.depth(B, 1.0, 1, forced=forced, want_logits=True, commit=False)
+        res[B] = (out.cpu(), logits.float().cpu())
+    o16, l16 = res[16]
+    assert all(torch.equal(o16[0], o16[b]) for b in range(16)), "batch rows differ from each other"
+    assert (l16[:, 0] - l16[:, 7]).abs().max() == 0
+    d = (l16[:, 0] - res[1][1][:, 0]).abs().max().item()
+    noise = float(gold["bf16_vs_fp32_gap"].max())
+    print(f"wide (B=16) vs narrow (B=1) logits: max|d|={d:.4f} (noise floor {noise:.4f})")
+    assert d <= 2 * noise
+    d = (l16[:, 0] - gold["logits"][0].float()).abs().max().item()
+    assert d <= 2 * noise + 1e-3
+    for cb in (o16[0] != gold["codes"][0]).nonzero().flatten().tolist():
+        assert float(gold["margin"][0, cb]) <= 2 * noise
+
+
 def test_tiny_graph_replay_equals_eager_and_oracle_free_run(tiny):
     """The hipGraph-captured frame step is bit-identical to eager launches, the history /
     EOS bookkeeping matches, and the greedy free-running trace equals the oracle's while no
