@@ -47,22 +47,32 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = 0.f;
 
-        for (int j = j0 + slot; j < j1; j += KPI) {
-            const uint4 kv = *reinterpret_cast<const uint4*>(kb + (long)j * HD + e * 8);
-            const uint4 vv = *reinterpret_cast<const uint4*>(vb + (long)j * HD + e * 8);
-            float s = dot8(qv, kv, 0.f);
+        // 4 key rows per lane in flight: all loads of a batch are issued before the first is consumed
+        for (int jb = j0 + slot; jb < j1; jb += 4 * KPI) {
+            uint4 kv[4], vv[4];
 #pragma unroll
-            for (int off = 1; off < LPK; off <<= 1) s += __shfl_xor(s, off, WAVE);
-            s *= a.scale;
-            const float mn = fmaxf(mx, s);
-            const float corr = __expf(mx - mn);          // mx = -inf on the first key -> 0
-            const float pw = __expf(s - mn);
-            l = l * corr + pw;
-            o[0] = o[0] * corr + pw * lo2f(vv.x); o[1] = o[1] * corr + pw * hi2f(vv.x);
-            o[2] = o[2] * corr + pw * lo2f(vv.y); o[3] = o[3] * corr + pw * hi2f(vv.y);
-            o[4] = o[4] * corr + pw * lo2f(vv.z); o[5] = o[5] * corr + pw * hi2f(vv.z);
-            o[6] = o[6] * corr + pw * lo2f(vv.w); o[7] = o[7] * corr + pw * hi2f(vv.w);
-            mx = mn;
+            for (int u = 0; u < 4; ++u) {
+                const int j = min(jb + u * KPI, j1 - 1);
+                kv[u] = *reinterpret_cast<const uint4*>(kb + (long)j * HD + e * 8);
+                vv[u] = *reinterpret_cast<const uint4*>(vb + (long)j * HD + e * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float s = dot8(qv, kv[u], 0.f);
+#pragma unroll
+                for (int off = 1; off < LPK; off <<= 1) s += __shfl_xor(s, off, WAVE);
+                if (jb + u * KPI >= j1) continue;            // uniform across the LPK lanes of a key
+                s *= a.scale;
+                const float mn = fmaxf(mx, s);
+                const float corr = __expf(mx - mn);          // mx = -inf on the first key -> 0
+                const float pw = __expf(s - mn);
+                l = l * corr + pw;
+                o[0] = o[0] * corr + pw * lo2f(vv[u].x); o[1] = o[1] * corr + pw * hi2f(vv[u].x);
+                o[2] = o[2] * corr + pw * lo2f(vv[u].y); o[3] = o[3] * corr + pw * hi2f(vv[u].y);
+                o[4] = o[4] * corr + pw * lo2f(vv[u].z); o[5] = o[5] * corr + pw * hi2f(vv[u].z);
+                o[6] = o[6] * corr + pw * lo2f(vv[u].w); o[7] = o[7] * corr + pw * hi2f(vv[u].w);
+                mx = mn;
+            }
         }
         // merge the KPI key slots (lanes that share e)
 #pragma unroll

@@ -347,7 +347,7 @@ static hipError_t launch_advance(CsmModel* m, int B, const int* fed, int pos_inc
     a.frame = m->frame; a.B = B; a.ncb = m->cfg.n_codebooks; a.bstride = m->max_batch; a.history = m->history;
     a.n_frames = m->n_frames; a.max_frames = m->max_frames; a.eos_at = m->eos_at; a.cur_tokens = m->cur_tokens;
     a.cur_mask = m->cur_mask; a.cur_pos = m->cur_pos; a.rng = m->rng; a.out_frame = nullptr; a.fed = fed; a.pos_inc = pos_inc;
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -384,7 +384,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
         if ((ki != 1 && ki != 2 && ki != 4 && ki != 16) || (kf != 1 && kf != 2 && kf != 4 && kf != 16))
             return fail(nullptr, CSM_E_INVALID, "csm_create: dim and ffn must be 512*{1,2,4,16}");
     }
-    if (cfg->audio_vocab > SAMPLE_MAX_ITERS * 512) return fail(nullptr, CSM_E_INVALID, "csm_create: audio_vocab too large");
+    if (cfg->audio_vocab > 4096 || cfg->n_codebooks > 63 || max_batch > 256) return fail(nullptr, CSM_E_INVALID, "csm_create: audio_vocab <= 4096, n_codebooks <= 63, max_batch <= 256 required");
     if (cfg->n_codebooks > cfg->decoder.max_seq) return fail(nullptr, CSM_E_INVALID, "csm_create: n_codebooks > decoder max_seq");
     CsmModel* m = new CsmModel();
     m->cfg = *cfg; m->w = *w; m->max_batch = max_batch; m->max_frames = max_frames;

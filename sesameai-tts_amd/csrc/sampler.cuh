@@ -14,22 +14,35 @@ __global__ __launch_bounds__(256) void k_embed_sum(const int* tokens /*[M][33]*/
                                                    const bf16_t* text_emb, const bf16_t* audio_emb,
                                                    int audio_vocab, int text_vocab, int ncb, int d,
                                                    bf16_t* h /*[M][d]*/) {
+    __shared__ const bf16_t* rows[64];             // row pointer per slot (nullptr = masked out)
     const int m = blockIdx.x;
-    const int* tk = tokens + (long)m * (ncb + 1);
-    const uint8_t* mk = mask + (long)m * (ncb + 1);
+    if (threadIdx.x <= ncb && threadIdx.x < 64) {
+        const int s = threadIdx.x;
+        int t = tokens[(long)m * (ncb + 1) + s];
+        const bf16_t* row = nullptr;
+        if (mask[(long)m * (ncb + 1) + s]) {
+            if (s < ncb) { t = min(max(t, 0), audio_vocab - 1); row = audio_emb + ((long)s * audio_vocab + t) * d; }
+            else         { t = min(max(t, 0), text_vocab - 1);  row = text_emb + (long)t * d; }
+        }
+        rows[s] = row;
+    }
+    __syncthreads();
     for (int c = threadIdx.x; c < d / 8; c += 256) {
         float acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-        for (int s = 0; s <= ncb; ++s) {
-            if (!mk[s]) continue;
-            int t = tk[s];
-            const bf16_t* row;
-            if (s < ncb) { t = min(max(t, 0), audio_vocab - 1); row = audio_emb + ((long)s * audio_vocab + t) * d; }
-            else         { t = min(max(t, 0), text_vocab - 1);  row = text_emb + (long)t * d; }
-            const uint4 v = reinterpret_cast<const uint4*>(row)[c];
-            acc[0] += lo2f(v.x); acc[1] += hi2f(v.x); acc[2] += lo2f(v.y); acc[3] += hi2f(v.y);
-            acc[4] += lo2f(v.z); acc[5] += hi2f(v.z); acc[6] += lo2f(v.w); acc[7] += hi2f(v.w);
+        for (int s0 = 0; s0 <= ncb; s0 += 11) {      // 11 independent row loads in flight, summed in slot order
+            uint4 v[11];
+#pragma unroll
+            for (int u = 0; u < 11; ++u) {
+                const bf16_t* row = (s0 + u <= ncb) ? rows[s0 + u] : nullptr;
+                v[u] = row ? reinterpret_cast<const uint4*>(row)[c] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 11; ++u) {
+                acc[0] += lo2f(v[u].x); acc[1] += hi2f(v[u].x); acc[2] += lo2f(v[u].y); acc[3] += hi2f(v[u].y);
+                acc[4] += lo2f(v[u].z); acc[5] += hi2f(v[u].z); acc[6] += lo2f(v[u].w); acc[7] += hi2f(v[u].w);
+            }
         }
         uint4 o;
         o.x = pack_bf(acc[0], acc[1]); o.y = pack_bf(acc[2], acc[3]);
@@ -306,24 +319,27 @@ struct AdvanceArgs {
     int pos_inc;          // 1 after a backbone step consumed cur_pos, 0 after a prefill
 };
 
-__global__ void k_advance(const AdvanceArgs a) {
+__global__ __launch_bounds__(256) void k_advance(const AdvanceArgs a) {
+    __shared__ int nz[256];                         // per-sequence count of non-zero codes (B <= 256)
     const int n = *a.n_frames;
-    for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
-        bool allzero = true;
-        for (int c = 0; c < a.ncb; ++c) {
-            const int v = a.frame[b * a.ncb + c];
-            allzero &= (v == 0);
-            if (n < a.max_frames) a.history[((long)n * a.bstride + b) * a.ncb + c] = v;
-            a.cur_tokens[b * (a.ncb + 1) + c] = a.fed ? a.fed[b * a.ncb + c] : v;
-            a.cur_mask[b * (a.ncb + 1) + c] = 1;
-            if (a.out_frame) a.out_frame[b * a.ncb + c] = v;
-        }
-        a.cur_tokens[b * (a.ncb + 1) + a.ncb] = 0;
-        a.cur_mask[b * (a.ncb + 1) + a.ncb] = 0;
-        if (allzero && a.eos_at[b] < 0) a.eos_at[b] = n;
-        a.cur_pos[b] += a.pos_inc;
+    for (int b = threadIdx.x; b < a.B; b += blockDim.x) nz[b] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.B * a.ncb; i += blockDim.x) {
+        const int b = i / a.ncb, c = i % a.ncb;
+        const int v = a.frame[i];
+        if (v != 0) atomicAdd(&nz[b], 1);
+        if (n < a.max_frames) a.history[((long)n * a.bstride + b) * a.ncb + c] = v;
+        a.cur_tokens[b * (a.ncb + 1) + c] = a.fed ? a.fed[i] : v;
+        a.cur_mask[b * (a.ncb + 1) + c] = 1;
+        if (a.out_frame) a.out_frame[i] = v;
     }
     __syncthreads();
+    for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
+        a.cur_tokens[b * (a.ncb + 1) + a.ncb] = 0;
+        a.cur_mask[b * (a.ncb + 1) + a.ncb] = 0;
+        if (nz[b] == 0 && a.eos_at[b] < 0) a.eos_at[b] = n;
+        a.cur_pos[b] += a.pos_inc;
+    }
     if (threadIdx.x == 0) { *a.n_frames = n + 1; a.rng[1] += 1; }
 }
 

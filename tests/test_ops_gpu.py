@@ -95,11 +95,11 @@ def test_qkv_rope_kvappend(abi, d, H, KV, hd, rows_per_seq):
     op_gemv(abi, 3, dev(x), dev(wq), w1=dev(wk), w2=dev(wv), norm_scale=dev(scale), out=qout, ldo=H * hd,
             N=(H + 2 * KV) * hd, head_dim=hd, nq=H * hd, nkv=KV * hd, kv_heads=KV, smax=smax,
             rows_per_seq=rows_per_seq, pos=dev(pos.reshape(-1), torch.int32), rope=dev(table), kcache=kc, vcache=vc)
-    assert_bf16_close(qout.view(B, rows_per_seq, H, hd), q, what="q rope")
+    assert_bf16_close(qout.view(B, rows_per_seq, H, hd), q, abs_floor=0.008, what="q rope")   # x0*c - x1*s can cancel
     for b in range(B):
         for t in range(rows_per_seq):
             p = int(pos[b, t])
-            assert_bf16_close(kc[b, :, p], k[b, t], what="k cache")
+            assert_bf16_close(kc[b, :, p], k[b, t], abs_floor=0.008, what="k cache")
             assert_bf16_close(vc[b, :, p], v[b, t], what="v cache")
     written = torch.zeros(B, smax, dtype=torch.bool)
     for b in range(B):
@@ -153,8 +153,8 @@ def test_wide_mfma_path(abi, M):
     op_gemv(abi, 13, dev(x), dev(wq), w1=dev(wk), w2=dev(wv), out=qout, ldo=H * hd, N=(H + 2 * KV) * hd, head_dim=hd,
             nq=H * hd, nkv=KV * hd, kv_heads=KV, smax=smax, rows_per_seq=S, pos=dev(pos.reshape(-1), torch.int32),
             rope=dev(table), kcache=kc, vcache=vc)
-    assert_bf16_close(qout.view(1, S, H, hd), q, abs_floor=5e-5, what="mfma q rope")
-    assert_bf16_close(kc[0, :, 3:3 + M].transpose(0, 1), k[0], abs_floor=5e-5, what="mfma k cache")
+    assert_bf16_close(qout.view(1, S, H, hd), q, abs_floor=0.008, what="mfma q rope")     # x0*c - x1*s can cancel: 1 ulp of the inputs
+    assert_bf16_close(kc[0, :, 3:3 + M].transpose(0, 1), k[0], abs_floor=0.008, what="mfma k cache")
     assert_bf16_close(vc[0, :, 3:3 + M].transpose(0, 1), v[0], abs_floor=5e-5, what="mfma v cache")
 
 
