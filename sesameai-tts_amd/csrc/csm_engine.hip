@@ -34,6 +34,7 @@ struct Stack {
     bf16_t *kc, *vc;            // [L][B][KV][cache_len][hd]
     long layer_stride;          // elements per layer
     int nt_attn, nt_mlp;        // cache policy of the q/k/v/o and of the gate/up/down weight streams
+    CsmLayerWeights pk[CSM_MAX_LAYERS];   // matrix-core operand-order copies of wq..w3 (k_pack_w) for the wide-M path
 };
 
 struct CsmModel {
@@ -45,6 +46,9 @@ struct CsmModel {
     bf16_t *h, *q, *att, *act;          // backbone rows [max_rows][..]
     float* part;                        // [PART_ROWS][H][NSPLIT][hd+2]
     bf16_t *dec_in;                     // [B][2][d_bb]   row0 = last_h, row1 = c0 embedding
+    bf16_t *pk_projection, *pk_c0_head, *pk_audio_head;   // packed copies for the wide-M path
+    long pk_head_stride;                // elements between packed audio heads
+    std::vector<void*> pk_allocs;
     bf16_t *proj_emb;                   // [n_codebooks*audio_vocab][d_dec] = projection(audio_embeddings), built once at create:
                                         // the decoder input of steps >= 2 is a 2 KB row gather instead of a 4.2 MB GEMV
     bf16_t *hdec, *qd, *attd, *actd;    // decoder rows [2B][..]
@@ -132,13 +136,16 @@ static hipError_t launch_gemv(int kind, int K, int hd, const GemvArgs& a, hipStr
 static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
     if (K % 256 != 0) return hipErrorInvalidValue;
     dim3 grid((a.N + 31) / 32, (a.M + 31) / 32);
+    const bool deep = K >= 4096 && K % 1024 == 0;         // 16-way K split for the down projections
     switch (kind) {
-        case 0: hipLaunchKernelGGL((k_mm32<EPI_STORE, 64>), grid, dim3(256), 0, st, a, K); break;
-        case 1: hipLaunchKernelGGL((k_mm32<EPI_RESID, 64>), grid, dim3(256), 0, st, a, K); break;
-        case 3: if (hd == 64) hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 64>), grid, dim3(256), 0, st, a, K);
-                else hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 128>), grid, dim3(256), 0, st, a, K);
+        case 0: hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4>), grid, dim3(256), 0, st, a, K); break;
+        case 1: if (deep) hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 16>), grid, dim3(1024), 0, st, a, K);
+                else hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4>), grid, dim3(256), 0, st, a, K);
                 break;
-        case 4: hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64>), grid, dim3(256), 0, st, a, K); break;
+        case 3: if (hd == 64) hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 64, 4>), grid, dim3(256), 0, st, a, K);
+                else hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 128, 4>), grid, dim3(256), 0, st, a, K);
+                break;
+        case 4: hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4>), grid, dim3(256), 0, st, a, K); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -173,13 +180,14 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
     hipError_t e;
     for (int l = 0; l < S.d.n_layers; ++l) {
         const CsmLayerWeights& w = S.lw[l];
+        const CsmLayerWeights& pk = S.pk[l];
         bf16_t* kc = S.kc + (long)l * S.layer_stride;
         bf16_t* vc = S.vc + (long)l * S.layer_stride;
         GemvArgs a;
         if ((e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = d; a.M = M;
-        a.w0 = (const bf16_t*)w.wq; a.w1 = (const bf16_t*)w.wk; a.w2 = (const bf16_t*)w.wv;
+        a.w0 = (const bf16_t*)pk.wq; a.w1 = (const bf16_t*)pk.wk; a.w2 = (const bf16_t*)pk.wv;
         a.N = S.nq + 2 * S.nkv; a.out = q; a.ldo = S.nq;
         a.nq = S.nq; a.nkv = S.nkv; a.smax = S.cache_len; a.rows_per_seq = rows_per_seq; a.kv_heads = S.d.n_kv_heads;
         a.pos = pos; a.rope = S.rope; a.kcache = kc; a.vcache = vc;
@@ -190,15 +198,15 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
         if ((e = launch_attn(S.hd, t, st)) != hipSuccess) return e;
         memset(&a, 0, sizeof a);
-        a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)w.wo; a.N = d; a.out = h; a.ldo = d; a.resid = h;
+        a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)pk.wo; a.N = d; a.out = h; a.ldo = d; a.resid = h;
         if ((e = launch_mm(1, S.nq, S.hd, a, st)) != hipSuccess) return e;
         if ((e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
         memset(&a, 0, sizeof a);
-        a.x = att; a.x_row_stride = d; a.M = M; a.w0 = (const bf16_t*)w.w1; a.w1 = (const bf16_t*)w.w3; a.N = S.d.ffn;
+        a.x = att; a.x_row_stride = d; a.M = M; a.w0 = (const bf16_t*)pk.w1; a.w1 = (const bf16_t*)pk.w3; a.N = S.d.ffn;
         a.out = act; a.ldo = S.d.ffn;
         if ((e = launch_mm(4, d, S.hd, a, st)) != hipSuccess) return e;
         memset(&a, 0, sizeof a);
-        a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)w.w2; a.N = d; a.out = h; a.ldo = d; a.resid = h;
+        a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)pk.w2; a.N = d; a.out = h; a.ldo = d; a.resid = h;
         if ((e = launch_mm(1, S.d.ffn, S.hd, a, st)) != hipSuccess) return e;
     }
     return hipSuccess;
@@ -294,7 +302,9 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
                 memset(&a, 0, sizeof a);
                 a.x = m->dec_in; a.x_row_stride = 2L * dbb; a.M = B;
                 a.w0 = (const bf16_t*)m->w.projection; a.N = dd; a.out = m->hdec; a.ldo = 2L * dd; a.nt = 0;
-                if ((e = (B >= WIDE_MIN_ROWS && m->wide_path) ? launch_mm(0, dbb, 0, a, st) : launch_gemv(0, dbb, 0, a, st)) != hipSuccess) return e;
+                if (B >= WIDE_MIN_ROWS && m->wide_path) { a.w0 = m->pk_projection; e = launch_mm(0, dbb, 0, a, st); }
+                else e = launch_gemv(0, dbb, 0, a, st);
+                if (e != hipSuccess) return e;
             }
             // decoder positions are static per step: rows (0,1) on the first call, then cb
             const int* pos = m->dec_pos + (long)(cb == 1 ? 0 : cb) * 2 * m->max_batch;
@@ -321,6 +331,7 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             const long xs = cb == 0 ? 2L * dbb : (long)dd;
             if ((e = launch_rmsnorm_rows(a.x, a.x_row_stride, a.x_row_offset, B, Kh, a.norm_scale, a.eps, xn, xs, st)) != hipSuccess) return e;
             a.x = xn; a.x_row_stride = xs; a.x_row_offset = 0;
+            a.w0 = cb == 0 ? m->pk_c0_head : m->pk_audio_head + (long)(cb - 1) * m->pk_head_stride;
             if ((e = launch_mm(0, Kh, 0, a, st)) != hipSuccess) return e;
         } else if ((e = launch_gemv(2, cb == 0 ? dbb : dd, 0, a, st)) != hipSuccess) return e;
         if (logits_out) {
@@ -361,6 +372,33 @@ __global__ void k_copy_step_inputs(const int* tokens, const uint8_t* mask, const
                                    int* cur_tokens, uint8_t* cur_mask, int* cur_pos) {
     for (int i = threadIdx.x; i < n_tok; i += blockDim.x) { cur_tokens[i] = tokens[i]; cur_mask[i] = mask[i]; }
     for (int b = threadIdx.x; b < B; b += blockDim.x) cur_pos[b] = pos[b];
+}
+
+static hipError_t pack_weight(CsmModel* m, const void* w, int N, int K, bf16_t** out) {
+    const long pieces = (long)((N + 31) / 32) * (K / 64) * 256;
+    hipError_t e = hipMalloc((void**)out, (size_t)pieces * 16);
+    if (e != hipSuccess) return e;
+    m->pk_allocs.push_back(*out);
+    hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, nullptr, (const bf16_t*)w, N, K, *out);
+    return hipGetLastError();
+}
+
+static hipError_t pack_stack(CsmModel* m, Stack& S) {
+    hipError_t e;
+    const int d = S.d.dim;
+    for (int l = 0; l < S.d.n_layers; ++l) {
+        const CsmLayerWeights& w = S.lw[l];
+        CsmLayerWeights& p = S.pk[l];
+        bf16_t* t;
+        if ((e = pack_weight(m, w.wq, S.nq, d, &t)) != hipSuccess) return e; p.wq = t;
+        if ((e = pack_weight(m, w.wk, S.nkv, d, &t)) != hipSuccess) return e; p.wk = t;
+        if ((e = pack_weight(m, w.wv, S.nkv, d, &t)) != hipSuccess) return e; p.wv = t;
+        if ((e = pack_weight(m, w.wo, d, S.nq, &t)) != hipSuccess) return e; p.wo = t;
+        if ((e = pack_weight(m, w.w1, S.d.ffn, d, &t)) != hipSuccess) return e; p.w1 = t;
+        if ((e = pack_weight(m, w.w3, S.d.ffn, d, &t)) != hipSuccess) return e; p.w3 = t;
+        if ((e = pack_weight(m, w.w2, d, S.d.ffn, &t)) != hipSuccess) return e; p.w2 = t;
+    }
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -447,6 +485,23 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     HIPCHK((CsmModel*)nullptr, hipMemset(m->n_frames, 0, 16));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->cur_pos, 0, (size_t)max_batch * 4));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->eos_at, 0xff, (size_t)max_batch * 4));
+    if (m->wide_path) {
+        HIPCHK((CsmModel*)nullptr, pack_stack(m, m->bb));
+        HIPCHK((CsmModel*)nullptr, pack_stack(m, m->dec));
+        HIPCHK((CsmModel*)nullptr, pack_weight(m, w->projection, dd, dbb, &m->pk_projection));
+        HIPCHK((CsmModel*)nullptr, pack_weight(m, w->c0_head, cfg->audio_vocab, dbb, &m->pk_c0_head));
+        // the 31 audio heads: packed one after the other (each padded to a multiple of 32 rows)
+        m->pk_head_stride = (long)((cfg->audio_vocab + 31) / 32) * (dd / 64) * 256 * 8;
+        HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pk_audio_head, (size_t)m->pk_head_stride * 2 * (ncb - 1)));
+        m->pk_allocs.push_back(m->pk_audio_head);
+        for (int i = 0; i < ncb - 1; ++i) {
+            const long pieces = m->pk_head_stride / 8;
+            hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, nullptr,
+                               (const bf16_t*)w->audio_head_t + (long)i * cfg->audio_vocab * dd, cfg->audio_vocab, dd,
+                               m->pk_audio_head + (long)i * m->pk_head_stride);
+        }
+        HIPCHK((CsmModel*)nullptr, hipGetLastError());
+    }
     {   // proj_emb = Linear(projection)(audio_embeddings), with the production GEMV kernel (same rounding as at run time)
         GemvArgs a;
         memset(&a, 0, sizeof a);
@@ -468,6 +523,7 @@ extern "C" void csm_destroy(csm_handle m) {
                     m->hdec, m->qd, m->attd, m->actd, m->logits, m->frame, m->cur_tokens, m->cur_mask, m->cur_pos,
                     m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos};
     for (void* p : ptrs) (void)hipFree(p);
+    for (void* p : m->pk_allocs) (void)hipFree(p);
     delete m;
 }
 
@@ -619,9 +675,29 @@ extern "C" int csm_op_gemv(int kind, int M, int K, int N, const void* x, long x_
     a.out = (bf16_t*)out; a.ldo = ldo; a.nt = nt; a.resid = (const bf16_t*)resid;
     a.nq = nq; a.nkv = nkv; a.smax = smax; a.rows_per_seq = rows_per_seq; a.kv_heads = kv_heads; a.pos = pos;
     a.rope = (const bf16_t*)rope; a.kcache = (bf16_t*)kcache; a.vcache = (bf16_t*)vcache;
-    // kinds 10/11/13/14: the wide-M matrix-core path (mm.cuh) of kinds 0/1/3/4 (x already normalised)
-    hipError_t e = kind >= 10 ? launch_mm(kind - 10, K, head_dim, a, (hipStream_t)stream)
-                              : launch_gemv(kind, K, head_dim, a, (hipStream_t)stream);
+    // kinds 10/11/13/14: the wide-M matrix-core path (mm.cuh) of kinds 0/1/3/4 (x already normalised);
+    // the hook re-tiles the row-major test weights into the matrix-core operand order first
+    hipError_t e;
+    if (kind >= 10) {
+        std::vector<void*> tmp;
+        auto pack = [&](const bf16_t* w, int n) -> const bf16_t* {
+            if (!w) return nullptr;
+            const long pieces = (long)((n + 31) / 32) * (K / 64) * 256;
+            void* t = nullptr;
+            if (hipMalloc(&t, (size_t)pieces * 16) != hipSuccess) return nullptr;
+            tmp.push_back(t);
+            hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, n, K, (bf16_t*)t);
+            return (const bf16_t*)t;
+        };
+        if (kind == 13) { a.w0 = pack(a.w0, nq); a.w1 = pack(a.w1, nkv); a.w2 = pack(a.w2, nkv); }
+        else if (kind == 14) { a.w0 = pack(a.w0, N); a.w1 = pack(a.w1, N); }
+        else a.w0 = pack(a.w0, N);
+        e = launch_mm(kind - 10, K, head_dim, a, (hipStream_t)stream);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        for (void* t : tmp) (void)hipFree(t);
+    } else {
+        e = launch_gemv(kind, K, head_dim, a, (hipStream_t)stream);
+    }
     if (e != hipSuccess) { g_create_err = std::string("csm_op_gemv: ") + hipGetErrorString(e); return e == hipErrorInvalidValue ? CSM_E_INVALID : CSM_E_HIP; }
     return CSM_OK;
 }

@@ -46,43 +46,80 @@ __global__ __launch_bounds__(256) void k_rmsnorm_rows(const bf16_t* x, long x_ro
 
 __device__ __forceinline__ bf16x8_t as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
 
+// Matrix-core operand order for the weight stream ("memory laid out for the hardware"): W [N][K]
+// row-major is re-tiled ONCE at load time so that every wave-level load of the wide-M kernels is
+// one fully contiguous 1 KB read:  Wt[ntile][chunk][q][lane][8]  with
+//   Wt[...] = W[ntile*32 + (lane & 31)][chunk*64 + (lane >> 5)*32 + q*8 + j]
+// (lane, q) being exactly the (row, k-step) a lane feeds to v_mfma_f32_32x32x16_bf16 in k_mm32.
+// Rows beyond N (N padded to a multiple of 32) are zero.  One thread per 16-byte piece.
+__global__ void k_pack_w(const bf16_t* w, int N, int K, bf16_t* wt) {
+    const long piece = (long)blockIdx.x * blockDim.x + threadIdx.x;       // ((ntile*(K/64) + chunk)*4 + q)*64 + lane
+    const long total = (long)((N + 31) / 32) * (K / 64) * 4 * 64;
+    if (piece >= total) return;
+    const int lane = (int)(piece & 63), q = (int)((piece >> 6) & 3);
+    const long tc = piece >> 8;
+    const int chunk = (int)(tc % (K / 64));
+    const int ntile = (int)(tc / (K / 64));
+    const int n = ntile * 32 + (lane & 31);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (n < N) v = *reinterpret_cast<const uint4*>(w + (long)n * K + chunk * 64 + (lane >> 5) * 32 + q * 8);
+    reinterpret_cast<uint4*>(wt)[piece] = v;
+}
+
 // GemvArgs is reused: x (row stride x_row_stride), M, w0/w1/w2, N, out/ldo, resid, QKV fields.
-// K is a runtime argument (multiple of 256).
-template <int EPI, int HD>
-__global__ __launch_bounds__(256) void k_mm32(const GemvArgs a, const int K) {
-    __shared__ float red[EPI == EPI_SWIGLU ? 2 : 1][4][16][64];
+// K is a runtime argument (multiple of 64 * NW).  NW = waves per block = K split (4, or 16 for the
+// K = 8192 down projections so that a 32-row stripe of a 16 MB matrix is pulled by 16 waves).
+template <int EPI, int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K) {
+    __shared__ float red[EPI == EPI_SWIGLU ? 2 : 1][NW][16][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
     const int mrow = min(m0 + r, a.M - 1);
-    int nrow = min(n0 + r, a.N - 1);
-    const bf16_t* wa;                                     // weight row feeding accumulator 0
-    const bf16_t* wb = nullptr;                           // SwiGLU: the matching up-projection row
-    if (EPI == EPI_QKV_ROPE) {
-        if (nrow < a.nq) wa = a.w0 + (long)nrow * K;
-        else if (nrow < a.nq + a.nkv) wa = a.w1 + (long)(nrow - a.nq) * K;
-        else wa = a.w2 + (long)(nrow - a.nq - a.nkv) * K;
+    // w0/w1/w2 are PACKED (k_pack_w): tile pointer = base + ntile * (K/64) * 4 KB; a wave-level load of
+    // step q in chunk c is the contiguous 1 KB at  tile + ((c*4 + q)*64 + lane) * 16 bytes
+    const uint4* wa;                                      // weight tile feeding accumulator 0
+    const uint4* wb = nullptr;                            // SwiGLU: the matching up-projection tile
+    const long tile_u4 = (long)(K / 64) * 256;            // uint4 per n-tile
+    if (EPI == EPI_QKV_ROPE) {                            // nq, nkv are multiples of 32: a tile never straddles q/k/v
+        if (n0 < a.nq) wa = reinterpret_cast<const uint4*>(a.w0) + (long)(n0 / 32) * tile_u4;
+        else if (n0 < a.nq + a.nkv) wa = reinterpret_cast<const uint4*>(a.w1) + (long)((n0 - a.nq) / 32) * tile_u4;
+        else wa = reinterpret_cast<const uint4*>(a.w2) + (long)((n0 - a.nq - a.nkv) / 32) * tile_u4;
     } else {
-        wa = a.w0 + (long)nrow * K;
-        if (EPI == EPI_SWIGLU) wb = a.w1 + (long)nrow * K;
+        wa = reinterpret_cast<const uint4*>(a.w0) + (long)(n0 / 32) * tile_u4;
+        if (EPI == EPI_SWIGLU) wb = reinterpret_cast<const uint4*>(a.w1) + (long)(n0 / 32) * tile_u4;
     }
     const bf16_t* xa = a.x + (long)mrow * a.x_row_stride + a.x_row_offset;
-    const int kspan = K / 4, kbeg = wave * kspan;
+    const int kspan = K / NW, kbeg = wave * kspan, kend = kbeg + kspan;
     f32x16_t acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    for (int kc = kbeg; kc < kbeg + kspan; kc += 64) {
-        uint4 av[4], bv[4], cv[4];
+    // register double buffer: the loads of chunk c+1 are in flight while chunk c feeds the MFMAs
+    uint4 av[2][4], bv[2][4], cv[2][4];
+    auto load = [&](int buf, int kc) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            av[q] = *reinterpret_cast<const uint4*>(xa + kc + h * 32 + q * 8);
-            bv[q] = *reinterpret_cast<const uint4*>(wa + kc + h * 32 + q * 8);
-            if (EPI == EPI_SWIGLU) cv[q] = *reinterpret_cast<const uint4*>(wb + kc + h * 32 + q * 8);
+            av[buf][q] = *reinterpret_cast<const uint4*>(xa + kc + h * 32 + q * 8);
+            bv[buf][q] = ldg16<true>(wa + ((kc >> 6) * 4 + q) * 64 + lane);
+            if (EPI == EPI_SWIGLU) cv[buf][q] = ldg16<true>(wb + ((kc >> 6) * 4 + q) * 64 + lane);
         }
+    };
+    load(0, kbeg);
+    for (int kc = kbeg; kc < kend; kc += 128) {
+        if (kc + 64 < kend) load(1, kc + 64);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[q]), as_bf16x8(bv[q]), acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[0][q]), as_bf16x8(bv[0][q]), acc0, 0, 0, 0);
             if (EPI == EPI_SWIGLU)
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[q]), as_bf16x8(cv[q]), acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[0][q]), as_bf16x8(cv[0][q]), acc1, 0, 0, 0);
+        }
+        if (kc + 64 < kend) {
+            if (kc + 128 < kend) load(0, kc + 128);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[1][q]), as_bf16x8(bv[1][q]), acc0, 0, 0, 0);
+                if (EPI == EPI_SWIGLU)
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[1][q]), as_bf16x8(cv[1][q]), acc1, 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -91,6 +128,7 @@ __global__ __launch_bounds__(256) void k_mm32(const GemvArgs a, const int K) {
         if (EPI == EPI_SWIGLU) red[1][wave][i][lane] = acc1[i];
     }
     __syncthreads();
+    if (wave >= 4) return;                                // waves 0..3 finish the tile
     // thread (wave g, lane) finishes regs 4g..4g+3 of `lane`: rows 8g + 4h + {0..3}, column n0 + r
     {
 #pragma clang fp contract(off)
@@ -99,7 +137,9 @@ __global__ __launch_bounds__(256) void k_mm32(const GemvArgs a, const int K) {
         for (int i = 0; i < 4; ++i) {
             const int reg = wave * 4 + i;
             const int m = m0 + 8 * wave + 4 * h + i;
-            float s0 = red[0][0][reg][lane] + red[0][1][reg][lane] + red[0][2][reg][lane] + red[0][3][reg][lane];
+            float s0 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s0 += red[0][w][reg][lane];       // fixed order: deterministic
             float y = round_bf(s0);
             if (EPI == EPI_QKV_ROPE) {
                 // partner column n^1 lives in the neighbouring lane; every lane must take part in the shuffle
@@ -122,7 +162,10 @@ __global__ __launch_bounds__(256) void k_mm32(const GemvArgs a, const int K) {
                 }
             } else if (m < a.M && n < a.N) {
                 if (EPI == EPI_SWIGLU) {
-                    const float u = round_bf(red[1][0][reg][lane] + red[1][1][reg][lane] + red[1][2][reg][lane] + red[1][3][reg][lane]);
+                    float s1 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) s1 += red[1][w][reg][lane];
+                    const float u = round_bf(s1);
                     const float sg = round_bf(y / (1.0f + __expf(-y)));
                     y = sg * u;
                 } else if (EPI == EPI_RESID) {
