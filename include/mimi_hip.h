@@ -58,6 +58,19 @@ typedef struct MimiWeights {
     MimiConv res1[MIMI_MAX_STAGES];   /* Conv1d k3  C -> C/2                             */
     MimiConv res2[MIMI_MAX_STAGES];   /* Conv1d k1  C/2 -> C                             */
     MimiConv conv_out;                /* Conv1d k3  n_filters -> 1                       */
+    /* ---- ENCODE side (voice prompts, sesameai/generator.py:86); has_encoder == 0: absent ---- */
+    int32_t has_encoder;
+    const float* enc_conv_in_w;       /* [taps][n_filters]  (c_in = 1)                   */
+    const float* enc_conv_in_b;       /* [n_filters]                                     */
+    MimiConv enc_res1[MIMI_MAX_STAGES];   /* Conv1d k3  C -> C/2   (stage j works at C = n_filters << j) */
+    MimiConv enc_res2[MIMI_MAX_STAGES];   /* Conv1d k1  C/2 -> C                         */
+    MimiConv enc_down[MIMI_MAX_STAGES];   /* Conv1d k=2r stride r, C -> 2C, r = ratios reversed; taps = 2r */
+    MimiConv enc_conv_out;            /* Conv1d k3  (n_filters << n_stages) -> hidden    */
+    MimiTrLayer enc_tr[MIMI_MAX_TR_LAYERS];
+    const float* downsample;          /* [4 taps][hidden][hidden] Conv1d k4 s2, replicate padding, no bias */
+    const float* in_proj_first;       /* [codebook_dim][hidden]  rvq_first.input_proj    */
+    const float* in_proj_rest;        /* [codebook_dim][hidden]  rvq_rest.input_proj     */
+    const float* codebook_sqnorm;     /* [n_codebooks][codebook_size]  |e|^2             */
 } MimiWeights;
 
 typedef struct MimiDecoder* mimi_handle;
@@ -80,6 +93,12 @@ int mimi_decode(mimi_handle h, const int32_t* codes, int B, int T, long stride_b
 int mimi_decode_strided(mimi_handle h, const int32_t* codes, int B, int T, long stride_b, long stride_k,
                         long stride_t, void* pcm, int stateful, void* stream);
 int mimi_reset_stream(mimi_handle h, void* stream);
+
+/* MimiModel.encode (sesameai/generator.py:86): wav [B] rows of n_samples fp32 @ 24 kHz (row b at
+ * wav + b*stride_b) -> codes [B][n_codebooks][T] int32, T = ceil(n_samples / hop).  Residual
+ * vector quantisation = nearest centroid per level (first index on ties).  Uses the decoder's
+ * work buffers: it ends any stateful decode stream.  n_samples <= hop * max_frames.            */
+int mimi_encode(mimi_handle h, const float* wav, long n_samples, long stride_b, int B, int32_t* codes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -139,4 +139,28 @@ def build_hf_mimi(s, w: Dict[str, torch.Tensor]):
             rb.block[3].conv.bias.copy_(w[f"seanet.up.{j}.res.conv2.bias"])
         last = dl[2 + 3 * len(s.ratios)]
         last.conv.weight.copy_(w["seanet.conv_out.weight"]); last.conv.bias.copy_(w["seanet.conv_out.bias"])
+        if "enc.conv_in.weight" in w:          # encode side
+            el = m.encoder.layers
+            el[0].conv.weight.copy_(w["enc.conv_in.weight"]); el[0].conv.bias.copy_(w["enc.conv_in.bias"])
+            for j in range(len(s.ratios)):
+                rb, cv = el[1 + 3 * j], el[3 + 3 * j]
+                rb.block[1].conv.weight.copy_(w[f"enc.down.{j}.res.conv1.weight"]); rb.block[1].conv.bias.copy_(w[f"enc.down.{j}.res.conv1.bias"])
+                rb.block[3].conv.weight.copy_(w[f"enc.down.{j}.res.conv2.weight"]); rb.block[3].conv.bias.copy_(w[f"enc.down.{j}.res.conv2.bias"])
+                cv.conv.weight.copy_(w[f"enc.down.{j}.conv.weight"]); cv.conv.bias.copy_(w[f"enc.down.{j}.conv.bias"])
+            lastc = el[2 + 3 * len(s.ratios)]
+            lastc.conv.weight.copy_(w["enc.conv_out.weight"]); lastc.conv.bias.copy_(w["enc.conv_out.bias"])
+            for i, layer in enumerate(m.encoder_transformer.layers):
+                L = f"enc_transformer.{i}"
+                wq, wk, wv = w[f"{L}.in_proj_weight"].chunk(3, dim=0)
+                layer.self_attn.q_proj.weight.copy_(_perm_rows(wq, H, hd))
+                layer.self_attn.k_proj.weight.copy_(_perm_rows(wk, H, hd))
+                layer.self_attn.v_proj.weight.copy_(wv)
+                layer.self_attn.o_proj.weight.copy_(w[f"{L}.out_proj.weight"])
+                layer.input_layernorm.weight.copy_(w[f"{L}.norm1.weight"]); layer.input_layernorm.bias.copy_(w[f"{L}.norm1.bias"])
+                layer.post_attention_layernorm.weight.copy_(w[f"{L}.norm2.weight"]); layer.post_attention_layernorm.bias.copy_(w[f"{L}.norm2.bias"])
+                layer.mlp.fc1.weight.copy_(w[f"{L}.linear1.weight"]); layer.mlp.fc2.weight.copy_(w[f"{L}.linear2.weight"])
+                layer.self_attn_layer_scale.scale.copy_(w[f"{L}.layer_scale_1.scale"]); layer.mlp_layer_scale.scale.copy_(w[f"{L}.layer_scale_2.scale"])
+            m.downsample.conv.weight.copy_(w["downsample.conv.weight"])
+            q.semantic_residual_vector_quantizer.input_proj.weight.copy_(w["rvq_first.input_proj.weight"])
+            q.acoustic_residual_vector_quantizer.input_proj.weight.copy_(w["rvq_rest.input_proj.weight"])
     return m

@@ -100,12 +100,47 @@ def weight_names(s: MimiShape) -> List[Tuple[str, Tuple[int, ...], str]]:
     return out
 
 
-def make_weights(s: MimiShape, seed: int = 4321) -> Dict[str, torch.Tensor]:
+def encoder_weight_names(s: MimiShape) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """ENCODE side (voice prompts: sesameai/generator.py:86): SEANet encoder, encoder transformer,
+    stride-2 downsample, RVQ input projections.  Kept in a separate list (and a separate RNG
+    stream) so the committed decode goldens stay valid."""
+    out: List[Tuple[str, Tuple[int, ...], str]] = []
+    c, d = s.n_filters, s.hidden
+    out += [("enc.conv_in.weight", (c, 1, s.kernel), "conv"), ("enc.conv_in.bias", (c,), "small")]
+    for j, r in enumerate(reversed(s.ratios)):
+        h = c // s.compress
+        out += [(f"enc.down.{j}.res.conv1.weight", (h, c, s.res_kernel), "conv"), (f"enc.down.{j}.res.conv1.bias", (h,), "small"),
+                (f"enc.down.{j}.res.conv2.weight", (c, h, 1), "conv"), (f"enc.down.{j}.res.conv2.bias", (c,), "small"),
+                (f"enc.down.{j}.conv.weight", (2 * c, c, 2 * r), "conv"), (f"enc.down.{j}.conv.bias", (2 * c,), "small")]
+        c *= 2
+    out += [("enc.conv_out.weight", (d, c, s.last_kernel), "conv"), ("enc.conv_out.bias", (d,), "small")]
+    for i in range(s.tr_layers):
+        L = f"enc_transformer.{i}"
+        out += [(f"{L}.norm1.weight", (d,), "ones"), (f"{L}.norm1.bias", (d,), "small"),
+                (f"{L}.in_proj_weight", (3 * d, d), "linear"), (f"{L}.out_proj.weight", (d, d), "linear"),
+                (f"{L}.layer_scale_1.scale", (d,), "scale"),
+                (f"{L}.norm2.weight", (d,), "ones"), (f"{L}.norm2.bias", (d,), "small"),
+                (f"{L}.linear1.weight", (s.tr_ffn, d), "linear"), (f"{L}.linear2.weight", (d, s.tr_ffn), "linear"),
+                (f"{L}.layer_scale_2.scale", (d,), "scale")]
+    out += [("downsample.conv.weight", (d, d, 4), "conv"),
+            ("rvq_first.input_proj.weight", (s.codebook_dim, d, 1), "conv"),
+            ("rvq_rest.input_proj.weight", (s.codebook_dim, d, 1), "conv")]
+    return out
+
+
+def make_weights(s: MimiShape, seed: int = 4321, encoder: bool = False) -> Dict[str, torch.Tensor]:
     """Seeded synthetic fp32 weights: codebooks N(0,1), convs/linears Kaiming-uniform-like
-    (U[-sqrt(3/fan_in), +]) so activations keep O(1) scale through the stack."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
+    (U[-sqrt(3/fan_in), +]) so activations keep O(1) scale through the stack.  ``encoder=True``
+    adds the encode-side tensors from a second generator (seed + 1)."""
     w: Dict[str, torch.Tensor] = {}
-    for name, shp, kind in weight_names(s):
+    _fill(w, weight_names(s), torch.Generator(device="cpu").manual_seed(seed))
+    if encoder:
+        _fill(w, encoder_weight_names(s), torch.Generator(device="cpu").manual_seed(seed + 1))
+    return w
+
+
+def _fill(w: Dict[str, torch.Tensor], names, g: torch.Generator) -> None:
+    for name, shp, kind in names:
         if kind == "normal":
             t = torch.randn(shp, generator=g)
         elif kind == "usage":
@@ -127,7 +162,6 @@ def make_weights(s: MimiShape, seed: int = 4321) -> Dict[str, torch.Tensor]:
             bound = math.sqrt(3.0 / fan_in)
             t = (torch.rand(shp, generator=g) * 2 - 1) * bound
         w[name] = t.float()
-    return w
 
 
 # ----------------------------------------------------------------------------------------
@@ -167,7 +201,8 @@ def _rope_interleaved(x: torch.Tensor, pos: torch.Tensor, theta: float) -> torch
     return out.flatten(-2)
 
 
-def transformer(s: MimiShape, w: Dict[str, torch.Tensor], x: torch.Tensor, offset: int = 0) -> torch.Tensor:
+def transformer(s: MimiShape, w: Dict[str, torch.Tensor], x: torch.Tensor, offset: int = 0,
+                prefix: str = "transformer") -> torch.Tensor:
     """x (B,T,d) -> (B,T,d); causal with context window (key j visible to query i iff
     0 <= i-j < context)."""
     B, T, d = x.shape
@@ -177,7 +212,7 @@ def transformer(s: MimiShape, w: Dict[str, torch.Tensor], x: torch.Tensor, offse
     delta = pos[:, None] - pos[None, :]
     allowed = (delta >= 0) & (delta < s.tr_context)
     for i in range(s.tr_layers):
-        L = f"transformer.{i}"
+        L = f"{prefix}.{i}"
         h = F.layer_norm(x, (d,), w[f"{L}.norm1.weight"], w[f"{L}.norm1.bias"], s.norm_eps)
         qkv = F.linear(h, w[f"{L}.in_proj_weight"]).view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
@@ -219,3 +254,57 @@ def decode_stateless_chunks(s: MimiShape, w: Dict[str, torch.Tensor], codes: tor
     frames are decoded independently (all streaming state dropped at the seams)."""
     T = codes.shape[-1]
     return torch.cat([decode(s, w, codes[..., t:t + chunk]) for t in range(0, T, chunk)], dim=-1)
+
+
+# ----------------------------------------------------------------------------------------
+# ENCODE (moshi MimiModel.encode as called at sesameai/generator.py:86; structure checked against
+# transformers.models.mimi in tests/test_oracle_vs_hf.py)
+# ----------------------------------------------------------------------------------------
+def _strided_causal_conv(x: torch.Tensor, w: torch.Tensor, b, stride: int, pad_mode: str = "constant") -> torch.Tensor:
+    """StreamingConv1d with stride: left pad k - stride, right pad so that ceil(len/stride) frames come out."""
+    k = w.shape[-1]
+    n = x.shape[-1]
+    pad_total = k - stride
+    n_frames = math.ceil((n - k + pad_total) / stride + 1) - 1
+    extra = max(0, n_frames * stride + k - pad_total - n)
+    x = F.pad(x, (pad_total, extra), mode=pad_mode)
+    return F.conv1d(x, w, b, stride=stride)
+
+
+@torch.inference_mode()
+def encode_latent(s: MimiShape, w: Dict[str, torch.Tensor], wav: torch.Tensor) -> torch.Tensor:
+    """wav (B,1,n) -> pre-quantisation embeddings (B, hidden, T), T = ceil(n / hop)."""
+    x = causal_conv1d(wav, w["enc.conv_in.weight"], w["enc.conv_in.bias"])
+    for j, r in enumerate(reversed(s.ratios)):
+        y = causal_conv1d(F.elu(x), w[f"enc.down.{j}.res.conv1.weight"], w[f"enc.down.{j}.res.conv1.bias"])
+        y = causal_conv1d(F.elu(y), w[f"enc.down.{j}.res.conv2.weight"], w[f"enc.down.{j}.res.conv2.bias"])
+        x = x + y
+        x = _strided_causal_conv(F.elu(x), w[f"enc.down.{j}.conv.weight"], w[f"enc.down.{j}.conv.bias"], r)
+    x = causal_conv1d(F.elu(x), w["enc.conv_out.weight"], w["enc.conv_out.bias"])
+    x = transformer(s, w, x.transpose(1, 2), prefix="enc_transformer").transpose(1, 2)
+    return _strided_causal_conv(x, w["downsample.conv.weight"], None, 2, pad_mode="replicate")
+
+
+def _rvq_encode(res: torch.Tensor, books: List[torch.Tensor]) -> List[torch.Tensor]:
+    """res (B,T,D); nearest-centroid residual quantisation (torch.cdist + argmin, first index on ties)."""
+    out = []
+    for e in books:
+        idx = torch.cdist(res.reshape(1, -1, res.shape[-1]), e[None], p=2)[0].argmin(dim=-1).view(res.shape[:-1])
+        out.append(idx)
+        res = res - F.embedding(idx, e)
+    return out
+
+
+@torch.inference_mode()
+def encode(s: MimiShape, w: Dict[str, torch.Tensor], wav: torch.Tensor) -> torch.Tensor:
+    """wav (B,1,n) fp32 @ 24 kHz -> codes (B, num_codebooks, ceil(n/1920)) int64.  Split RVQ: the
+    semantic codebook and the acoustic stack both quantise the SAME embeddings, each behind its own
+    1x1 input projection."""
+    z = encode_latent(s, w, wav)
+    def emb(k):
+        return w[f"rvq.{k}.embedding_sum"] / w[f"rvq.{k}.cluster_usage"].clamp(min=1e-5)[:, None]
+    first = F.conv1d(z, w["rvq_first.input_proj.weight"]).transpose(1, 2)
+    rest = F.conv1d(z, w["rvq_rest.input_proj.weight"]).transpose(1, 2)
+    codes = _rvq_encode(first, [emb(k) for k in range(s.num_semantic)])
+    codes += _rvq_encode(rest, [emb(k) for k in range(s.num_semantic, s.num_codebooks)])
+    return torch.stack(codes, dim=1)

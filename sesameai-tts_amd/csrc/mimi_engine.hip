@@ -27,10 +27,13 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 static thread_local std::string g_mimi_err;
 
-#define MAX_TAPS 8
+#define MAX_TAPS 16
 
 struct GemmArgs {
-    const float* x; long ldx;       // A row for output time t, tap j: x + (t + shift[j]) * ldx
+    const float* x; long ldx;       // A row for output time t, tap j: x + (t * in_stride + shift[j]) * ldx
+    int in_stride;                  // 1, or the stride of a down-sampling conv
+    int edge, row_lo, row_hi;       // edge 0: rows are always in range (left context stored in front of row 0);
+                                    // 1: rows outside [row_lo,row_hi) read as zero; 2: clamped (replicate padding)
     int T_in, C_in, C_out;
     const float* w;                 // [phases][taps][C_out][C_in]
     const float* bias;
@@ -56,7 +59,11 @@ __global__ __launch_bounds__(64) void k_gemm32(const GemmArgs a) {
     const int trow = trow_ok ? (t0 + r) : (a.T_in - 1);
     const int nrow = nrow_ok ? (n0 + r) : (a.C_out - 1);
     for (int j = 0; j < a.taps; ++j) {
-        const float* xa = a.x + (long)(trow + a.shift[j]) * a.ldx + h * 16;
+        int arow = trow * a.in_stride + a.shift[j];
+        bool aok = true;
+        if (a.edge == 1) { aok = arow >= a.row_lo && arow < a.row_hi; arow = min(max(arow, a.row_lo), a.row_hi - 1); }
+        else if (a.edge == 2) arow = min(max(arow, a.row_lo), a.row_hi - 1);
+        const float* xa = a.x + (long)arow * a.ldx + h * 16;
         const float* wb = a.w + (((long)p * a.taps + j) * a.C_out + nrow) * a.C_in + h * 16;
         for (int kc = 0; kc < a.C_in; kc += 32) {
             float4 av[4], bv[4];
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(64) void k_gemm32(const GemmArgs a) {
             for (int s = 0; s < 16; ++s) {
                 float va = af[s];
                 if (a.elu_in) va = elu1(va);
-                if (!trow_ok) va = 0.f;
+                if (!trow_ok || !aok) va = 0.f;
                 const float vb = nrow_ok ? bf[s] : 0.f;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, acc, 0, 0, 0);
             }
@@ -239,6 +246,49 @@ __global__ void k_slide_hist(float* base /*row -hist*/, int hist, long T, int C)
     for (int r = 0; r < hist; ++r) base[(long)r * C + c] = base[((long)r + T) * C + c];   // ascending r: source is always ahead
 }
 
+// ---- encode-side kernels ---------------------------------------------------------------
+// first encoder conv (1 channel in): out[t][co] = b[co] + sum_k w[k][co] * wav[t - (taps-1) + k]
+__global__ void k_enc_conv_in(const float* wav, long n, int taps, int C, const float* w, const float* b, float* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * C) return;
+    const long t = i / C;
+    const int co = (int)(i % C);
+    float acc = b[co];
+    for (int k = 0; k < taps; ++k) {
+        const long ti = t - (taps - 1) + k;
+        if (ti >= 0) acc = fmaf(wav[ti], w[k * C + co], acc);
+    }
+    out[i] = acc;
+}
+
+// nearest centroid of one RVQ level + residual update: score[t][c] = r_t . e_c (from the GEMM),
+// code = argmin_c (|e_c|^2 - 2 score) (first index on ties), r_t -= e_code.   grid = T, block = 256
+__global__ __launch_bounds__(256) void k_rvq_pick(const float* score, int ncodes, const float* sqnorm, const float* book, int dim,
+                                                  float* resid, int32_t* codes, long code_stride_t) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    __shared__ int pick;
+    const int t = blockIdx.x, tid = threadIdx.x;
+    float best = INFINITY; int idx = 0x7fffffff;
+    for (int c = tid; c < ncodes; c += 256) {
+        const float dsc = sqnorm[c] - 2.0f * score[(long)t * ncodes + c];
+        if (dsc < best) { best = dsc; idx = c; }             // ascending c per thread: keeps the first minimum
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(idx, o, 64);
+        if (ob < best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    }
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int x = 1; x < 4; ++x) if (bv[x] < best || (bv[x] == best && bi[x] < idx)) { best = bv[x]; idx = bi[x]; }
+        pick = idx; codes[(long)t * code_stride_t] = idx;
+    }
+    __syncthreads();
+    const int e = pick;
+    for (int d = tid; d < dim; d += 256) resid[(long)t * dim + d] -= book[(long)e * dim + d];
+}
+
 // ---------------------------------------------------------------------------------------
 struct HBuf {            // activation buffer with `hist` rows of left context in front of row 0
     float* base = nullptr;
@@ -311,7 +361,7 @@ extern "C" int mimi_create(const MimiConfig* cfg, const MimiWeights* w, int max_
     }
 #define A4(p, n) MCHK((MimiDecoder*)nullptr, hipMalloc((void**)&(p), (size_t)(n) * 4))
     A4(m->tok, T2 * d); A4(m->ln, T2 * d); A4(m->qkv, T2 * 3 * d); A4(m->q, T2 * d); A4(m->att, T2 * d);
-    A4(m->ffn, T2 * cfg->tr_ffn);
+    A4(m->ffn, T2 * (cfg->tr_ffn > cfg->codebook_size ? cfg->tr_ffn : cfg->codebook_size));   // also the RVQ score buffer
     A4(m->kc, (long)cfg->tr_layers * m->cap_tokens * d); A4(m->vc, (long)cfg->tr_layers * m->cap_tokens * d);
 #undef A4
     MCHK((MimiDecoder*)nullptr, hipDeviceSynchronize());
@@ -345,9 +395,11 @@ extern "C" int mimi_reset_stream(mimi_handle m, void* stream) {
 
 static hipError_t gemm(hipStream_t st, const float* x, long ldx, long T_in, const float* w, const float* bias, int C_in,
                        int C_out, int taps, int phases, const int* shifts, int elu_in, int act_out, const float* col_scale,
-                       const float* resid, long ldr, float* out, long ldo) {
+                       const float* resid, long ldr, float* out, long ldo, int in_stride = 1, int edge = 0, int row_lo = 0,
+                       int row_hi = 0) {
     GemmArgs a;
     memset(&a, 0, sizeof a);
+    a.in_stride = in_stride; a.edge = edge; a.row_lo = row_lo; a.row_hi = row_hi;
     a.x = x; a.ldx = ldx; a.T_in = (int)T_in; a.C_in = C_in; a.C_out = C_out; a.w = w; a.bias = bias; a.taps = taps;
     a.phases = phases;
     for (int j = 0; j < taps; ++j) a.shift[j] = shifts[j];
@@ -440,6 +492,108 @@ static int slide_all(MimiDecoder* m, int T, hipStream_t st) {
         MCHK(m, slide(m->u[j], Tj, st)); MCHK(m, slide(m->xj[j], Tj, st));
     }
     return 0;
+}
+
+static long ceil_div(long a, long b) { return (a + b - 1) / b; }
+
+static int transformer_pass(MimiDecoder* m, const MimiTrLayer* layers, long T2, int offset, float* last_out, hipStream_t st) {
+    const MimiConfig& c = m->cfg;
+    const int d = c.hidden;
+    const int zero = 0;
+    for (int l = 0; l < c.tr_layers; ++l) {
+        const MimiTrLayer& L = layers[l];
+        float* kc = m->kc + (long)l * m->cap_tokens * d;
+        float* vc = m->vc + (long)l * m->cap_tokens * d;
+        hipLaunchKernelGGL(k_layernorm, dim3((unsigned)T2), dim3(64), 0, st, m->tok, d, L.ln1_w, L.ln1_b, c.norm_eps, m->ln);
+        MCHK(m, gemm(st, m->ln, d, T2, L.in_proj, nullptr, d, 3 * d, 1, 1, &zero, 0, 0, nullptr, nullptr, 0, m->qkv, 3 * d));
+        {
+            const long n = T2 * (d / 2);
+            hipLaunchKernelGGL(k_rope_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->qkv, (int)T2, d, offset,
+                               m->w.rope_freqs, m->q, kc, vc);
+        }
+        hipLaunchKernelGGL(k_mimi_attn, dim3((unsigned)T2, c.tr_heads), dim3(64), 0, st, m->q, kc, vc, d, offset, c.tr_context, m->att);
+        MCHK(m, gemm(st, m->att, d, T2, L.out_proj, nullptr, d, d, 1, 1, &zero, 0, 0, L.ls1, m->tok, d, m->tok, d));
+        hipLaunchKernelGGL(k_layernorm, dim3((unsigned)T2), dim3(64), 0, st, m->tok, d, L.ln2_w, L.ln2_b, c.norm_eps, m->ln);
+        MCHK(m, gemm(st, m->ln, d, T2, L.lin1, nullptr, d, c.tr_ffn, 1, 1, &zero, 0, 1, nullptr, nullptr, 0, m->ffn, c.tr_ffn));
+        float* dst = (l + 1 < c.tr_layers) ? m->tok : last_out;
+        MCHK(m, gemm(st, m->ffn, c.tr_ffn, T2, L.lin2, nullptr, c.tr_ffn, d, 1, 1, &zero, 0, 0, L.ls2, m->tok, d, dst, d));
+        MCHK(m, hipGetLastError());
+    }
+    return 0;
+}
+
+static int encode_one(MimiDecoder* m, const float* wav, long n, int32_t* codes, long T, hipStream_t st) {
+    const MimiConfig& c = m->cfg;
+    const MimiWeights& w = m->w;
+    const int d = c.hidden, S = c.n_stages;
+    const int zero = 0;
+    int shifts[MAX_TAPS];
+    // SEANet encoder; stage j lives in the decoder's stage buffers of index S-1-j (same time scale and width)
+    long L = n;
+    int C = c.n_filters;
+    {
+        const long tot = L * C;
+        hipLaunchKernelGGL(k_enc_conv_in, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, wav, L, c.kernel, C,
+                           w.enc_conv_in_w, w.enc_conv_in_b, m->u[S - 1].row0());
+    }
+    for (int j = 0; j < S; ++j) {
+        const int bi = S - 1 - j;
+        const MimiConv &r1 = w.enc_res1[j], &r2 = w.enc_res2[j], &dn = w.enc_down[j];
+        float* x = m->u[bi].row0();
+        for (int k = 0; k < r1.taps; ++k) shifts[k] = k - (r1.taps - 1);
+        MCHK(m, gemm(st, x, C, L, r1.w, r1.bias, r1.c_in, r1.c_out, r1.taps, 1, shifts, 1, 0, nullptr, nullptr, 0, m->r1[bi], r1.c_out,
+                     1, 1, 0, (int)L));
+        MCHK(m, gemm(st, m->r1[bi], r1.c_out, L, r2.w, r2.bias, r2.c_in, r2.c_out, 1, 1, &zero, 1, 0, nullptr, x, C, m->xj[bi].row0(), C,
+                     1, 1, 0, (int)L));
+        // ELU -> strided conv k = 2r: out[t] = sum_k W_k x[t*r + k - r]; zero padding on both sides
+        const int r = dn.taps / 2;
+        const long Lo = ceil_div(L, r);
+        for (int k = 0; k < dn.taps; ++k) shifts[k] = k - r;
+        float* out = (j + 1 < S) ? m->u[bi - 1].row0() : m->s0.row0();
+        MCHK(m, gemm(st, m->xj[bi].row0(), C, Lo, dn.w, dn.bias, dn.c_in, dn.c_out, dn.taps, 1, shifts, 1, 0, nullptr, nullptr, 0, out,
+                     dn.c_out, r, 1, 0, (int)L));
+        L = Lo; C = dn.c_out;
+    }
+    const MimiConv& co = w.enc_conv_out;
+    for (int k = 0; k < co.taps; ++k) shifts[k] = k - (co.taps - 1);
+    MCHK(m, gemm(st, m->s0.row0(), C, L, co.w, co.bias, co.c_in, co.c_out, co.taps, 1, shifts, 1, 0, nullptr, nullptr, 0, m->tok, d,
+                 1, 1, 0, (int)L));
+    // encoder transformer (stateless) -> a0
+    if (transformer_pass(m, w.enc_tr, L, 0, m->a0.row0(), st)) return -2;
+    // stride-2 downsample, replicate padding, no bias -> rvq buffer [T][d]
+    const int dshift[4] = {-2, -1, 0, 1};
+    MCHK(m, gemm(st, m->a0.row0(), d, T, w.downsample, nullptr, d, d, 4, 1, dshift, 0, 0, nullptr, nullptr, 0, m->rvq.row0(), d,
+                 2, 2, 0, (int)L));
+    // split RVQ: semantic level on in_proj_first(z), acoustic levels on in_proj_rest(z)
+    const int cd = c.codebook_dim;
+    float* res_first = m->ln;                   // [T][cd]
+    float* res_rest = m->q;                     // [T][cd]
+    MCHK(m, gemm(st, m->rvq.row0(), d, T, w.in_proj_first, nullptr, d, cd, 1, 1, &zero, 0, 0, nullptr, nullptr, 0, res_first, cd));
+    MCHK(m, gemm(st, m->rvq.row0(), d, T, w.in_proj_rest, nullptr, d, cd, 1, 1, &zero, 0, 0, nullptr, nullptr, 0, res_rest, cd));
+    for (int k = 0; k < c.n_codebooks; ++k) {
+        float* res = k < c.n_semantic ? res_first : res_rest;
+        const float* book = w.codebooks + (long)k * c.codebook_size * cd;
+        MCHK(m, gemm(st, res, cd, T, book, nullptr, cd, c.codebook_size, 1, 1, &zero, 0, 0, nullptr, nullptr, 0, m->ffn, c.codebook_size));
+        hipLaunchKernelGGL(k_rvq_pick, dim3((unsigned)T), dim3(256), 0, st, m->ffn, c.codebook_size,
+                           w.codebook_sqnorm + (long)k * c.codebook_size, book, cd, res, codes + (long)k * T, 1L);
+        MCHK(m, hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int mimi_encode(mimi_handle m, const float* wav, long n_samples, long stride_b, int B, int32_t* codes, void* stream) {
+    if (!m || !wav || !codes || B < 1 || n_samples < 1) return mfail(m, "mimi_encode: bad argument");
+    if (!m->w.has_encoder) return mfail(m, "mimi_encode: this codec was created without encoder weights");
+    long hop = 2;
+    for (int j = 0; j < m->cfg.n_stages; ++j) hop *= m->cfg.ratios[j];
+    const long T = ceil_div(n_samples, hop);
+    if (T > m->max_frames) return mfail(m, "mimi_encode: audio longer than hop * max_frames");
+    hipStream_t st = (hipStream_t)stream;
+    for (int b = 0; b < B; ++b) {
+        int rc = encode_one(m, wav + (long)b * stride_b, n_samples, codes + (long)b * m->cfg.n_codebooks * T, T, st);
+        if (rc) return rc;
+    }
+    return mimi_reset_stream(m, stream);      // the work buffers were reused: start any later stream from scratch
 }
 
 extern "C" int mimi_decode_strided(mimi_handle m, const int32_t* codes, int B, int T, long stride_b, long stride_k, long stride_t,

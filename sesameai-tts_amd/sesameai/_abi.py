@@ -82,6 +82,7 @@ MIMI_SIGNATURES = {
     "mimi_decode": (_i, [_vp, _vp, _i, _i, _l, _l, _vp, _i, _vp]),
     "mimi_decode_strided": (_i, [_vp, _vp, _i, _i, _l, _l, _l, _vp, _i, _vp]),
     "mimi_reset_stream": (_i, [_vp, _vp]),
+    "mimi_encode": (_i, [_vp, _vp, _l, _l, _i, _vp, _vp]),
 }
 
 for _name, (_res, _args) in list(SIGNATURES.items()) + list(MIMI_SIGNATURES.items()):

@@ -1,9 +1,9 @@
-"""Mimi codec (decode side) on gfx950 -- the object the reference keeps in
+"""Mimi codec (decode and encode) on gfx950 -- the object the reference keeps in
 ``Generator._audio_tokenizer`` (moshi ``loaders.get_mimi``, sesameai/generator.py:52-57).
 
 Surface used by the reference: ``.decode(codes[B,32,T]) -> [B,1,1920*T]`` (generator.py:116,299,
 tts_service.py:245), ``.sample_rate`` (generator.py:59), ``.set_num_codebooks(32)`` (:55) and
-``.encode(wav[B,1,n])`` (:86; voice prompts only -- not on the GPU yet, see DESIGN.md "next").
+``.encode(wav[B,1,n]) -> [B,32,ceil(n/1920)]`` (:86; voice prompts).
 All arithmetic runs in libcsm_hip.so (include/mimi_hip.h); this file only re-lays-out the
 checkpoint tensors into the tap-major form the kernels stream and owns the device memory.
 """
@@ -45,10 +45,16 @@ class _MimiWeights(C.Structure):
     _fields_ = [("codebooks", C.c_void_p), ("proj_first", C.c_void_p), ("proj_rest", C.c_void_p),
                 ("rope_freqs", C.c_void_p), ("upsample", C.c_void_p), ("tr", _MimiTrLayer * MAX_TR),
                 ("conv_in", _MimiConv), ("up", _MimiConv * MAX_ST), ("res1", _MimiConv * MAX_ST),
-                ("res2", _MimiConv * MAX_ST), ("conv_out", _MimiConv)]
+                ("res2", _MimiConv * MAX_ST), ("conv_out", _MimiConv),
+                ("has_encoder", C.c_int32), ("enc_conv_in_w", C.c_void_p), ("enc_conv_in_b", C.c_void_p),
+                ("enc_res1", _MimiConv * MAX_ST), ("enc_res2", _MimiConv * MAX_ST), ("enc_down", _MimiConv * MAX_ST),
+                ("enc_conv_out", _MimiConv), ("enc_tr", _MimiTrLayer * MAX_TR), ("downsample", C.c_void_p),
+                ("in_proj_first", C.c_void_p), ("in_proj_rest", C.c_void_p), ("codebook_sqnorm", C.c_void_p)]
 
 
 lib.mimi_create.argtypes = [C.POINTER(_MimiConfig), C.POINTER(_MimiWeights), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+lib.mimi_encode.restype = C.c_int
+lib.mimi_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_void_p]
 lib.mimi_decode_strided.restype = C.c_int
 lib.mimi_decode_strided.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long,
                                     C.c_void_p, C.c_int, C.c_void_p]
@@ -115,12 +121,45 @@ def state_dict_layout(s: MimiArgs) -> List[Tuple[str, Tuple[int, ...], str]]:
     return out
 
 
-def synthetic_state_dict(s: MimiArgs, seed: int = 4321) -> Dict[str, torch.Tensor]:
+def encoder_state_dict_layout(s: MimiArgs) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """Encode-side tensors (SEANet encoder, encoder transformer, stride-2 downsample, RVQ input projections)."""
+    out: List[Tuple[str, Tuple[int, ...], str]] = []
+    c, d = s.n_filters, s.hidden
+    out += [("enc.conv_in.weight", (c, 1, s.kernel), "conv"), ("enc.conv_in.bias", (c,), "small")]
+    for j, r in enumerate(reversed(s.ratios)):
+        h = c // s.compress
+        out += [(f"enc.down.{j}.res.conv1.weight", (h, c, s.res_kernel), "conv"), (f"enc.down.{j}.res.conv1.bias", (h,), "small"),
+                (f"enc.down.{j}.res.conv2.weight", (c, h, 1), "conv"), (f"enc.down.{j}.res.conv2.bias", (c,), "small"),
+                (f"enc.down.{j}.conv.weight", (2 * c, c, 2 * r), "conv"), (f"enc.down.{j}.conv.bias", (2 * c,), "small")]
+        c *= 2
+    out += [("enc.conv_out.weight", (d, c, s.last_kernel), "conv"), ("enc.conv_out.bias", (d,), "small")]
+    for i in range(s.tr_layers):
+        L = f"enc_transformer.{i}"
+        out += [(f"{L}.norm1.weight", (d,), "ones"), (f"{L}.norm1.bias", (d,), "small"),
+                (f"{L}.in_proj_weight", (3 * d, d), "linear"), (f"{L}.out_proj.weight", (d, d), "linear"),
+                (f"{L}.layer_scale_1.scale", (d,), "scale"),
+                (f"{L}.norm2.weight", (d,), "ones"), (f"{L}.norm2.bias", (d,), "small"),
+                (f"{L}.linear1.weight", (s.tr_ffn, d), "linear"), (f"{L}.linear2.weight", (d, s.tr_ffn), "linear"),
+                (f"{L}.layer_scale_2.scale", (d,), "scale")]
+    out += [("downsample.conv.weight", (d, d, 4), "conv"),
+            ("rvq_first.input_proj.weight", (s.codebook_dim, d, 1), "conv"),
+            ("rvq_rest.input_proj.weight", (s.codebook_dim, d, 1), "conv")]
+    return out
+
+
+def synthetic_state_dict(s: MimiArgs, seed: int = 4321, encoder: bool = True) -> Dict[str, torch.Tensor]:
     """Seeded random fp32 weights of the true shapes (no checkpoint can be downloaded here):
-    codebooks N(0,1), convs/linears U(+-sqrt(3/fan_in)) so activations stay O(1)."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
+    codebooks N(0,1), convs/linears U(+-sqrt(3/fan_in)) so activations stay O(1).  The encode-side
+    tensors come from a second generator (seed + 1)."""
     w: Dict[str, torch.Tensor] = {}
-    for name, shp, kind in state_dict_layout(s):
+    _fill(w, state_dict_layout(s), torch.Generator(device="cpu").manual_seed(seed))
+    if encoder:
+        _fill(w, encoder_state_dict_layout(s), torch.Generator(device="cpu").manual_seed(seed + 1))
+    return w
+
+
+def _fill(w: Dict[str, torch.Tensor], names, g: torch.Generator) -> None:
+    for name, shp, kind in names:
         if kind == "normal":
             t = torch.randn(shp, generator=g)
         elif kind == "usage":
@@ -140,7 +179,6 @@ def synthetic_state_dict(s: MimiArgs, seed: int = 4321) -> Dict[str, torch.Tenso
                 fan_in = shp[1]
             t = (torch.rand(shp, generator=g) * 2 - 1) * math.sqrt(3.0 / fan_in)
         w[name] = t.float()
-    return w
 
 
 def from_moshi_state_dict(sd: Dict[str, torch.Tensor], s: MimiArgs) -> Dict[str, torch.Tensor]:
@@ -257,6 +295,25 @@ class MimiCodec:
             w.res1[j] = self._conv(sd[f"seanet.up.{j}.res.conv1.weight"], sd[f"seanet.up.{j}.res.conv1.bias"])
             w.res2[j] = self._conv(sd[f"seanet.up.{j}.res.conv2.weight"], sd[f"seanet.up.{j}.res.conv2.bias"])
         w.conv_out = self._conv(sd["seanet.conv_out.weight"], sd["seanet.conv_out.bias"])
+        self.has_encoder = all(n in sd for n, _, _ in encoder_state_dict_layout(s))
+        w.has_encoder = int(self.has_encoder)
+        if self.has_encoder:
+            w.enc_conv_in_w = self._dev(sd["enc.conv_in.weight"][:, 0, :].t())          # [taps][C]
+            w.enc_conv_in_b = self._dev(sd["enc.conv_in.bias"])
+            for j, r in enumerate(reversed(s.ratios)):
+                w.enc_res1[j] = self._conv(sd[f"enc.down.{j}.res.conv1.weight"], sd[f"enc.down.{j}.res.conv1.bias"])
+                w.enc_res2[j] = self._conv(sd[f"enc.down.{j}.res.conv2.weight"], sd[f"enc.down.{j}.res.conv2.bias"])
+                w.enc_down[j] = self._conv(sd[f"enc.down.{j}.conv.weight"], sd[f"enc.down.{j}.conv.bias"])   # taps = 2r, stride r
+            w.enc_conv_out = self._conv(sd["enc.conv_out.weight"], sd["enc.conv_out.bias"])
+            for i in range(s.tr_layers):
+                L = f"enc_transformer.{i}"
+                w.enc_tr[i] = _MimiTrLayer(*[self._dev(sd[f"{L}.{n}"]) for n in (
+                    "norm1.weight", "norm1.bias", "in_proj_weight", "out_proj.weight", "layer_scale_1.scale",
+                    "norm2.weight", "norm2.bias", "linear1.weight", "linear2.weight", "layer_scale_2.scale")])
+            w.downsample = self._dev(sd["downsample.conv.weight"].permute(2, 0, 1))       # [4][out][in]
+            w.in_proj_first = self._dev(sd["rvq_first.input_proj.weight"][:, :, 0])       # [cd][d]
+            w.in_proj_rest = self._dev(sd["rvq_rest.input_proj.weight"][:, :, 0])
+            w.codebook_sqnorm = self._dev(books.pow(2).sum(-1))                           # [K][2048]
         return cfg, w
 
     # -- reference surface ----------------------------------------------------------------------------
@@ -264,9 +321,18 @@ class MimiCodec:
         if n != self.args.num_codebooks:
             raise ValueError(f"this codec is built for {self.args.num_codebooks} codebooks")
 
+    @torch.inference_mode()
     def encode(self, wav: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("Mimi ENCODE (voice-prompt audio -> codes) is not on the GPU yet (SURVEY.md 8(f) item 2); "
-                                  "pass pre-computed codes via Segment.audio_codes")
+        """wav (B,1,n) fp32 @ 24 kHz -> codes (B,32,ceil(n/1920)) int64 (generator.py:86)."""
+        if not self.has_encoder:
+            raise RuntimeError("this MimiCodec was built without encoder weights; pass Segment.audio_codes instead")
+        assert wav.dim() == 3 and wav.shape[1] == 1, "wav must be (B, 1, n)"
+        B, _, n = wav.shape
+        T = -(-n // self.args.hop)
+        x = wav.to(device=self.device, dtype=torch.float32).contiguous()
+        codes = torch.empty(B, self.args.num_codebooks, T, dtype=torch.int32, device=self.device)
+        check(lib.mimi_encode(self._h, x.data_ptr(), n, x.stride(0), B, codes.data_ptr(), _stream()), self._h, mimi=True)
+        return codes.long()
 
     def _run(self, codes: torch.Tensor, stateful: bool) -> torch.Tensor:
         assert codes.dim() == 3 and codes.shape[1] == self.args.num_codebooks, "codes must be (B, 32, T)"

@@ -18,7 +18,7 @@ def tiny_codec():
     from oracle import mimi_ref as M
     from sesameai.mimi import MimiCodec, mimi_tiny_args, synthetic_state_dict
     s = M.mimi_tiny()
-    w = M.make_weights(s, seed=4321)
+    w = M.make_weights(s, seed=4321, encoder=True)
     sd = synthetic_state_dict(mimi_tiny_args(), seed=4321)
     assert set(w) == set(sd) and all(torch.equal(w[k], sd[k]) for k in w), "product and oracle synthetic Mimi weights differ"
     return s, w, MimiCodec(mimi_tiny_args(), sd, max_frames=64)
@@ -77,6 +77,43 @@ def test_codes_beyond_codebook_are_clamped(tiny_codec):
     hi = codes.clone(); hi[0, 5, 2] = 2050
     cl = codes.clone(); cl[0, 5, 2] = 2047
     assert torch.equal(codec.decode(hi), codec.decode(cl))
+
+
+def _check_codes(got, want, what):
+    """RVQ codes are integers; the only freedom is an fp32 near-tie between two centroids, after
+    which the remaining levels of that frame legitimately differ.  Require >= 90 % of the frames
+    to match on all 32 levels and the first codebook (semantic) to match almost everywhere."""
+    got, want = got.cpu(), want.cpu()
+    assert got.shape == want.shape and got.dtype == torch.int64
+    frames_ok = (got == want).all(dim=1).float().mean().item()
+    first_ok = (got[:, 0] == want[:, 0]).float().mean().item()
+    print(f"{what}: frames identical on all levels {frames_ok:.3f}, semantic codebook {first_ok:.3f}, all codes {(got == want).float().mean().item():.3f}")
+    assert frames_ok >= 0.9 and first_ok >= 0.97
+
+
+def test_tiny_encode_vs_oracle(tiny_codec):
+    """Mimi ENCODE (voice-prompt audio -> codes, generator.py:86): ragged length, batch of 2."""
+    from oracle import mimi_ref as M
+    s, w, codec = tiny_codec
+    wav = torch.randn(2, 1, 1920 * 9 + 777, generator=torch.Generator().manual_seed(12)) * 0.3
+    codes = codec.encode(wav)
+    assert codes.shape == (2, 32, 10)
+    _check_codes(codes, M.encode(s, w, wav), "tiny encode")
+    # encode -> decode round trip runs and has the right length
+    pcm = codec.decode(codes)
+    assert pcm.shape == (2, 1, 10 * 1920) and torch.isfinite(pcm).all()
+
+
+def test_full_size_encode_vs_oracle():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import mimi_ref as M
+    from sesameai.mimi import MimiArgs, MimiCodec, synthetic_state_dict
+    s = M.mimi_full()
+    w = M.make_weights(s, seed=4321, encoder=True)
+    codec = MimiCodec(MimiArgs(), synthetic_state_dict(MimiArgs(), seed=4321), max_frames=32)
+    wav = torch.randn(1, 1, 1920 * 20 + 5, generator=torch.Generator().manual_seed(13)) * 0.3
+    _check_codes(codec.encode(wav), M.encode(s, w, wav), "full-size encode")
 
 
 def test_full_size_decode_vs_golden():

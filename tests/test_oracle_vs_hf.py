@@ -95,6 +95,23 @@ def test_mimi_decode_matches_hf(which):
     assert (mine - theirs).abs().max() <= 1e-5 * theirs.abs().max()
 
 
+@pytest.mark.parametrize("which", ["tiny", "full"])
+def test_mimi_encode_matches_hf(which):
+    """ENCODE side (SEANet encoder, encoder transformer, replicate-padded stride-2 downsample,
+    split RVQ nearest-centroid search) against transformers' MimiModel.encode."""
+    s = M.mimi_tiny() if which == "tiny" else M.mimi_full()
+    w = M.make_weights(s, encoder=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hf = build_hf_mimi(s, w)
+    wav = torch.randn(2, 1, 1920 * 7 + 333, generator=torch.Generator().manual_seed(1)) * 0.3
+    mine = M.encode(s, w, wav)
+    with torch.no_grad():
+        theirs = hf.encode(wav)[0]
+    assert mine.shape == theirs.shape == (2, 32, 8)
+    assert (mine == theirs).all(dim=1).float().mean() >= 0.95          # whole frames (fp32 near-ties aside)
+
+
 def test_mimi_decode_is_causal_and_stateless_chunks_differ():
     """frames >= t never change samples < 1920 t; the reference's stateless
     10-frame chunking (generator.py:111-117) is NOT equal to whole decode after chunk 0."""
