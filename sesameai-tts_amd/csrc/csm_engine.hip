@@ -46,6 +46,7 @@ struct CsmModel {
     bf16_t *h, *q, *att, *act;          // backbone rows [max_rows][..]
     float* part;                        // [PART_ROWS][H][NSPLIT][hd+2]
     bf16_t *dec_in;                     // [B][2][d_bb]   row0 = last_h, row1 = c0 embedding
+    float* slab;                        // [8][max_rows][max(d_bb, d_dec)] fp32 split-K partials of the wide path
     bf16_t *pk_projection, *pk_c0_head, *pk_audio_head;   // packed copies for the wide-M path
     long pk_head_stride;                // elements between packed audio heads
     std::vector<void*> pk_allocs;
@@ -151,6 +152,28 @@ static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStrea
     return hipGetLastError();
 }
 
+// residual projections of the wide path: fp32 partial tiles into a.slab, K split over `kg` blocks
+static int slab_groups(int M, int K) {
+    if (M > 64) return 1;                                  // enough row tiles already
+    int kg = K / 1024;                                     // 1024 k per block (256 per wave)
+    return kg < 1 ? 1 : (kg > 8 ? 8 : kg);
+}
+static hipError_t launch_mm_slab(int K, int kg, const GemvArgs& a, hipStream_t st) {
+    if (K % (256 * kg) != 0) return hipErrorInvalidValue;
+    dim3 grid((a.N + 31) / 32, (a.M + 31) / 32, kg);
+    hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4>), grid, dim3(256), 0, st, a, K);
+    return hipGetLastError();
+}
+static hipError_t launch_resid_norm(bf16_t* h, const float* slab, int kg, int M, int N, long row_step, long row_first, int M_out,
+                                    const bf16_t* scale, float eps, bf16_t* xn, long xn_stride, hipStream_t st) {
+    dim3 grid((M_out + 3) / 4);
+    if (N <= 512) hipLaunchKernelGGL((k_resid_norm<1>), grid, dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, M_out, scale, eps, xn, xn_stride);
+    else if (N <= 1024) hipLaunchKernelGGL((k_resid_norm<2>), grid, dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, M_out, scale, eps, xn, xn_stride);
+    else if (N <= 2048) hipLaunchKernelGGL((k_resid_norm<4>), grid, dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, M_out, scale, eps, xn, xn_stride);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 static hipError_t launch_rmsnorm_rows(const bf16_t* x, long stride, long offset, int M, int K, const bf16_t* scale, float eps,
                                       bf16_t* out, long out_stride, hipStream_t st) {
     hipLaunchKernelGGL(k_rmsnorm_rows, dim3((M + 3) / 4), dim3(256), 0, st, x, stride, offset, M, K, scale, eps, out, out_stride);
@@ -184,7 +207,8 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         bf16_t* kc = S.kc + (long)l * S.layer_stride;
         bf16_t* vc = S.vc + (long)l * S.layer_stride;
         GemvArgs a;
-        if ((e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+        // layer 0 normalises h directly; later layers got xn from the previous down-projection's finisher
+        if (l == 0 && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = d; a.M = M;
         a.w0 = (const bf16_t*)pk.wq; a.w1 = (const bf16_t*)pk.wk; a.w2 = (const bf16_t*)pk.wv;
@@ -197,17 +221,23 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = 1;
         t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
         if ((e = launch_attn(S.hd, t, st)) != hipSuccess) return e;
+        // o-proj -> fp32 slabs; finisher: h += sum(slabs), xn = mlp_norm(h)
         memset(&a, 0, sizeof a);
-        a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)pk.wo; a.N = d; a.out = h; a.ldo = d; a.resid = h;
-        if ((e = launch_mm(1, S.nq, S.hd, a, st)) != hipSuccess) return e;
-        if ((e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+        a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)pk.wo; a.N = d; a.slab = m->slab;
+        int kg = slab_groups(M, S.nq);
+        if ((e = launch_mm_slab(S.nq, kg, a, st)) != hipSuccess) return e;
+        if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = d; a.M = M; a.w0 = (const bf16_t*)pk.w1; a.w1 = (const bf16_t*)pk.w3; a.N = S.d.ffn;
         a.out = act; a.ldo = S.d.ffn;
         if ((e = launch_mm(4, d, S.hd, a, st)) != hipSuccess) return e;
+        // down-proj -> slabs; finisher applies the NEXT layer's sa_norm (or nothing after the last layer)
         memset(&a, 0, sizeof a);
-        a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)pk.w2; a.N = d; a.out = h; a.ldo = d; a.resid = h;
-        if ((e = launch_mm(1, S.d.ffn, S.hd, a, st)) != hipSuccess) return e;
+        a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)pk.w2; a.N = d; a.slab = m->slab;
+        kg = slab_groups(M, S.d.ffn);
+        if ((e = launch_mm_slab(S.d.ffn, kg, a, st)) != hipSuccess) return e;
+        const bf16_t* next_scale = (l + 1 < S.d.n_layers) ? (const bf16_t*)S.lw[l + 1].sa_norm : nullptr;
+        if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, next_scale, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -460,6 +490,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     ALLOC(m->part, (size_t)PART_ROWS * cfg->backbone.n_heads * BB_NSPLIT_MAX * (m->bb.hd + 4) * 4);
     ALLOC(m->dec_in, (size_t)max_batch * 2 * dbb * 2);
     ALLOC(m->proj_emb, (size_t)ncb * cfg->audio_vocab * dd * 2);
+    ALLOC(m->slab, (size_t)8 * max_rows * (dbb > dd ? dbb : dd) * 4);
     ALLOC(m->hdec, (size_t)2 * max_batch * dd * 2);
     ALLOC(m->qd, (size_t)2 * max_batch * m->dec.nq * 2);
     ALLOC(m->attd, (size_t)2 * max_batch * m->dec.nq * 2);
@@ -519,7 +550,7 @@ extern "C" void csm_destroy(csm_handle m) {
     if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
     if (m->graph) (void)hipGraphDestroy(m->graph);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
-    void* ptrs[] = {m->bb.kc, m->bb.vc, m->dec.kc, m->dec.vc, m->h, m->q, m->att, m->act, m->part, m->dec_in, m->proj_emb,
+    void* ptrs[] = {m->bb.kc, m->bb.vc, m->dec.kc, m->dec.vc, m->h, m->q, m->att, m->act, m->part, m->dec_in, m->proj_emb, m->slab,
                     m->hdec, m->qd, m->attd, m->actd, m->logits, m->frame, m->cur_tokens, m->cur_mask, m->cur_pos,
                     m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos};
     for (void* p : ptrs) (void)hipFree(p);

@@ -16,7 +16,7 @@
 #include "common.cuh"
 
 enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_ATTN = 2, PRO_COMBINE = 3 };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV_ROPE = 2, EPI_SWIGLU = 3 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV_ROPE = 2, EPI_SWIGLU = 3, EPI_SLAB = 4 };
 
 struct GemvArgs {
     // activations: row m lives at x + m * x_row_stride + x_row_offset (elements), K wide
@@ -53,6 +53,8 @@ struct GemvArgs {
     // PRO_COMBINE (backbone split-K attention): activation row = merged partial softmax states
     const float* part;          // [M][aH][nsplit][64 + 4]: o[64], m, l, pad
     int nsplit;
+    // EPI_SLAB (wide-M split-K): fp32 partial sums, slab g of [gridDim.z][M][N]
+    float* slab;
 };
 
 // Depth-decoder attention fused into the output projection's prologue (hd = 128, at most 32

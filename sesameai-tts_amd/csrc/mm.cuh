@@ -44,6 +44,61 @@ __global__ __launch_bounds__(256) void k_rmsnorm_rows(const bf16_t* x, long x_ro
     }
 }
 
+// Finishes a split-K residual projection of the wide path and (optionally) applies the next RMSNorm:
+//   h[r] = bf16(h[r] + bf16(sum_g slab[g][r]))      (fixed g order: deterministic)
+//   xn[i] = RMSNorm(h[r]) * scale                   (skipped when scale == nullptr)
+// for output row i, r = i * row_step + row_first (row selection = "last row of every sequence" for the heads).
+// One wave per row; the row stays in registers between the two passes (N <= 64 * 8 * NCH).
+template <int NCH>
+__global__ __launch_bounds__(256) void k_resid_norm(bf16_t* h, const float* slab, int KG, int M, int N, long row_step, long row_first,
+                                                    int M_out, const bf16_t* scale, float eps, bf16_t* xn, long xn_stride) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= M_out) return;
+    const long r = (long)i * row_step + row_first;
+    float v[NCH][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = (c * 64 + lane) * 8;
+        if (col >= N) continue;
+        const uint4 hv = *reinterpret_cast<const uint4*>(h + r * N + col);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int g = 0; g < KG; ++g) {
+            const float4 p0 = *reinterpret_cast<const float4*>(slab + ((long)g * M + r) * N + col);
+            const float4 p1 = *reinterpret_cast<const float4*>(slab + ((long)g * M + r) * N + col + 4);
+            acc[0] += p0.x; acc[1] += p0.y; acc[2] += p0.z; acc[3] += p0.w;
+            acc[4] += p1.x; acc[5] += p1.y; acc[6] += p1.z; acc[7] += p1.w;
+        }
+        const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float hj = (j & 1) ? hi2f(hw[j >> 1]) : lo2f(hw[j >> 1]);
+            v[c][j] = round_bf(hj + round_bf(acc[j]));
+            ss += v[c][j] * v[c][j];
+        }
+        uint4 o;
+        o.x = pack_bf(v[c][0], v[c][1]); o.y = pack_bf(v[c][2], v[c][3]); o.z = pack_bf(v[c][4], v[c][5]); o.w = pack_bf(v[c][6], v[c][7]);
+        *reinterpret_cast<uint4*>(h + r * N + col) = o;
+    }
+    if (scale == nullptr) return;
+    ss = wave_sum(ss);
+    const float rs = 1.0f / sqrtf(ss / (float)N + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = (c * 64 + lane) * 8;
+        if (col >= N) continue;
+        const uint4 g = *reinterpret_cast<const uint4*>(scale + col);
+        uint4 o;
+        o.x = pack_bf(round_bf(v[c][0] * rs) * lo2f(g.x), round_bf(v[c][1] * rs) * hi2f(g.x));
+        o.y = pack_bf(round_bf(v[c][2] * rs) * lo2f(g.y), round_bf(v[c][3] * rs) * hi2f(g.y));
+        o.z = pack_bf(round_bf(v[c][4] * rs) * lo2f(g.z), round_bf(v[c][5] * rs) * hi2f(g.z));
+        o.w = pack_bf(round_bf(v[c][6] * rs) * lo2f(g.w), round_bf(v[c][7] * rs) * hi2f(g.w));
+        *reinterpret_cast<uint4*>(xn + (long)i * xn_stride + col) = o;
+    }
+}
+
 __device__ __forceinline__ bf16x8_t as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
 
 // Matrix-core operand order for the weight stream ("memory laid out for the hardware"): W [N][K]
@@ -89,7 +144,9 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K)
         if (EPI == EPI_SWIGLU) wb = reinterpret_cast<const uint4*>(a.w1) + (long)(n0 / 32) * tile_u4;
     }
     const bf16_t* xa = a.x + (long)mrow * a.x_row_stride + a.x_row_offset;
-    const int kspan = K / NW, kbeg = wave * kspan, kend = kbeg + kspan;
+    // EPI_SLAB: gridDim.z blocks split K further; each writes its fp32 partial tile to slab[blockIdx.z]
+    const int kblk = K / gridDim.z;
+    const int kspan = kblk / NW, kbeg = blockIdx.z * kblk + wave * kspan, kend = kbeg + kspan;
     f32x16_t acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
@@ -140,6 +197,10 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K)
             float s0 = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) s0 += red[0][w][reg][lane];       // fixed order: deterministic
+            if (EPI == EPI_SLAB) {
+                if (m < a.M && n < a.N) a.slab[((long)blockIdx.z * a.M + m) * a.N + n] = s0;
+                continue;
+            }
             float y = round_bf(s0);
             if (EPI == EPI_QKV_ROPE) {
                 // partner column n^1 lives in the neighbouring lane; every lane must take part in the shuffle
