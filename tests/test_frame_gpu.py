@@ -218,6 +218,47 @@ def test_prompt_too_long_raises(tiny):
         gen.generate_codes(tok, msk, int(30_000 / 80), 0.9, 50)      # 1700 >= 2048 - 375
 
 
+def test_long_context_streaming_config5_shape():
+    """BASELINE config 5 shape at CSM-1B size (bf16 here): 10 prompt segments -> S = 1334 rows,
+    375 frames (30 s), Mimi decoded statefully every 10 frames.  Checks the position guard
+    (1334 + 375 <= 2048), that the run completes without EOS on random weights, and that the
+    streamed audio equals the whole-utterance decode of the same codes."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sesameai.generator import Generator
+    from sesameai.mimi import MimiArgs, MimiCodec
+    from sesameai.models import Model, csm_1b_args
+    g = torch.Generator().manual_seed(5)
+    rows_t, rows_m = [], []
+    for seg in range(10):
+        t = torch.zeros(131, 33, dtype=torch.long); mk = torch.zeros(131, 33, dtype=torch.bool)
+        t[:30, 32] = torch.randint(0, 128256, (30,), generator=g); mk[:30, 32] = True
+        t[30:130, :32] = torch.randint(0, 2048, (100, 32), generator=g); mk[30:, :32] = True      # + EOS row
+        rows_t.append(t); rows_m.append(mk)
+    t = torch.zeros(24, 33, dtype=torch.long); mk = torch.zeros(24, 33, dtype=torch.bool)
+    t[:, 32] = torch.randint(0, 128256, (24,), generator=g); mk[:, 32] = True
+    tok, msk = torch.cat(rows_t + [t]), torch.cat(rows_m + [mk])
+    assert tok.shape[0] == 1334
+    model = Model(csm_1b_args(), None, max_frames=400, max_prefill_rows=1400)
+    codec = MimiCodec(MimiArgs(), None, max_frames=400)
+    gen = Generator(model, audio_tokenizer=codec)
+    model.seed(11)
+    chunks = []
+    codec.reset_stream()
+
+    def on_frames(fr):                                            # fr: [n][1][32] -> stateful Mimi stream
+        chunks.append(codec.decode_stream(fr.permute(1, 2, 0).contiguous()))
+
+    frames = gen.generate_codes(tok, msk, 375, 0.9, 50, on_frames=on_frames, poll=10)
+    assert frames.shape == (375, 1, 32) and int(gen.last_eos_at[0]) == -1
+    streamed = torch.cat(chunks, dim=-1)
+    whole = codec.decode(frames.permute(1, 2, 0).contiguous())
+    assert streamed.shape == whole.shape == (1, 1, 375 * 1920)
+    assert (streamed - whole).abs().max().item() <= 1e-5 * whole.abs().max().item()
+    with pytest.raises(ValueError, match="Inputs too long"):
+        gen.generate_codes(tok, msk, 2048 - 1334, 0.9, 50)         # S >= 2048 - max_generation_len
+
+
 def test_csm1b_teacher_forced_vs_golden():
     """Full CSM-1B shapes, seeded weights: logits (top-8 per row) and greedy indices for every
     codebook of every golden frame, teacher-forced on the oracle's trajectory."""
