@@ -133,6 +133,42 @@ def synthetic_state_dict(args: ModelArgs, seed: int = 1234, std: float = 0.02) -
     return sd
 
 
+def from_hf_state_dict(args: ModelArgs, hf: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Converts a ``transformers`` ``CsmForConditionalGeneration`` checkpoint (the HF-format
+    ``sesame/csm-1b`` repo) to the reference's torchtune layout.  The HF port uses half-split RoPE,
+    so each head's q/k rows were permuted by ``cat(arange(0,hd,2), arange(1,hd,2))`` at conversion;
+    this applies the inverse permutation."""
+    def unperm(w: torch.Tensor, n_heads: int, hd: int) -> torch.Tensor:
+        perm = torch.cat([torch.arange(0, hd, 2), torch.arange(1, hd, 2)])
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(hd)
+        return w.view(n_heads, hd, -1)[:, inv, :].reshape(n_heads * hd, -1)
+
+    out: Dict[str, torch.Tensor] = {
+        "text_embeddings.weight": hf["embed_text_tokens.weight"],
+        "audio_embeddings.weight": hf["backbone_model.embed_tokens.embed_audio_tokens.weight"],
+        "projection.weight": hf["depth_decoder.model.inputs_embeds_projector.weight"],
+        "codebook0_head.weight": hf["lm_head.weight"],
+        "audio_head": hf["depth_decoder.codebooks_head.weight"],
+        "backbone.norm.scale": hf["backbone_model.norm.weight"],
+        "decoder.norm.scale": hf["depth_decoder.model.norm.weight"],
+    }
+    for pfx, hpfx, f in (("backbone", "backbone_model", FLAVORS[args.backbone_flavor]),
+                         ("decoder", "depth_decoder.model", FLAVORS[args.decoder_flavor])):
+        for i in range(f.num_layers):
+            L, Hh = f"{pfx}.layers.{i}", f"{hpfx}.layers.{i}"
+            out[f"{L}.attn.q_proj.weight"] = unperm(hf[f"{Hh}.self_attn.q_proj.weight"], f.num_heads, f.head_dim)
+            out[f"{L}.attn.k_proj.weight"] = unperm(hf[f"{Hh}.self_attn.k_proj.weight"], f.num_kv_heads, f.head_dim)
+            out[f"{L}.attn.v_proj.weight"] = hf[f"{Hh}.self_attn.v_proj.weight"]
+            out[f"{L}.attn.output_proj.weight"] = hf[f"{Hh}.self_attn.o_proj.weight"]
+            out[f"{L}.mlp.w1.weight"] = hf[f"{Hh}.mlp.gate_proj.weight"]
+            out[f"{L}.mlp.w3.weight"] = hf[f"{Hh}.mlp.up_proj.weight"]
+            out[f"{L}.mlp.w2.weight"] = hf[f"{Hh}.mlp.down_proj.weight"]
+            out[f"{L}.sa_norm.scale"] = hf[f"{Hh}.input_layernorm.weight"]
+            out[f"{L}.mlp_norm.scale"] = hf[f"{Hh}.post_attention_layernorm.weight"]
+    return out
+
+
 def _stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -184,7 +220,10 @@ class Model:
         import os
         from safetensors.torch import load_file
         f = path if path.endswith(".safetensors") else os.path.join(path, "model.safetensors")
-        return cls(csm_1b_args(), load_file(f), device=device, **kw)
+        sd = load_file(f)
+        if "backbone_model.norm.weight" in sd:          # transformers-format checkpoint
+            sd = from_hf_state_dict(csm_1b_args(), sd)
+        return cls(csm_1b_args(), sd, device=device, **kw)
 
     def parameters(self):
         return iter(self._w.values())

@@ -77,6 +77,27 @@ def test_generate_codes_stops_at_eos_and_guards_length():
     assert len(frames) == 2 and calls["n"] == 3
 
 
+def test_hf_checkpoint_conversion_round_trip():
+    """a transformers-format CSM checkpoint (half-split RoPE rows) converts back to the reference layout."""
+    pytest.importorskip("transformers.models.csm.modeling_csm")
+    import warnings
+    from oracle.hf_map import build_hf_csm
+    from sesameai.models import csm_tiny_args, from_hf_state_dict
+    shape = C.csm_tiny()
+    w = {k: v.float() for k, v in C.make_weights(shape, norm_jitter=0.1).items()}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bb, dd, heads = build_hf_csm(shape, w)
+    hf = {f"backbone_model.{k}": v for k, v in bb.state_dict().items()}
+    hf.update({f"depth_decoder.model.{k}": v for k, v in dd.state_dict().items()})
+    hf["embed_text_tokens.weight"] = w["text_embeddings.weight"]
+    hf["lm_head.weight"] = w["codebook0_head.weight"]
+    hf["depth_decoder.codebooks_head.weight"] = heads
+    back = from_hf_state_dict(csm_tiny_args(), hf)
+    for k, v in w.items():
+        assert torch.equal(back[k].float(), v), k
+
+
 WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "sesameai-tts_amd"))
