@@ -33,6 +33,8 @@ int main(int argc, char** argv) {
         {"dec gateup(swiglu)   33.5MB x16 sets(HBM)", 4, 33554432, 16}, {"dec down (resid) 16.8MB x32 sets(HBM)", 11, 16777216, 32},
         {"dec qkv  3.1MB x124 sets (HBM)", 3, 3145728, 124}, {"head 2051x1024 4.2MB x31 sets", 2, 4200448, 31},
         {"proj 1024x2048 plain 4.2MB x1", 0, 4194304, 1},
+        {"dec gateup R=2 (1 pair/wave)  x4 sets", 42, 33554432, 4}, {"dec gateup R=8 (4 pairs/wave) x4 sets", 48, 33554432, 4},
+        {"dec down R=2 (2 rows/wave)    x4 sets", 112, 16777216, 4},
     };
     // ---- mixed chain: the real depth-decoder step: proj, 4 x (qkv, oproj, gateup, down), head; 31 steps ----
     // weights: 4 layer sets (58 MB each) + proj 4.2 MB + 31 heads x 4.2 MB, like the real frame
@@ -101,6 +103,9 @@ int main(int argc, char** argv) {
                 case 4: a.x_row_stride = 1024; a.w0 = wl; a.w1 = wl + 8192 * 1024; a.N = 8192; a.out = out; a.ldo = 8192; launch<2, 4, PRO_NORM, EPI_SWIGLU, 64>(a, 4096, st); break;
                 case 11: a.x_row_stride = 8192; a.w0 = wl; a.N = 1024; a.out = out; a.ldo = 1024; a.resid = out; launch<16, 1, PRO_PLAIN, EPI_RESID, 64>(a, 1024, st); break;
                 case 2: a.x_row_stride = 1024; a.w0 = wl; a.N = 2051; a.out = out; a.ldo = 2560; launch<2, 2, PRO_NORM, EPI_STORE, 64>(a, 1026, st); break;
+                case 42: a.x_row_stride = 1024; a.w0 = wl; a.w1 = wl + 8192 * 1024; a.N = 8192; a.out = out; a.ldo = 8192; launch<2, 2, PRO_NORM, EPI_SWIGLU, 64>(a, 8192, st); break;
+                case 48: a.x_row_stride = 1024; a.w0 = wl; a.w1 = wl + 8192 * 1024; a.N = 8192; a.out = out; a.ldo = 8192; launch<2, 8, PRO_NORM, EPI_SWIGLU, 64>(a, 2048, st); break;
+                case 112: a.x_row_stride = 8192; a.w0 = wl; a.N = 1024; a.out = out; a.ldo = 1024; a.resid = out; launch<16, 2, PRO_PLAIN, EPI_RESID, 64>(a, 512, st); break;
                 case 0: a.x_row_stride = 2048; a.w0 = wl; a.N = 1024; a.out = out; a.ldo = 1024; launch<4, 2, PRO_PLAIN, EPI_STORE, 64>(a, 512, st); break;
             }
         }
