@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle frames to time")
     ap.add_argument("--cpu-threads", type=int, default=min(32, os.cpu_count() or 1))
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16",
+                    help="fp8 = OCP-e4m3 weight stream for the decode step (BASELINE config 5; not the headline)")
     ap.add_argument("--tiny", action="store_true", help="tiny shapes (plumbing check only; not a valid bench)")
     args = ap.parse_args()
     if args.cpu_worker:
@@ -157,7 +159,7 @@ def main():
     else:
         sd = synthetic_state_dict(margs, seed=1234)
     model = Model(margs, sd, device=str(dev), max_frames=args.steps + args.warmup + 8,
-                  max_prefill_rows=B * (args.ctx_text + args.ctx_frames + 1 + args.gen_text))
+                  max_prefill_rows=B * (args.ctx_text + args.ctx_frames + 1 + args.gen_text), weights_dtype=args.weights)
     del sd
     log("weights on device; creating caches")
     model.setup_caches(B)
@@ -217,12 +219,13 @@ def main():
     # with a separate `rocprofv3 --pmc FETCH_SIZE` pass of this same command and committed under profiles/
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-    if os.path.exists(pmc) and B == 1 and not args.tiny:
+    if os.path.exists(pmc) and B == 1 and not args.tiny and args.weights == "bf16":
         traffic = json.load(open(pmc)).get("traffic_bytes_per_frame")
     out = {
         "metric": "audio frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if args.weights == "bf16" else "bf16 activations, fp8-e4m3 weights (decode step)",
         "data": "synthetic (seeded random weights of CSM-1B shapes, seeded random prompts)",
         "config": {"workload": ("tiny plumbing check" if args.tiny else
                                 f"CSM-1B single utterance per GPU (B={B}), one voice-prompt segment, S={S} prompt rows, "

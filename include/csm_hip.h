@@ -70,6 +70,15 @@ typedef struct CsmWeights {
     const void *bb_rope;                /* [max_seq][hd/2][2] bf16 (cos,sin), Llama3ScaledRoPE
                                            cache after model.to(bf16) (generator.py:343)       */
     const void *dec_rope;               /* same for the decoder's head_dim                     */
+    /* ---- optional OCP-e4m3 weight stream for the decode step (BASELINE config 5) -------------
+     * fp8 != 0: bb8/dec8 hold wq..w3 as e4m3 bytes [out][in] and bb8s/dec8s the per-output-row
+     * fp32 scales (powers of two, so e4m3*scale is exactly the bf16 value in bb/dec above, which
+     * the prefill / batched path keeps using).  Heads likewise.                                */
+    int32_t fp8;
+    CsmLayerWeights bb8[CSM_MAX_LAYERS], bb8s[CSM_MAX_LAYERS];
+    CsmLayerWeights dec8[CSM_MAX_LAYERS], dec8s[CSM_MAX_LAYERS];
+    const void *c0_head8, *c0_head8s;   /* [audio_vocab][d_bb] e4m3, [audio_vocab] f32          */
+    const void *audio_head8, *audio_head8s;   /* [n_codebooks-1][audio_vocab][d_dec] e4m3, [..][audio_vocab] f32 */
 } CsmWeights;
 
 typedef struct CsmModel* csm_handle;

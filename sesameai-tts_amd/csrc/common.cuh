@@ -45,6 +45,22 @@ __device__ __forceinline__ float dpp_f(float old, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
                                                                 CTRL, ROW_MASK, 0xF, false));
 }
+// 16 OCP-e4m3 weights (one uint4) x 16 bf16 activations (two uint4): v_cvt_scalef32_pk_bf16_fp8 turns
+// two fp8 bytes into a packed bf16 pair in one instruction (exact: e4m3 has 3 mantissa bits), which
+// then feeds v_dot2c_f32_bf16 like a bf16 weight would.
+__device__ __forceinline__ float dot16_fp8(const uint4& w, const uint4& x0, const uint4& x1, float acc) {
+    const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+    const uint32_t xd[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const bf16x2_t lo = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(wd[d], 1.0f, false);
+        const bf16x2_t hi = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(wd[d], 1.0f, true);
+        acc = __builtin_amdgcn_fdot2_f32_bf16(lo, __builtin_bit_cast(bf16x2_t, xd[2 * d]), acc, false);
+        acc = __builtin_amdgcn_fdot2_f32_bf16(hi, __builtin_bit_cast(bf16x2_t, xd[2 * d + 1]), acc, false);
+    }
+    return acc;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f<0xB1, 0xF>(0.f, v);       // quad_perm [1,0,3,2]
     v += dpp_f<0x4E, 0xF>(0.f, v);       // quad_perm [2,3,0,1]

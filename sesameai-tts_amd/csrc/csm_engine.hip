@@ -34,6 +34,7 @@ struct Stack {
     bf16_t *kc, *vc;            // [L][B][KV][cache_len][hd]
     long layer_stride;          // elements per layer
     int nt_attn, nt_mlp;        // cache policy of the q/k/v/o and of the gate/up/down weight streams
+    const CsmLayerWeights *w8, *w8s;      // fp8 weight stream + scales (nullptr = bf16)
     CsmLayerWeights pk[CSM_MAX_LAYERS];   // matrix-core operand-order copies of wq..w3 (k_pack_w) for the wide-M path
 };
 
@@ -90,16 +91,16 @@ static int fail(CsmModel* h, int code, const char* msg) {
 // ---------------------------------------------------------------------------------------
 // GEMV dispatch: (KITERS, MT) are runtime -> template switch
 // ---------------------------------------------------------------------------------------
-template <int KITERS, int R, int PRO, int EPI, int HD>
+template <int KITERS, int R, int PRO, int EPI, int HD, int WT = 0>
 static hipError_t launch_gemv_mt(const GemvArgs& a, int units, hipStream_t st) {
     const int blocks = (units + 3) / 4;
     int mt = a.M >= 3 ? 4 : (a.M == 2 ? 2 : 1);
     if (KITERS >= 16 && mt > 2) mt = 2;                     // keep the x tile <= 32 KB of LDS
     const size_t smem = (size_t)mt * KITERS * 512 * 2 + 64 + (PRO == PRO_ATTN ? 4 * 64 * 4 : 0);
     switch (mt) {
-        case 1: hipLaunchKernelGGL((k_gemv<1, KITERS, R, PRO, EPI, HD>), dim3(blocks), dim3(256), smem, st, a); break;
-        case 2: hipLaunchKernelGGL((k_gemv<2, KITERS, R, PRO, EPI, HD>), dim3(blocks), dim3(256), smem, st, a); break;
-        default: hipLaunchKernelGGL((k_gemv<4, KITERS, R, PRO, EPI, HD>), dim3(blocks), dim3(256), smem, st, a); break;
+        case 1: hipLaunchKernelGGL((k_gemv<1, KITERS, R, PRO, EPI, HD, WT>), dim3(blocks), dim3(256), smem, st, a); break;
+        case 2: hipLaunchKernelGGL((k_gemv<2, KITERS, R, PRO, EPI, HD, WT>), dim3(blocks), dim3(256), smem, st, a); break;
+        default: hipLaunchKernelGGL((k_gemv<4, KITERS, R, PRO, EPI, HD, WT>), dim3(blocks), dim3(256), smem, st, a); break;
     }
     return hipGetLastError();
 }
@@ -130,6 +131,31 @@ static hipError_t launch_gemv(int kind, int K, int hd, const GemvArgs& a, hipStr
         GEMV_CASE(16, 1, 2)
     }
 #undef GEMV_CASE
+    return hipErrorInvalidValue;
+}
+
+// OCP-e4m3 weight stream (a.s0/s1/s2 = per-row scales); same kinds as launch_gemv
+static hipError_t launch_gemv8(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
+    if (K % 512 != 0) return hipErrorInvalidValue;
+#define GEMV8_CASE(KI, RS)                                                                                          \
+    case KI:                                                                                                        \
+        switch (kind) {                                                                                             \
+            case 1: return launch_gemv_mt<KI, RS, PRO_PLAIN, EPI_RESID, 64, 1>(a, (a.N + RS - 1) / RS, st);         \
+            case 2: return launch_gemv_mt<KI, RS, PRO_NORM, EPI_STORE, 64, 1>(a, (a.N + RS - 1) / RS, st);          \
+            case 3: return hd == 64 ? launch_gemv_mt<KI, 2, PRO_NORM, EPI_QKV_ROPE, 64, 1>(a, (a.N + 1) / 2, st)    \
+                                    : launch_gemv_mt<KI, 2, PRO_NORM, EPI_QKV_ROPE, 128, 1>(a, (a.N + 1) / 2, st);  \
+            case 4: return launch_gemv_mt<KI, 2, PRO_NORM, EPI_SWIGLU, 64, 1>(a, a.N, st);                          \
+            case 5: return launch_gemv_mt<KI, RS, PRO_ATTN, EPI_RESID, 64, 1>(a, (a.N + RS - 1) / RS, st);          \
+            case 6: return launch_gemv_mt<KI, RS, PRO_COMBINE, EPI_RESID, 64, 1>(a, (a.N + RS - 1) / RS, st);       \
+        }                                                                                                           \
+        return hipErrorInvalidValue;
+    switch (K / 512) {
+        GEMV8_CASE(1, 2)
+        GEMV8_CASE(2, 2)
+        GEMV8_CASE(4, 2)
+        GEMV8_CASE(16, 1)
+    }
+#undef GEMV8_CASE
     return hipErrorInvalidValue;
 }
 
@@ -270,7 +296,12 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
         a.N = S.nq + 2 * S.nkv; a.out = q; a.ldo = S.nq;
         a.nq = S.nq; a.nkv = S.nkv; a.smax = S.cache_len; a.rows_per_seq = rows_per_seq; a.kv_heads = S.d.n_kv_heads;
         a.pos = pos; a.pos_base = pos_base; a.rope = S.rope; a.kcache = kc; a.vcache = vc;
-        if ((e = launch_gemv(3, d, S.hd, a, st)) != hipSuccess) return e;
+        const bool f8 = S.w8 != nullptr;
+        if (f8) {
+            a.w0 = (const bf16_t*)S.w8[l].wq; a.w1 = (const bf16_t*)S.w8[l].wk; a.w2 = (const bf16_t*)S.w8[l].wv;
+            a.s0 = (const float*)S.w8s[l].wq; a.s1 = (const float*)S.w8s[l].wk; a.s2 = (const float*)S.w8s[l].wv;
+        }
+        if ((e = f8 ? launch_gemv8(3, d, S.hd, a, st) : launch_gemv(3, d, S.hd, a, st)) != hipSuccess) return e;
         bool fuse_comb = false;
         const bool fuse_attn = S.hd == 128 && S.cache_len <= 32 && m->fuse_dec_attn && (S.d.n_heads / S.d.n_kv_heads) % 2 == 0;
         if (!fuse_attn) {
@@ -292,19 +323,25 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
             a.pos = pos; a.pos_base = pos_base; a.smax = S.cache_len; a.rows_per_seq = rows_per_seq; a.kv_heads = S.d.n_kv_heads;
         }
         if (fuse_comb) { a.part = m->part; a.nsplit = nsplit; a.aH = S.d.n_heads; }
-        if ((e = launch_gemv(fuse_attn ? 5 : (fuse_comb ? 6 : 1), S.nq, S.hd, a, st)) != hipSuccess) return e;
+        if (f8) { a.w0 = (const bf16_t*)S.w8[l].wo; a.s0 = (const float*)S.w8s[l].wo; }
+        {
+            const int kind = fuse_attn ? 5 : (fuse_comb ? 6 : 1);
+            if ((e = f8 ? launch_gemv8(kind, S.nq, S.hd, a, st) : launch_gemv(kind, S.nq, S.hd, a, st)) != hipSuccess) return e;
+        }
         // (4) RMSNorm -> gate/up -> SiLU*up
         memset(&a, 0, sizeof a);
         a.nt = S.nt_mlp;
         a.x = h; a.x_row_stride = d; a.M = M; a.norm_scale = (const bf16_t*)w.mlp_norm; a.eps = S.d.norm_eps;
         a.w0 = (const bf16_t*)w.w1; a.w1 = (const bf16_t*)w.w3; a.N = S.d.ffn; a.out = act; a.ldo = S.d.ffn;
-        if ((e = launch_gemv(4, d, S.hd, a, st)) != hipSuccess) return e;
+        if (f8) { a.w0 = (const bf16_t*)S.w8[l].w1; a.w1 = (const bf16_t*)S.w8[l].w3; a.s0 = (const float*)S.w8s[l].w1; a.s1 = (const float*)S.w8s[l].w3; }
+        if ((e = f8 ? launch_gemv8(4, d, S.hd, a, st) : launch_gemv(4, d, S.hd, a, st)) != hipSuccess) return e;
         // (5) down projection + residual
         memset(&a, 0, sizeof a);
         a.nt = S.nt_mlp;
         a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)w.w2; a.N = d;
         a.out = h; a.ldo = d; a.resid = h;
-        if ((e = launch_gemv(1, S.d.ffn, S.hd, a, st)) != hipSuccess) return e;
+        if (f8) { a.w0 = (const bf16_t*)S.w8[l].w2; a.s0 = (const float*)S.w8s[l].w2; }
+        if ((e = f8 ? launch_gemv8(1, S.d.ffn, S.hd, a, st) : launch_gemv(1, S.d.ffn, S.hd, a, st)) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -363,6 +400,10 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             a.x = xn; a.x_row_stride = xs; a.x_row_offset = 0;
             a.w0 = cb == 0 ? m->pk_c0_head : m->pk_audio_head + (long)(cb - 1) * m->pk_head_stride;
             if ((e = launch_mm(0, Kh, 0, a, st)) != hipSuccess) return e;
+        } else if (m->w.fp8) {
+            if (cb == 0) { a.w0 = (const bf16_t*)m->w.c0_head8; a.s0 = (const float*)m->w.c0_head8s; }
+            else { a.w0 = (const bf16_t*)((const char*)m->w.audio_head8 + (long)(cb - 1) * V * dd); a.s0 = (const float*)m->w.audio_head8s + (long)(cb - 1) * V; }
+            if ((e = launch_gemv8(2, cb == 0 ? dbb : dd, 0, a, st)) != hipSuccess) return e;
         } else if ((e = launch_gemv(2, cb == 0 ? dbb : dd, 0, a, st)) != hipSuccess) return e;
         if (logits_out) {
             e = hipMemcpy2DAsync((char*)logits_out + (size_t)cb * B * V * 2, (size_t)V * 2, m->logits, (size_t)m->ldl * 2,
@@ -437,6 +478,7 @@ static hipError_t pack_stack(CsmModel* m, Stack& S) {
 static void init_stack(Stack& S, const CsmLlamaDims& d, const CsmLayerWeights* lw, const void* norm, const void* rope,
                        int cache_len, int nt_attn, int nt_mlp) {
     S.d = d; S.lw = lw; S.final_norm = (const bf16_t*)norm; S.rope = (const bf16_t*)rope;
+    S.w8 = nullptr; S.w8s = nullptr;
     S.hd = d.dim / d.n_heads; S.nq = d.n_heads * S.hd; S.nkv = d.n_kv_heads * S.hd; S.cache_len = cache_len; S.nt_attn = nt_attn; S.nt_mlp = nt_mlp;
 }
 
@@ -516,6 +558,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     HIPCHK((CsmModel*)nullptr, hipMemset(m->n_frames, 0, 16));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->cur_pos, 0, (size_t)max_batch * 4));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->eos_at, 0xff, (size_t)max_batch * 4));
+    if (w->fp8) { m->bb.w8 = m->w.bb8; m->bb.w8s = m->w.bb8s; m->dec.w8 = m->w.dec8; m->dec.w8s = m->w.dec8s; }
     if (m->wide_path) {
         HIPCHK((CsmModel*)nullptr, pack_stack(m, m->bb));
         HIPCHK((CsmModel*)nullptr, pack_stack(m, m->dec));
@@ -682,10 +725,11 @@ extern "C" double csm_bytes_per_frame(csm_handle m, int B, double p_mean) {
         const double hd = d.dim / d.n_heads;
         return 2.0 * (d.dim * (d.n_heads * hd) * 2 + 2.0 * d.dim * (d.n_kv_heads * hd) + 3.0 * d.dim * d.ffn);
     };
-    double w = c.backbone.n_layers * layer(c.backbone) + c.decoder.n_layers * layer(c.decoder);
-    w += 2.0 * c.audio_vocab * c.backbone.dim;                                   // c0 head
-    w += 2.0 * c.decoder.dim * c.backbone.dim;                                   // projection
-    w += 2.0 * (c.n_codebooks - 1) * (double)c.audio_vocab * c.decoder.dim;      // audio heads
+    const double wb = m->w.fp8 ? 0.5 : 1.0;                                      // e4m3 weight stream: 1 byte per weight
+    double w = wb * (c.backbone.n_layers * layer(c.backbone) + c.decoder.n_layers * layer(c.decoder));
+    w += wb * 2.0 * c.audio_vocab * c.backbone.dim;                              // c0 head
+    w += 2.0 * c.decoder.dim * c.backbone.dim;                                   // projection (one bf16 GEMV per frame)
+    w += wb * 2.0 * (c.n_codebooks - 1) * (double)c.audio_vocab * c.decoder.dim; // audio heads
     const double kv = 2.0 * c.backbone.n_layers * 2.0 * c.backbone.n_kv_heads * (c.backbone.dim / c.backbone.n_heads) * (p_mean + 1);
     return w + B * kv;
 }

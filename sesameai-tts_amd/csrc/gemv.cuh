@@ -55,6 +55,8 @@ struct GemvArgs {
     int nsplit;
     // EPI_SLAB (wide-M split-K): fp32 partial sums, slab g of [gridDim.z][M][N]
     float* slab;
+    // WT == 1: w0/w1/w2 point to OCP-e4m3 bytes [N][K]; per-output-row power-of-two scales
+    const float *s0, *s1, *s2;
 };
 
 // Depth-decoder attention fused into the output projection's prologue (hd = 128, at most 32
@@ -278,7 +280,7 @@ __device__ __forceinline__ void stage_x(bf16_t* xs, float* red, const GemvArgs& 
 
 // R = weight rows per wave.  EPI_QKV_ROPE: R == 2 (one interleaved RoPE pair).
 // EPI_SWIGLU: R == 2*P, rows [0,P) are gate rows i..i+P-1 and [P,2P) the matching up rows.
-template <int MT, int KITERS, int R, int PRO, int EPI, int HD>
+template <int MT, int KITERS, int R, int PRO, int EPI, int HD, int WT = 0>
 __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     constexpr int K = KITERS * 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -289,16 +291,20 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     const int unit = blockIdx.x * 4 + wave;              // one unit = R weight rows
 
     // ---- resolve this wave's R weight rows (nullptr = past the end) ------------------------
-    const bf16_t* wrow[R];
+    constexpr int WS = WT == 1 ? 1 : 2;                   // bytes per weight
+    const char* wrow[R];
+    float wsc[R];                                         // WT == 1: the row's scale
     int orow[R];                                          // output row index
+#pragma unroll
+    for (int r = 0; r < R; ++r) wsc[r] = 1.0f;
     if (EPI == EPI_QKV_ROPE) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             int row = unit * R + r;
             orow[r] = row;
-            if (row < a.nq) wrow[r] = a.w0 + (long)row * K;
-            else if (row < a.nq + a.nkv) wrow[r] = a.w1 + (long)(row - a.nq) * K;
-            else if (row < a.N) wrow[r] = a.w2 + (long)(row - a.nq - a.nkv) * K;
+            if (row < a.nq) { wrow[r] = (const char*)a.w0 + (long)row * K * WS; if (WT) wsc[r] = a.s0[row]; }
+            else if (row < a.nq + a.nkv) { wrow[r] = (const char*)a.w1 + (long)(row - a.nq) * K * WS; if (WT) wsc[r] = a.s1[row - a.nq]; }
+            else if (row < a.N) { wrow[r] = (const char*)a.w2 + (long)(row - a.nq - a.nkv) * K * WS; if (WT) wsc[r] = a.s2[row - a.nq - a.nkv]; }
             else wrow[r] = nullptr;
         }
     } else if (EPI == EPI_SWIGLU) {
@@ -307,34 +313,47 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
         for (int r = 0; r < P; ++r) {
             int row = unit * P + r;
             orow[r] = orow[r + P] = row;
-            wrow[r] = row < a.N ? a.w0 + (long)row * K : nullptr;
-            wrow[r + P] = row < a.N ? a.w1 + (long)row * K : nullptr;
+            wrow[r] = row < a.N ? (const char*)a.w0 + (long)row * K * WS : nullptr;
+            wrow[r + P] = row < a.N ? (const char*)a.w1 + (long)row * K * WS : nullptr;
+            if (WT && row < a.N) { wsc[r] = a.s0[row]; wsc[r + P] = a.s1[row]; }
         }
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             int row = unit * R + r;
             orow[r] = row;
-            wrow[r] = row < a.N ? a.w0 + (long)row * K : nullptr;
+            wrow[r] = row < a.N ? (const char*)a.w0 + (long)row * K * WS : nullptr;
+            if (WT && row < a.N) wsc[r] = a.s0[row];
         }
     }
 
     // ---- issue every weight load of this wave up front; they stay in VGPRs ----------------
-    uint4 wv[R][KITERS];
-    if (a.nt) {
+    // WT == 1: a lane's 16 bytes hold 16 weights, so one wave load covers 1024 k (half of them masked at K = 512)
+    constexpr int WI = WT == 1 ? (KITERS + 1) / 2 : KITERS;
+    uint4 wv[R][WI];
+    if constexpr (WT == 1) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int i = 0; i < KITERS; ++i)
-                wv[r][i] = wrow[r] ? ldg16<true>(reinterpret_cast<const uint4*>(wrow[r]) + i * 64 + lane)
-                                   : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < WI; ++i)
+                wv[r][i] = (wrow[r] && (i * 64 + lane) * 16 < K) ? ldg16<true>(reinterpret_cast<const uint4*>(wrow[r]) + i * 64 + lane)
+                                                                  : make_uint4(0, 0, 0, 0);
     } else {
+        if (a.nt) {
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int i = 0; i < KITERS; ++i)
-                wv[r][i] = wrow[r] ? ldg16<false>(reinterpret_cast<const uint4*>(wrow[r]) + i * 64 + lane)
-                                   : make_uint4(0, 0, 0, 0);
+                for (int i = 0; i < WI; ++i)
+                    wv[r][i] = wrow[r] ? ldg16<true>(reinterpret_cast<const uint4*>(wrow[r]) + i * 64 + lane)
+                                       : make_uint4(0, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int i = 0; i < WI; ++i)
+                    wv[r][i] = wrow[r] ? ldg16<false>(reinterpret_cast<const uint4*>(wrow[r]) + i * 64 + lane)
+                                       : make_uint4(0, 0, 0, 0);
+        }
     }
 
     // ---- prefetch the epilogue's operands for the first M tile (lane m finishes row m): the
@@ -368,19 +387,34 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[m][r] = 0.f;
+        if constexpr (WT == 1) {
 #pragma unroll
-        for (int i = 0; i < KITERS; ++i) {
+            for (int i = 0; i < WI; ++i) {
+                const int c2 = (i * 64 + lane) * 2;          // first of the lane's two 8-element x chunks
+                const bool in = c2 * 8 < K;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const uint4 xv = reinterpret_cast<const uint4*>(xs + m * K)[i * 64 + lane];
+                for (int m = 0; m < MT; ++m) {
+                    const uint4 x0 = in ? reinterpret_cast<const uint4*>(xs + m * K)[c2] : make_uint4(0, 0, 0, 0);
+                    const uint4 x1 = in ? reinterpret_cast<const uint4*>(xs + m * K)[c2 + 1] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[m][r] = dot8(wv[r][i], xv, acc[m][r]);
+                    for (int r = 0; r < R; ++r) acc[m][r] = dot16_fp8(wv[r][i], x0, x1, acc[m][r]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KITERS; ++i) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const uint4 xv = reinterpret_cast<const uint4*>(xs + m * K)[i * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[m][r] = dot8(wv[r][i], xv, acc[m][r]);
+                }
             }
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[m][r] = wave_sum(acc[m][r]);
+            for (int r = 0; r < R; ++r) acc[m][r] = wave_sum(acc[m][r]) * wsc[r];     // power-of-two scale: exact
 
         // ---- epilogue: lane m finishes token row m0+m -------------------------------------
         {

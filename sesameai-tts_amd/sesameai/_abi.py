@@ -42,7 +42,12 @@ class CsmWeights(C.Structure):
                 ("bb", CsmLayerWeights * CSM_MAX_LAYERS), ("bb_norm", C.c_void_p),
                 ("dec", CsmLayerWeights * CSM_MAX_LAYERS), ("dec_norm", C.c_void_p),
                 ("projection", C.c_void_p), ("c0_head", C.c_void_p), ("audio_head_t", C.c_void_p),
-                ("bb_rope", C.c_void_p), ("dec_rope", C.c_void_p)]
+                ("bb_rope", C.c_void_p), ("dec_rope", C.c_void_p),
+                ("fp8", C.c_int32),
+                ("bb8", CsmLayerWeights * CSM_MAX_LAYERS), ("bb8s", CsmLayerWeights * CSM_MAX_LAYERS),
+                ("dec8", CsmLayerWeights * CSM_MAX_LAYERS), ("dec8s", CsmLayerWeights * CSM_MAX_LAYERS),
+                ("c0_head8", C.c_void_p), ("c0_head8s", C.c_void_p),
+                ("audio_head8", C.c_void_p), ("audio_head8s", C.c_void_p)]
 
 
 _vp, _i, _f, _l, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_uint64

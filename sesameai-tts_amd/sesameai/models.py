@@ -133,6 +133,40 @@ def synthetic_state_dict(args: ModelArgs, seed: int = 1234, std: float = 0.02) -
     return sd
 
 
+MATRIX_SUFFIXES = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "output_proj.weight", "w1.weight", "w2.weight", "w3.weight")
+
+
+def quantize_fp8_rows(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """[N][K] -> (e4m3 bytes [N][K] uint8, scale [N] fp32, dequantised bf16 [N][K]).  OCP e4m3fn with one
+    POWER-OF-TWO scale per output row, 2^ceil(log2(max|row| / 448)): e4m3 has 3 mantissa bits, so
+    byte * scale is exactly representable in bf16 and the fp8 decode stream computes the same dot
+    products as a bf16 model holding the dequantised weights."""
+    wf = w.float()
+    mx = wf.abs().amax(dim=1).clamp(min=1e-30)
+    scale = torch.exp2(torch.ceil(torch.log2(mx / 448.0)))
+    q = (wf / scale[:, None]).to(torch.float8_e4m3fn)
+    deq = (q.float() * scale[:, None]).to(torch.bfloat16)
+    return q.view(torch.uint8), scale.float(), deq
+
+
+def fp8_weight_set(args: ModelArgs, sd: Dict[str, torch.Tensor]):
+    """Quantises every projection matrix of both stacks + the heads.  Returns (state dict with the
+    matrices replaced by their dequantised bf16 values, {name: (bytes, scales)})."""
+    out, q8 = dict(sd), {}
+    for name in list(sd):
+        if name.endswith(MATRIX_SUFFIXES) and (name.startswith("backbone.layers") or name.startswith("decoder.layers")):
+            q, s, deq = quantize_fp8_rows(sd[name])
+            out[name] = deq; q8[name] = (q, s)
+    q, s, deq = quantize_fp8_rows(sd["codebook0_head.weight"])
+    out["codebook0_head.weight"] = deq; q8["codebook0_head.weight"] = (q, s)
+    ah = sd["audio_head"]                                       # [31][d][V]: quantise per logit row = per (i, v)
+    aht = ah.transpose(1, 2).contiguous()                       # [31][V][d]
+    q, s, deq = quantize_fp8_rows(aht.reshape(-1, aht.shape[-1]))
+    out["audio_head"] = deq.view_as(aht).transpose(1, 2).contiguous()
+    q8["audio_head_t"] = (q.view(aht.shape), s.view(aht.shape[0], aht.shape[1]))
+    return out, q8
+
+
 def from_hf_state_dict(args: ModelArgs, hf: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Converts a ``transformers`` ``CsmForConditionalGeneration`` checkpoint (the HF-format
     ``sesame/csm-1b`` repo) to the reference's torchtune layout.  The HF port uses half-split RoPE,
@@ -177,7 +211,8 @@ class Model:
     """Drop-in for the reference ``Model`` (sesameai/models.py:99-203)."""
 
     def __init__(self, config: ModelArgs, state_dict: Optional[Dict[str, torch.Tensor]] = None,
-                 device: str = "cuda", max_frames: int = 2048, max_prefill_rows: int = 2048):
+                 device: str = "cuda", max_frames: int = 2048, max_prefill_rows: int = 2048,
+                 weights_dtype: str = "bf16"):
         if not torch.cuda.is_available():
             raise RuntimeError("sesameai (MI355X build) needs a ROCm GPU: there is no CPU fallback")
         self.config = config
@@ -185,6 +220,15 @@ class Model:
         self.bb, self.dec = FLAVORS[config.backbone_flavor], FLAVORS[config.decoder_flavor]
         if state_dict is None:
             state_dict = synthetic_state_dict(config)
+        if weights_dtype not in ("bf16", "fp8"):
+            raise ValueError("weights_dtype must be 'bf16' or 'fp8'")
+        self.weights_dtype = weights_dtype
+        self._q8: Dict[str, torch.Tensor] = {}
+        if weights_dtype == "fp8":     # decode step streams e4m3 bytes; prefill / batch keep the (dequantised) bf16
+            state_dict, q8 = fp8_weight_set(config, state_dict)
+            for name, (q, sc) in q8.items():
+                self._q8[name] = q.to(self.device).contiguous()
+                self._q8[name + ".scale"] = sc.to(self.device).contiguous()
         layout = dict(state_dict_layout(config))
         missing = [k for k in layout if k not in state_dict]
         if missing:
@@ -253,6 +297,18 @@ class Model:
         w.bb_norm, w.dec_norm = p("backbone.norm.scale"), p("decoder.norm.scale")
         w.projection, w.c0_head = p("projection.weight"), p("codebook0_head.weight")
         w.audio_head_t, w.bb_rope, w.dec_rope = p("audio_head_t"), p("bb_rope"), p("dec_rope")
+        w.fp8 = int(self.weights_dtype == "fp8")
+        if w.fp8:
+            q = lambda n: self._q8[n].data_ptr()
+            for pfx, arr, arrs, f in (("backbone", w.bb8, w.bb8s, self.bb), ("decoder", w.dec8, w.dec8s, self.dec)):
+                for i in range(f.num_layers):
+                    L = f"{pfx}.layers.{i}"
+                    names = [f"{L}.attn.q_proj.weight", f"{L}.attn.k_proj.weight", f"{L}.attn.v_proj.weight",
+                             f"{L}.attn.output_proj.weight", f"{L}.mlp.w1.weight", f"{L}.mlp.w2.weight", f"{L}.mlp.w3.weight"]
+                    arr[i] = _abi.CsmLayerWeights(*[q(n) for n in names], None, None)
+                    arrs[i] = _abi.CsmLayerWeights(*[q(n + ".scale") for n in names], None, None)
+            w.c0_head8, w.c0_head8s = q("codebook0_head.weight"), q("codebook0_head.weight.scale")
+            w.audio_head8, w.audio_head8s = q("audio_head_t"), q("audio_head_t.scale")
         return w
 
     def setup_caches(self, max_batch_size: int) -> None:

@@ -218,6 +218,46 @@ def test_prompt_too_long_raises(tiny):
         gen.generate_codes(tok, msk, int(30_000 / 80), 0.9, 50)      # 1700 >= 2048 - 375
 
 
+def test_fp8_weight_stream_matches_oracle_on_dequantised_weights():
+    """BASELINE config 5: the decode step streams OCP-e4m3 weights with power-of-two row scales.
+    byte*scale is exactly the bf16 value the oracle holds, so the fp8 path must agree with the
+    oracle on those dequantised weights to the same tolerance as the bf16 path does."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import csm_ref as C
+    from sesameai.models import Model, csm_tiny_args, fp8_weight_set, synthetic_state_dict
+    shape = C.csm_tiny()
+    w = C.fp8_dequantized(C.make_weights(shape, seed=1234))
+    sd = synthetic_state_dict(csm_tiny_args(), seed=1234)
+    deq, _ = fp8_weight_set(csm_tiny_args(), sd)
+    assert all(torch.equal(w[k], deq[k]) for k in w), "product and oracle fp8 dequantisation differ"
+    gold = torch.load(os.path.join(GOLD, "tiny_frames.pt"))
+    tok, msk = gold["prompt_tokens"], gold["prompt_mask"]
+    S = tok.shape[0]
+    m = Model(csm_tiny_args(), sd, max_frames=16, max_prefill_rows=64, weights_dtype="fp8")
+    m.setup_caches(1)
+    om = C.OracleModel(shape, w); om.setup_caches(1)
+    m.prefill(tok.unsqueeze(0), msk.unsqueeze(0), torch.arange(S).unsqueeze(0))
+    cur_t, cur_m, pos = tok.unsqueeze(0), msk.unsqueeze(0), torch.arange(S).unsqueeze(0)
+    noise = float(gold["bf16_vs_fp32_gap"].max())
+    worst = 0.0
+    for f in range(4):
+        tr = C.FrameTrace()
+        ref = om.generate_frame(cur_t, cur_m, pos, 1.0, 1, greedy=True, trace=tr)
+        want = torch.stack(tr.logits, 0)[:, 0].float()
+        out, logits = m.depth(1, 1.0, 1, forced=ref, want_logits=True, commit=False)
+        worst = max(worst, (logits[:, 0].float().cpu() - want).abs().max().item())
+        margin = torch.topk(want, 2, dim=-1)[0]
+        for cb in (out[0].cpu() != ref[0]).nonzero().flatten().tolist():
+            assert float(margin[cb, 0] - margin[cb, 1]) <= 2 * noise
+        cur_t = torch.cat([ref.long(), torch.zeros(1, 1).long()], dim=1).unsqueeze(1)
+        cur_m = torch.cat([torch.ones_like(ref).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
+        pos = pos[:, -1:] + 1
+        m.prefill(cur_t, cur_m, pos)                                 # S == 1: the narrow fp8 GEMV path
+    print(f"fp8 weight stream vs oracle(dequantised): max|dlogit|={worst:.4f} (noise floor {noise:.4f})")
+    assert worst <= 2 * noise + 1e-3
+
+
 def test_long_context_streaming_config5_shape():
     """BASELINE config 5 shape at CSM-1B size (bf16 here): 10 prompt segments -> S = 1334 rows,
     375 frames (30 s), Mimi decoded statefully every 10 frames.  Checks the position guard
