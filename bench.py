@@ -55,6 +55,50 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def dominant_kernels(model, dev, reps=400):
+    """The two kernels that take the most time in the frame (profiles/r01/final_kernel_stats.csv): the depth
+    decoder's fused RMSNorm+gate/up+SiLU GEMV and its down-projection GEMV.  Each is launched `reps` times
+    back to back on the current stream over the four decoder layers' real weights (cycling, like the frame
+    does) between HIP events; achieved = weight bytes of one launch / average duration."""
+    from sesameai import _abi
+    dec = model.dec
+    d, ffn = dec.embed_dim, dec.intermediate_dim
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, d, generator=g).to(torch.bfloat16).to(dev)
+    act = torch.randn(1, ffn, generator=g).to(torch.bfloat16).to(dev)
+    out_a = torch.zeros(1, ffn, dtype=torch.bfloat16, device=dev)
+    out_h = torch.zeros(1, d, dtype=torch.bfloat16, device=dev)
+    W = model._w
+    res = []
+    for name, kind, K, N, xin, outp in (("decoder rmsnorm+gate/up+silu GEMV", 4, d, ffn, x, out_a),
+                                        ("decoder down-proj+residual GEMV", 1, ffn, d, act, out_h)):
+        def launch(l):
+            L = f"decoder.layers.{l}"
+            if kind == 4:
+                _abi.lib.csm_op_gemv(4, 1, K, N, xin.data_ptr(), K, 0, W[f"{L}.mlp_norm.scale"].data_ptr(), 1e-5,
+                                     W[f"{L}.mlp.w1.weight"].data_ptr(), W[f"{L}.mlp.w3.weight"].data_ptr(), None, None,
+                                     outp.data_ptr(), N, None, K, 0, 64, 0, 0, 0, 0, 1, None, None, None, None, st)
+            else:
+                _abi.lib.csm_op_gemv(1, 1, K, N, xin.data_ptr(), K, 0, None, 1e-5, W[f"{L}.mlp.w2.weight"].data_ptr(), None, None,
+                                     outp.data_ptr(), outp.data_ptr(), N, None, K, 0, 64, 0, 0, 0, 0, 1, None, None, None, None, st)
+        for i in range(20):
+            launch(i % dec.num_layers)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(reps):
+            launch(i % dec.num_layers)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        nbytes = (2 if kind == 4 else 1) * K * N * 2
+        res.append({"kernel": name, "bytes_per_launch": nbytes, "avg_us": round(us, 2),
+                    "achieved_GBps": round(nbytes / us / 1e3, 1), "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 3),
+                    "note": "eager back-to-back launches (includes the ~1.6 us launch floor per kernel)"})
+    return res
+
+
 def cpu_worker(args):
     """Child process: the oracle (CPU restatement of the reference's eager `-d cpu` bf16 graph)
     on the same S=190 prompt; prints one JSON line per completed frame until the budget is spent."""
@@ -221,6 +265,7 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
     if os.path.exists(pmc) and B == 1 and not args.tiny and args.weights == "bf16":
         traffic = json.load(open(pmc)).get("traffic_bytes_per_frame")
+    kernels = None if (args.tiny or args.weights != "bf16") else dominant_kernels(model, dev)
     out = {
         "metric": "audio frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -238,7 +283,8 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "frame step (1 backbone + 31 depth-decoder steps, unique weights + KV)",
                      "bytes_per_launch": bytes_frame, "launch_ms": round(t_frame * 1e3, 4),
-                     "streamed_GBps": round((bytes_frame + 30 * 2 * 111.15e6 + 30 * 2 * 2.1e6) / t_frame / 1e9, 1)},
+                     "streamed_GBps": round((bytes_frame + 30 * 2 * 111.15e6 + 30 * 2 * 2.1e6) / t_frame / 1e9, 1),
+                     "dominant_kernels": kernels},
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and not args.tiny:
