@@ -58,13 +58,11 @@ struct CsmModel {
     int *frame, *cur_tokens, *cur_pos, *history, *n_frames, *eos_at, *dec_pos;
     uint8_t* cur_mask;
     uint64_t* rng;
-    int *pf_tokens, *pf_pos;            // staging for csm_prefill inputs is the caller's memory
     int host_frames;                    // frames launched since reset (host mirror)
     int wide_path;                      // MFMA path for M >= WIDE_MIN_ROWS (env CSM_WIDE=0 disables)
     int fuse_dec_attn;                  // depth-decoder attention fused into the O-projection (env CSM_FUSE_DEC_ATTN=0 disables)
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
     int last_S;                         // rows per sequence of the h buffer feeding csm_depth
-    int host_pos_max;                   // host mirror of max position (overflow guard)
     // graph
     hipGraphExec_t gexec; hipGraph_t graph;
     int g_B, g_topk; float g_temp; hipStream_t cap_stream;   // capture happens on an internal stream:
@@ -502,7 +500,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     m->max_rows = max_rows;
     m->ldl = ((cfg->audio_vocab + 511) / 512) * 512;
     m->gexec = nullptr; m->graph = nullptr; m->g_B = -1; m->cap_stream = nullptr;
-    m->host_frames = 0; m->have_last = false; m->last_S = 1; m->host_pos_max = 0;
+    m->host_frames = 0; m->have_last = false; m->last_S = 1;
     { const char* ev = getenv("CSM_FUSE_DEC_ATTN"); m->fuse_dec_attn = !(ev && ev[0] == '0'); }
     { const char* ev = getenv("CSM_WIDE"); m->wide_path = !(ev && ev[0] == '0'); }
     // Cache policy (measured, tools/microbench/gemv_bench.hip): a depth-decoder step touches
@@ -518,7 +516,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
         init_stack(m->dec, cfg->decoder, m->w.dec, w->dec_norm, w->dec_rope, cfg->n_codebooks, 0, dec_mlp_nt);
     }
     const int ncb = cfg->n_codebooks, dbb = cfg->backbone.dim, dd = cfg->decoder.dim;
-#define ALLOC(ptr, bytes) HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&(ptr), (bytes)))
+#define ALLOC(ptr, bytes) HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&(ptr), (bytes)))   /* on failure the handle is leaked on purpose: the process cannot continue without it */
     m->bb.layer_stride = (long)max_batch * cfg->backbone.n_kv_heads * m->bb.cache_len * m->bb.hd;
     m->dec.layer_stride = (long)max_batch * cfg->decoder.n_kv_heads * m->dec.cache_len * m->dec.hd;
     ALLOC(m->bb.kc, (size_t)m->bb.layer_stride * cfg->backbone.n_layers * 2);
@@ -609,7 +607,7 @@ extern "C" int csm_reset(csm_handle m, void* stream) {
     HIPCHK(m, hipMemsetAsync(m->n_frames, 0, 4, st));
     HIPCHK(m, hipMemsetAsync(m->cur_pos, 0, (size_t)m->max_batch * 4, st));
     HIPCHK(m, hipMemsetAsync(m->eos_at, 0xff, (size_t)m->max_batch * 4, st));
-    m->host_frames = 0; m->have_last = false; m->host_pos_max = 0;
+    m->host_frames = 0; m->have_last = false;
     return CSM_OK;
 }
 
