@@ -161,12 +161,9 @@ static hipError_t launch_gemv8(int kind, int K, int hd, const GemvArgs& a, hipSt
 static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
     if (K % 256 != 0) return hipErrorInvalidValue;
     dim3 grid((a.N + 31) / 32, (a.M + 31) / 32);
-    const bool deep = K >= 4096 && K % 1024 == 0;         // 16-way K split for the down projections
     switch (kind) {
         case 0: hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4>), grid, dim3(256), 0, st, a, K); break;
-        case 1: if (deep) hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 16>), grid, dim3(1024), 0, st, a, K);
-                else hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4>), grid, dim3(256), 0, st, a, K);
-                break;
+        case 1: hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4>), grid, dim3(256), 0, st, a, K); break;
         case 3: if (hd == 64) hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 64, 4>), grid, dim3(256), 0, st, a, K);
                 else hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 128, 4>), grid, dim3(256), 0, st, a, K);
                 break;

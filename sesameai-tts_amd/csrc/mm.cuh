@@ -65,11 +65,19 @@ __global__ __launch_bounds__(256) void k_resid_norm(bf16_t* h, const float* slab
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        for (int g = 0; g < KG; ++g) {
-            const float4 p0 = *reinterpret_cast<const float4*>(slab + ((long)g * M + r) * N + col);
-            const float4 p1 = *reinterpret_cast<const float4*>(slab + ((long)g * M + r) * N + col + 4);
-            acc[0] += p0.x; acc[1] += p0.y; acc[2] += p0.z; acc[3] += p0.w;
-            acc[4] += p1.x; acc[5] += p1.y; acc[6] += p1.z; acc[7] += p1.w;
+        float4 p0[8], p1[8];                                  // all slab loads in flight together (KG <= 8)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int gg = g < KG ? g : 0;
+            p0[g] = *reinterpret_cast<const float4*>(slab + ((long)gg * M + r) * N + col);
+            p1[g] = *reinterpret_cast<const float4*>(slab + ((long)gg * M + r) * N + col + 4);
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                         // fixed order: deterministic
+            if (g < KG) {
+                acc[0] += p0[g].x; acc[1] += p0[g].y; acc[2] += p0[g].z; acc[3] += p0[g].w;
+                acc[4] += p1[g].x; acc[5] += p1[g].y; acc[6] += p1[g].z; acc[7] += p1[g].w;
+            }
         }
         const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
 #pragma unroll
@@ -150,6 +158,34 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K)
     f32x16_t acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    if (kspan <= 256) {
+        // short K span (decode-step projections at K = 1024): every load of the wave is issued before the
+        // first MFMA -- one memory round trip instead of one per chunk
+        uint4 av[4][4], bv[4][4], cv[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int kc = kbeg + c * 64;
+            if (c * 64 < kspan) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    av[c][q] = *reinterpret_cast<const uint4*>(xa + kc + h * 32 + q * 8);
+                    bv[c][q] = ldg16<true>(wa + ((kc >> 6) * 4 + q) * 64 + lane);
+                    if (EPI == EPI_SWIGLU) cv[c][q] = ldg16<true>(wb + ((kc >> 6) * 4 + q) * 64 + lane);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c * 64 < kspan) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[c][q]), as_bf16x8(bv[c][q]), acc0, 0, 0, 0);
+                    if (EPI == EPI_SWIGLU)
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[c][q]), as_bf16x8(cv[c][q]), acc1, 0, 0, 0);
+                }
+            }
+        }
+    } else {
     // register double buffer: the loads of chunk c+1 are in flight while chunk c feeds the MFMAs
     uint4 av[2][4], bv[2][4], cv[2][4];
     auto load = [&](int buf, int kc) {
@@ -178,6 +214,7 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K)
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[1][q]), as_bf16x8(cv[1][q]), acc1, 0, 0, 0);
             }
         }
+    }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {

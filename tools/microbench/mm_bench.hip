@@ -16,7 +16,7 @@ int main() {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     struct Case { const char* name; int kind; int K, Nn; size_t wbytes; };
     std::vector<Case> cases = {
-        {"swiglu  K1024 N8192 (33.5MB)", 4, 1024, 8192, 33554432}, {"resid   K8192 N1024 NW16 (16.8MB)", 116, 8192, 1024, 16777216},
+        {"swiglu  K1024 N8192 (33.5MB)", 4, 1024, 8192, 33554432}, 
         {"resid   K8192 N1024 NW4", 1, 8192, 1024, 16777216}, {"resid   K1024 N1024 (2MB)", 1, 1024, 1024, 2097152},
         {"store   K1024 N2051 (4.2MB)", 0, 1024, 2051, 4259840}, {"swiglu  K2048 N8192 (67MB)", 4, 2048, 8192, 67108864},
     };
@@ -30,7 +30,6 @@ int main() {
             a.out = (i & 1) ? x : y; a.ldo = c.kind == 4 ? c.Nn : (c.Nn + 31) / 32 * 32; a.resid = a.out;
             dim3 grid((c.Nn + 31) / 32, 1);
             if (c.kind == 4) hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4>), grid, dim3(256), 0, st, a, c.K);
-            else if (c.kind == 116) hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 16>), grid, dim3(1024), 0, st, a, c.K);
             else if (c.kind == 1) hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4>), grid, dim3(256), 0, st, a, c.K);
             else hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4>), grid, dim3(256), 0, st, a, c.K);
         }
