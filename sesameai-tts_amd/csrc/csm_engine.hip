@@ -176,7 +176,8 @@ static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStrea
 // residual projections of the wide path: fp32 partial tiles into a.slab, K split over `kg` blocks
 static int slab_groups(int M, int K) {
     if (M > 64) return 1;                                  // enough row tiles already
-    int kg = K / 1024;                                     // 1024 k per block (256 per wave)
+    static const int per_block = getenv("CSM_SLAB_K") ? atoi(getenv("CSM_SLAB_K")) : 1024;
+    int kg = K / per_block;                                // k per block (a quarter per wave)
     return kg < 1 ? 1 : (kg > 8 ? 8 : kg);
 }
 static hipError_t launch_mm_slab(int K, int kg, const GemvArgs& a, hipStream_t st) {

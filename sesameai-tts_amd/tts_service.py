@@ -7,8 +7,9 @@ Only the hot path is re-implemented: generation runs on the MI355X kernels throu
 ``sesameai.generator``.  Host-side audio post-processing that the reference does with pydub
 (peak-normalise -> int16, 500 ms lead / 100 ms tail silence, 50 ms fades, tts_service.py:288-306)
 is done with NumPy and the stdlib ``wave`` module; playback, watermarking and the WAV/resample
-loading of voice prompts are out of scope -- voices are loaded from
-pre-tokenised prompt files (``<voice>.pt`` holding ``[(text | token ids, codes[32,T]), ...]``).
+are out of scope.  Voice prompts come from a ``samples.py``-style registry of
+WAV files (loaded with ``wave`` + polyphase resampling, encoded by the GPU Mimi encoder) or from
+pre-tokenised ``<voice>.pt`` files holding ``[(text | token ids, codes[32,T]), ...]``.
 """
 import argparse
 import os
@@ -29,9 +30,46 @@ from sesameai.generator import Segment, load_csm_1b  # noqa: E402  (same import 
 
 
 def discover_voices(voice_dir: str) -> dict:
-    if not os.path.isdir(voice_dir):
-        return {}
-    return {os.path.splitext(f)[0]: os.path.join(voice_dir, f) for f in sorted(os.listdir(voice_dir)) if f.endswith(".pt")}
+    """voice name -> prompt source: ``<voice>.pt`` (pre-tokenised ``[(text, codes[32,T]), ...]``) or a
+    ``samples.py``-style module next to it defining ``name = {wav_path: transcript}`` dicts
+    (reference: samples.py:14-25, tts_service.py:36-42)."""
+    voices = {}
+    if os.path.isdir(voice_dir):
+        for f in sorted(os.listdir(voice_dir)):
+            if f.endswith(".pt"):
+                voices[os.path.splitext(f)[0]] = os.path.join(voice_dir, f)
+        sp = os.path.join(voice_dir, "samples.py")
+        if os.path.exists(sp):
+            ns: dict = {}
+            exec(compile(open(sp).read(), sp, "exec"), ns)      # user-provided voice registry, like the reference's `import samples`
+            for name, obj in ns.items():
+                if not name.startswith("__") and isinstance(obj, dict):
+                    voices[name] = obj
+    return voices
+
+
+def load_audio(path: str, target_rate: int) -> torch.Tensor:
+    """reference: TTS._load_audio (tts_service.py:141-168) without torchaudio: PCM WAV via the stdlib
+    ``wave`` module, stereo -> mono by averaging, polyphase resampling to the codec rate."""
+    with wave.open(path, "rb") as f:
+        nch, width, rate, n = f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()
+        raw = f.readframes(n)
+    if width == 2:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif width == 4:
+        x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif width == 1:
+        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise ValueError(f"{path}: unsupported sample width {width}")
+    if nch > 1:
+        x = x.reshape(-1, nch).mean(axis=1)
+    if rate != target_rate:
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(rate, target_rate)
+        x = resample_poly(x, target_rate // g, rate // g).astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(x))
 
 
 class TTS:
@@ -62,9 +100,16 @@ class TTS:
             raise ValueError("Model not loaded. Call load_model() first.")
         self.cached_context_tokens, self.cached_context_masks = [], []
         self.voice_name = voice_name
-        self.voice_data = torch.load(self.voices[voice_name])
-        for text, codes in self.voice_data:                    # reference: _prepare_context :121-139
-            tokens, masks = self.generator._tokenize_segment(Segment(speaker=1, text=text, audio_codes=codes))
+        src = self.voices[voice_name]
+        if isinstance(src, dict):                                  # {wav path: transcript}: encode with Mimi on the GPU
+            self.voice_data = src
+            segments = [Segment(speaker=1, text=text, audio=load_audio(path, self.generator.sample_rate))
+                        for path, text in src.items()]
+        else:
+            self.voice_data = torch.load(src)
+            segments = [Segment(speaker=1, text=text, audio_codes=codes) for text, codes in self.voice_data]
+        for segment in segments:                                   # reference: _prepare_context :121-139
+            tokens, masks = self.generator._tokenize_segment(segment)
             self.cached_context_tokens.append(tokens)
             self.cached_context_masks.append(masks)
         self.generate_audio_segment("I'm getting all warmed up for our chatting to begin.")   # warm-up, :119

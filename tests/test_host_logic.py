@@ -135,3 +135,27 @@ def test_weight_broadcast_and_sharding_world_size_2_gloo(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r)]) for r in range(2)]
     rcs = [p.wait(timeout=180) for p in procs]
     assert rcs == [0, 0]
+
+
+def test_wav_loading_mono_and_resample(tmp_path):
+    """tts_service.load_audio: stereo int16 44.1 kHz -> mono float 24 kHz (reference _load_audio, tts_service.py:141-168)."""
+    import importlib.util
+    import wave
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("tts_service_amd", os.path.join(ROOT, "sesameai-tts_amd", "tts_service.py"))
+    lib = os.path.join(ROOT, "sesameai-tts_amd", "lib", "libcsm_hip.so")
+    if not os.path.exists(lib):
+        import __graft_entry__ as g
+        g.build()
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    sr, secs = 44100, 0.5
+    t = np.arange(int(sr * secs)) / sr
+    left, right = 0.5 * np.sin(2 * np.pi * 440 * t), 0.25 * np.sin(2 * np.pi * 440 * t)
+    pcm = (np.stack([left, right], 1) * 32767).astype("<i2")
+    path = str(tmp_path / "a.wav")
+    with wave.open(path, "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(sr); f.writeframes(pcm.tobytes())
+    x = mod.load_audio(path, 24000)
+    assert x.dim() == 1 and abs(x.shape[0] - 12000) <= 1 and x.dtype == torch.float32
+    want = 0.375 * np.sin(2 * np.pi * 440 * np.arange(x.shape[0]) / 24000)
+    assert np.abs(x.numpy()[200:-200] - want[200:-200]).max() < 5e-3
