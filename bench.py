@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--topk", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mimi", action="store_true", help="skip the (untimed-region) Mimi decode report")
     ap.add_argument("--cpu-frames", type=int, default=64)
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle frames to time")
     ap.add_argument("--cpu-threads", type=int, default=min(32, os.cpu_count() or 1))
@@ -253,6 +254,37 @@ def main():
     assert frames.shape[0] == 1 + args.warmup + args.steps
     assert int((frames < 0).sum()) == 0 and int(frames.max()) < margs.audio_vocab_size
 
+    # ---- Mimi decode of the generated frames (reported separately, never inside `value`) ----
+    mimi = None
+    if not args.tiny and not args.no_mimi:
+        from sesameai.mimi import MimiArgs, MimiCodec
+        codec = MimiCodec(MimiArgs(), None, device=str(dev), max_frames=max(frames.shape[0], 16))
+        codes = frames[:, 0, :].t().unsqueeze(0).contiguous().to(dev)          # (1, 32, T) of utterance 0
+        T = codes.shape[2]
+
+        def timed(fn, reps=3):
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3 / reps
+
+        whole_ms = timed(lambda: codec.decode(codes))
+
+        def stream_chunks():
+            codec.reset_stream()
+            for a in range(0, T, 10):
+                codec.decode_stream(codes[:, :, a:a + 10])
+        stream_ms = timed(stream_chunks)
+        gen_ms = prefill_ms + wall * 1e3 * (frames.shape[0] - 1) / args.steps
+        mimi = {"frames": T, "decode_whole_ms": round(whole_ms, 3), "decode_stream10_ms": round(stream_ms, 3),
+                "ms_per_10_frame_chunk": round(stream_ms / max((T + 9) // 10, 1), 3),
+                "end_to_end_ms": round(gen_ms + whole_ms, 2),
+                "end_to_end_rtf": round(T * 80.0 / (gen_ms + whole_ms), 2)}
+        log(f"mimi: {mimi}")
+        del codec
+
     ms_per_step = wall * 1e3 / args.steps
     value = world * B * args.steps / wall
     p_mean = S + args.warmup + args.steps / 2.0
@@ -278,7 +310,7 @@ def main():
                                 f"{'hipGraph' if use_graph else 'eager'} frame step"),
                    "batch_per_gpu": B, "prompt_rows": S, "parallelism": f"replicas x{world}"},
         "rtf": round(value / 12.5, 2), "rtf_per_stream": round(value / 12.5 / (world * B), 2),
-        "prefill_plus_frame0_ms": round(prefill_ms, 2),
+        "prefill_plus_frame0_ms": round(prefill_ms, 2), "mimi": mimi,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "frame step (1 backbone + 31 depth-decoder steps, unique weights + KV)",

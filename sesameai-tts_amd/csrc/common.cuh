@@ -104,3 +104,27 @@ __device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
     }
     return ctr;
 }
+
+// RMSNorm of one row by one wave (torchtune rounding: fp32 normalise -> bf16 -> * bf16 scale).  Shared by
+// k_rmsnorm_rows (mm.cuh) and the sampler's fused "next decoder input" norm so both give the same bits.
+__device__ __forceinline__ void rmsnorm_row_wave(const bf16_t* x, int K, const bf16_t* scale, float eps, bf16_t* out, int lane) {
+    const uint4* src = reinterpret_cast<const uint4*>(x);
+    float ss = 0.f;
+    for (int c = lane; c < K / 8; c += 64) {
+        const uint4 v = src[c];
+        float f;
+        f = lo2f(v.x); ss += f * f; f = hi2f(v.x); ss += f * f; f = lo2f(v.y); ss += f * f; f = hi2f(v.y); ss += f * f;
+        f = lo2f(v.z); ss += f * f; f = hi2f(v.z); ss += f * f; f = lo2f(v.w); ss += f * f; f = hi2f(v.w); ss += f * f;
+    }
+    ss = wave_sum(ss);
+    const float r = 1.0f / sqrtf(ss / (float)K + eps);
+    for (int c = lane; c < K / 8; c += 64) {
+        const uint4 v = src[c], g = reinterpret_cast<const uint4*>(scale)[c];
+        uint4 o;
+        o.x = pack_bf(round_bf(lo2f(v.x) * r) * lo2f(g.x), round_bf(hi2f(v.x) * r) * hi2f(g.x));
+        o.y = pack_bf(round_bf(lo2f(v.y) * r) * lo2f(g.y), round_bf(hi2f(v.y) * r) * hi2f(g.y));
+        o.z = pack_bf(round_bf(lo2f(v.z) * r) * lo2f(g.z), round_bf(hi2f(v.z) * r) * hi2f(g.z));
+        o.w = pack_bf(round_bf(lo2f(v.w) * r) * lo2f(g.w), round_bf(hi2f(v.w) * r) * hi2f(g.w));
+        reinterpret_cast<uint4*>(out)[c] = o;
+    }
+}

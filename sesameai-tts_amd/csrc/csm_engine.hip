@@ -21,7 +21,7 @@
 
 #define BB_NSPLIT_MAX 8
 #define PART_ROWS 32
-#define WIDE_MIN_ROWS 16      // M >= this: MFMA path (mm.cuh) instead of the weight-stationary GEMV
+#define WIDE_MIN_ROWS 3       // M >= this: MFMA path (mm.cuh) instead of the weight-stationary GEMV (measured: B=3 6.0 vs 6.5 ms, B=2 narrow wins)
 
 static thread_local std::string g_create_err;
 
@@ -59,7 +59,8 @@ struct CsmModel {
     uint8_t* cur_mask;
     uint64_t* rng;
     int host_frames;                    // frames launched since reset (host mirror)
-    int wide_path;                      // MFMA path for M >= WIDE_MIN_ROWS (env CSM_WIDE=0 disables)
+    int wide_path;                      // MFMA path for M >= wide_min (env CSM_WIDE=0 disables)
+    int wide_min;                       // WIDE_MIN_ROWS unless env CSM_WIDE_MIN overrides (tuning knob)
     int fuse_dec_attn;                  // depth-decoder attention fused into the O-projection (env CSM_FUSE_DEC_ATTN=0 disables)
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
     int last_S;                         // rows per sequence of the h buffer feeding csm_depth
@@ -174,10 +175,15 @@ static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStrea
 }
 
 // residual projections of the wide path: fp32 partial tiles into a.slab, K split over `kg` blocks
-static int slab_groups(int M, int K) {
-    if (M > 64) return 1;                                  // enough row tiles already
-    static const int per_block = getenv("CSM_SLAB_K") ? atoi(getenv("CSM_SLAB_K")) : 1024;
-    int kg = K / per_block;                                // k per block (a quarter per wave)
+static int slab_groups(int K, bool prompt) {
+    // Prompt rows must not depend on how many rows share the call (prefix-KV reuse is bit-identical to a cold
+    // prefill), so the split is a function of K alone there; prompts have row tiles to fill the chip with.
+    if (prompt) return K >= 4096 ? 4 : 1;
+    // Decode steps (M <= a few row tiles): one block pulls its bytes through ONE CU at ~70 GB/s, so spread K over
+    // up to 8 blocks of >= 256 k each (measured at M = 32: K 1024 -> kg 1/2/4 = 5.1/3.9/3.3 us, K 2048 N 2048 ->
+    // kg 2/4/8 = 5.4/4.3/4.4 us; K 8192 -> 8 x 1024: blocks of 2048 or 4096 k are 3 % / 12 % slower end to end)
+    static const int per_block = getenv("CSM_SLAB_K") ? atoi(getenv("CSM_SLAB_K")) : 256;
+    int kg = K / per_block;
     return kg < 1 ? 1 : (kg > 8 ? 8 : kg);
 }
 static hipError_t launch_mm_slab(int K, int kg, const GemvArgs& a, hipStream_t st) {
@@ -217,8 +223,12 @@ static hipError_t launch_attn(int hd, const AttnArgs& a, hipStream_t st, bool co
 // ---------------------------------------------------------------------------------------
 // one Llama stack over M token rows (in place on h)
 // ---------------------------------------------------------------------------------------
+// where the stack's final RMSNorm of each sequence's LAST row goes on the wide path (fused into the last finisher)
+struct FinalNorm { const bf16_t* scale; bf16_t* out; long out_stride; };
+
 static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t* att, bf16_t* act,
-                                 int M, int rows_per_seq, const int* pos, hipStream_t st) {
+                                 int M, int rows_per_seq, const int* pos, hipStream_t st, bool prompt, const FinalNorm& fin,
+                                 bool x_normed) {
     // unfused wide-M layer: norm -> MFMA qkv(+rope, KV append) -> attention -> MFMA o-proj(+res) ->
     // norm -> MFMA gate/up(SiLU*up) -> MFMA down(+res).  `att` doubles as the normalised-activation buffer.
     const int d = S.d.dim;
@@ -230,7 +240,7 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         bf16_t* vc = S.vc + (long)l * S.layer_stride;
         GemvArgs a;
         // layer 0 normalises h directly; later layers got xn from the previous down-projection's finisher
-        if (l == 0 && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+        if (l == 0 && !x_normed && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = d; a.M = M;
         a.w0 = (const bf16_t*)pk.wq; a.w1 = (const bf16_t*)pk.wk; a.w2 = (const bf16_t*)pk.wv;
@@ -246,7 +256,7 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         // o-proj -> fp32 slabs; finisher: h += sum(slabs), xn = mlp_norm(h)
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)pk.wo; a.N = d; a.slab = m->slab;
-        int kg = slab_groups(M, S.nq);
+        int kg = slab_groups(S.nq, prompt);
         if ((e = launch_mm_slab(S.nq, kg, a, st)) != hipSuccess) return e;
         if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
         memset(&a, 0, sizeof a);
@@ -256,10 +266,17 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         // down-proj -> slabs; finisher applies the NEXT layer's sa_norm (or nothing after the last layer)
         memset(&a, 0, sizeof a);
         a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)pk.w2; a.N = d; a.slab = m->slab;
-        kg = slab_groups(M, S.d.ffn);
+        kg = slab_groups(S.d.ffn, prompt);
         if ((e = launch_mm_slab(S.d.ffn, kg, a, st)) != hipSuccess) return e;
-        const bf16_t* next_scale = (l + 1 < S.d.n_layers) ? (const bf16_t*)S.lw[l + 1].sa_norm : nullptr;
-        if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, next_scale, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+        if (l + 1 < S.d.n_layers) {
+            if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)S.lw[l + 1].sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+        } else {
+            // last layer: only each sequence's last row is read again (heads / last_h); its finisher applies the
+            // stack's final norm
+            const int nseq = M / rows_per_seq;
+            if ((e = launch_resid_norm(h, m->slab, kg, M, d, rows_per_seq, rows_per_seq - 1, nseq, fin.scale, S.d.norm_eps,
+                                       fin.out, fin.out_stride, st)) != hipSuccess) return e;
+        }
     }
     return hipSuccess;
 }
@@ -267,8 +284,14 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
 // pos: per-row positions (always valid); pos_const >= 0: all rows of a sequence sit at pos_const + row-in-sequence
 // (depth decoder), which lets the narrow path drop the dependent position load
 static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t* att, bf16_t* act,
-                            int M, int rows_per_seq, const int* pos_arr, int pos_const, hipStream_t st, bool force_wide = false) {
-    if ((M >= WIDE_MIN_ROWS || force_wide) && m->wide_path) return run_stack_wide(m, S, h, q, att, act, M, rows_per_seq, pos_arr, st);
+                            int M, int rows_per_seq, const int* pos_arr, int pos_const, hipStream_t st, bool force_wide = false,
+                            bool x_normed = false) {
+    if ((M >= m->wide_min || force_wide) && m->wide_path) {
+        FinalNorm fin;
+        if (&S == &m->bb) { fin.scale = (const bf16_t*)m->w.bb_norm; fin.out = m->dec_in; fin.out_stride = 2L * S.d.dim; }
+        else { fin.scale = (const bf16_t*)m->w.dec_norm; fin.out = att; fin.out_stride = S.d.dim; }
+        return run_stack_wide(m, S, h, q, att, act, M, rows_per_seq, pos_arr, st, force_wide, fin, x_normed);
+    }
     const int* pos = pos_const >= 0 ? nullptr : pos_arr;
     const int pos_base = pos_const >= 0 ? pos_const : 0;
     const int d = S.d.dim;
@@ -365,13 +388,15 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
                 memset(&a, 0, sizeof a);
                 a.x = m->dec_in; a.x_row_stride = 2L * dbb; a.M = B;
                 a.w0 = (const bf16_t*)m->w.projection; a.N = dd; a.out = m->hdec; a.ldo = 2L * dd; a.nt = 0;
-                if (B >= WIDE_MIN_ROWS && m->wide_path) { a.w0 = m->pk_projection; e = launch_mm(0, dbb, 0, a, st); }
+                if (B >= m->wide_min && m->wide_path) { a.w0 = m->pk_projection; e = launch_mm(0, dbb, 0, a, st); }
                 else e = launch_gemv(0, dbb, 0, a, st);
                 if (e != hipSuccess) return e;
             }
             // decoder positions are static per step: rows (0,1) on the first call, then cb
             const int* pos = m->dec_pos + (long)(cb == 1 ? 0 : cb) * 2 * m->max_batch;
-            if ((e = run_stack(m, m->dec, m->hdec, m->qd, m->attd, m->actd, rows, cb == 1 ? 2 : 1, pos, cb == 1 ? 0 : cb, st)) != hipSuccess) return e;
+            // cb >= 2 on the wide path: the previous sampler already wrote sa_norm(row) into attd
+            const bool x_normed = cb >= 2 && B >= m->wide_min && m->wide_path;
+            if ((e = run_stack(m, m->dec, m->hdec, m->qd, m->attd, m->actd, rows, cb == 1 ? 2 : 1, pos, cb == 1 ? 0 : cb, st, false, x_normed)) != hipSuccess) return e;
         }
         // final RMSNorm + head -> logits (bf16, padded rows)
         memset(&a, 0, sizeof a);
@@ -387,12 +412,12 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             a.w0 = (const bf16_t*)m->w.audio_head_t + (long)(cb - 1) * V * dd; a.nt = 1;
         }
         a.M = B; a.N = V; a.out = m->logits; a.ldo = m->ldl;
-        if (B >= WIDE_MIN_ROWS && m->wide_path) {
-            // norm of each sequence's last row (side output = last_h for cb == 0), then the MFMA head
+        if (B >= m->wide_min && m->wide_path) {
+            // normalised last row of each sequence (= last_h for cb == 0), then the MFMA head
             const int Kh = cb == 0 ? dbb : dd;
             bf16_t* xn = cb == 0 ? m->dec_in : m->attd;
             const long xs = cb == 0 ? 2L * dbb : (long)dd;
-            if ((e = launch_rmsnorm_rows(a.x, a.x_row_stride, a.x_row_offset, B, Kh, a.norm_scale, a.eps, xn, xs, st)) != hipSuccess) return e;
+            // (the final norm was applied by the stack's last finisher: run_stack_wide)
             a.x = xn; a.x_row_stride = xs; a.x_row_offset = 0;
             a.w0 = cb == 0 ? m->pk_c0_head : m->pk_audio_head + (long)(cb - 1) * m->pk_head_stride;
             if ((e = launch_mm(0, Kh, 0, a, st)) != hipSuccess) return e;
@@ -414,7 +439,12 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
         // next decoder input = projection(embedding of the fed code) = one row of the table
         s.audio_emb = m->proj_emb; s.audio_vocab = V; s.d = dd;
         if (cb == 0) { s.emb_out = m->hdec + dd; s.emb_stride = 2L * dd; }
-        else if (cb < ncb - 1) { s.emb_out = m->hdec; s.emb_stride = dd; }
+        else if (cb < ncb - 1) {
+            s.emb_out = m->hdec; s.emb_stride = dd;
+            if (B >= m->wide_min && m->wide_path) {       // next decoder step runs wide: hand it layer 0's normalised input too
+                s.xn_scale = (const bf16_t*)m->dec.lw[0].sa_norm; s.xn_eps = c.decoder.norm_eps; s.xn_out = m->attd; s.xn_stride = dd;
+            }
+        }
         if ((e = launch_sample(s, B, st)) != hipSuccess) return e;
     }
     return hipSuccess;
@@ -501,6 +531,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     m->host_frames = 0; m->have_last = false; m->last_S = 1;
     { const char* ev = getenv("CSM_FUSE_DEC_ATTN"); m->fuse_dec_attn = !(ev && ev[0] == '0'); }
     { const char* ev = getenv("CSM_WIDE"); m->wide_path = !(ev && ev[0] == '0'); }
+    { const char* ev = getenv("CSM_WIDE_MIN"); m->wide_min = ev && atoi(ev) > 0 ? atoi(ev) : WIDE_MIN_ROWS; }
     // Cache policy (measured, tools/microbench/gemv_bench.hip): a depth-decoder step touches
     // ~230 MB, about the size of the 256 MB Infinity Cache, so with default-policy loads the
     // 31-step cycle thrashes it and even the 2-3 MB q/k/v/o streams come from HBM (4.9 us per

@@ -23,25 +23,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm_rows(const bf16_t* x, long x_ro
                                                       const bf16_t* scale, float eps, bf16_t* out, long out_stride) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
-    const uint4* src = reinterpret_cast<const uint4*>(x + (long)row * x_row_stride + x_row_offset);
-    float ss = 0.f;
-    for (int c = lane; c < K / 8; c += 64) {
-        const uint4 v = src[c];
-        float f;
-        f = lo2f(v.x); ss += f * f; f = hi2f(v.x); ss += f * f; f = lo2f(v.y); ss += f * f; f = hi2f(v.y); ss += f * f;
-        f = lo2f(v.z); ss += f * f; f = hi2f(v.z); ss += f * f; f = lo2f(v.w); ss += f * f; f = hi2f(v.w); ss += f * f;
-    }
-    ss = wave_sum(ss);
-    const float r = 1.0f / sqrtf(ss / (float)K + eps);
-    for (int c = lane; c < K / 8; c += 64) {
-        const uint4 v = src[c], g = reinterpret_cast<const uint4*>(scale)[c];
-        uint4 o;
-        o.x = pack_bf(round_bf(lo2f(v.x) * r) * lo2f(g.x), round_bf(hi2f(v.x) * r) * hi2f(g.x));
-        o.y = pack_bf(round_bf(lo2f(v.y) * r) * lo2f(g.y), round_bf(hi2f(v.y) * r) * hi2f(g.y));
-        o.z = pack_bf(round_bf(lo2f(v.z) * r) * lo2f(g.z), round_bf(hi2f(v.z) * r) * hi2f(g.z));
-        o.w = pack_bf(round_bf(lo2f(v.w) * r) * lo2f(g.w), round_bf(hi2f(v.w) * r) * hi2f(g.w));
-        reinterpret_cast<uint4*>(out + (long)row * out_stride)[c] = o;
-    }
+    rmsnorm_row_wave(x + (long)row * x_row_stride + x_row_offset, K, scale, eps, out + (long)row * out_stride, lane);
 }
 
 // Finishes a split-K residual projection of the wide path and (optionally) applies the next RMSNorm:

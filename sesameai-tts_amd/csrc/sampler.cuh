@@ -81,6 +81,10 @@ struct SampleArgs {
     int audio_vocab, d;
     bf16_t* emb_out;          // row b at emb_out + b*emb_stride (elements); may be null
     long emb_stride;
+    const bf16_t* xn_scale;   // optional: also write RMSNorm(row) * xn_scale (the next stack's first sa_norm, wide path)
+    float xn_eps;
+    bf16_t* xn_out;           // row b at xn_out + b*xn_stride
+    long xn_stride;
 };
 
 __device__ __forceinline__ uint32_t order_key(float t) {     // monotone map of a bf16-valued float
@@ -296,6 +300,8 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
         const uint4* src = reinterpret_cast<const uint4*>(a.audio_emb + ((long)a.codebook * a.audio_vocab + fed) * a.d);
         uint4* dst = reinterpret_cast<uint4*>(a.emb_out + (long)b * a.emb_stride);
         for (int c = tid; c < a.d / 8; c += 256) dst[c] = src[c];
+        if (a.xn_out && wave == 0)
+            rmsnorm_row_wave(reinterpret_cast<const bf16_t*>(src), a.d, a.xn_scale, a.xn_eps, a.xn_out + (long)b * a.xn_stride, lane);
     }
 }
 

@@ -299,18 +299,25 @@ def test_long_context_streaming_config5_shape():
         gen.generate_codes(tok, msk, 2048 - 1334, 0.9, 50)         # S >= 2048 - max_generation_len
 
 
-def test_csm1b_teacher_forced_vs_golden():
-    """Full CSM-1B shapes, seeded weights: logits (top-8 per row) and greedy indices for every
-    codebook of every golden frame, teacher-forced on the oracle's trajectory."""
+@pytest.fixture(scope="module")
+def csm1b():
+    """(golden, seeded CSM-1B state dict on the host) shared by the full-size tests."""
     path = os.path.join(GOLD, "csm1b_frames.pt")
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     if not os.path.exists(path):
         pytest.skip("csm1b golden not generated")
-    from sesameai.models import Model, csm_1b_args, synthetic_state_dict
+    from sesameai.models import csm_1b_args, synthetic_state_dict
     gold = torch.load(path)
-    m = Model(csm_1b_args(), synthetic_state_dict(csm_1b_args(), seed=int(gold["weight_seed"])), max_frames=64,
-              max_prefill_rows=256)
+    return gold, synthetic_state_dict(csm_1b_args(), seed=int(gold["weight_seed"]))
+
+
+def test_csm1b_teacher_forced_vs_golden(csm1b):
+    """Full CSM-1B shapes, seeded weights: logits (top-8 per row) and greedy indices for every
+    codebook of every golden frame, teacher-forced on the oracle's trajectory."""
+    from sesameai.models import Model, csm_1b_args
+    gold, sd = csm1b
+    m = Model(csm_1b_args(), sd, max_frames=64, max_prefill_rows=256)
     m.setup_caches(1)
     tok, msk = gold["prompt_tokens"], gold["prompt_mask"]
     S = tok.shape[0]
@@ -332,3 +339,64 @@ def test_csm1b_teacher_forced_vs_golden():
     assert max_diff <= 2 * noise + 1e-3
     for f, cb, margin in mism:
         assert margin <= 2 * noise, f"greedy index differs at frame {f} codebook {cb} with margin {margin}"
+
+
+def test_csm1b_batched_wide_path_vs_golden(csm1b):
+    """Full size, B = 4 identical utterances: every row takes the matrix-core (wide) path in BOTH stacks; rows must be
+    bit-identical to each other (no cross-row coupling) and match the oracle's golden logits like the B = 1 path."""
+    from sesameai.models import Model, csm_1b_args
+    gold, sd = csm1b
+    B = 4
+    m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * 256)
+    m.setup_caches(B)
+    tok, msk = gold["prompt_tokens"], gold["prompt_mask"]
+    S = tok.shape[0]
+    noise = float(gold["bf16_vs_fp32_gap"].max())
+    m.prefill(tok.unsqueeze(0).repeat(B, 1, 1), msk.unsqueeze(0).repeat(B, 1, 1), torch.arange(S).unsqueeze(0).repeat(B, 1))
+    max_diff = 0.0
+    for f in range(3):
+        forced = gold["codes"][f].unsqueeze(0).repeat(B, 1)
+        out, logits = m.depth(B, 1.0, 1, forced=forced, want_logits=True, commit=False)      # logits [32][B][V]
+        for b in range(1, B):
+            assert torch.equal(logits[:, b], logits[:, 0]) and torch.equal(out[b], out[0])
+        lg = logits[:, 0].float().cpu()
+        max_diff = max(max_diff, (torch.gather(lg, 1, gold["top_i"][f].long()) - gold["top_v"][f].float()).abs().max().item())
+        for cb in (out[0].cpu() != gold["codes"][f]).nonzero().flatten().tolist():
+            assert float(gold["margin"][f, cb]) <= 2 * noise, f"greedy index differs at frame {f} codebook {cb}"
+        row = torch.zeros(B, 1, 33, dtype=torch.long); row[:, 0, :32] = gold["codes"][f].long()
+        rmask = torch.ones(B, 1, 33, dtype=torch.bool); rmask[:, 0, 32] = False
+        m.prefill(row, rmask, torch.full((B, 1), S + f))
+    print(f"csm-1b B=4 wide path: max|dlogit|={max_diff:.4f} (gap {noise:.4f})")
+    assert max_diff <= 2 * noise + 1e-3
+
+
+def test_csm1b_prefix_reuse_bit_identical(csm1b):
+    """Full size: a follow-up sentence prefills only its new rows and generates exactly the frames of a cold prefill
+    (the split-K grouping of prompt rows is a function of K alone, never of the row count)."""
+    from sesameai.generator import Generator
+    from sesameai.models import Model, csm_1b_args
+    gold, sd = csm1b
+    m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=256)
+    m.setup_caches(1)
+    gen = Generator.__new__(Generator)
+    gen._model, gen.device, gen._eos_poll, gen._audio_tokenizer, gen._text_tokenizer = m, m.device, 4, None, None
+    g = torch.Generator().manual_seed(5)
+    ctx_t = torch.zeros(150, 33, dtype=torch.long); ctx_m = torch.zeros(150, 33, dtype=torch.bool)
+    ctx_t[:30, 32] = torch.randint(0, 128256, (30,), generator=g); ctx_m[:30, 32] = True
+    ctx_t[30:, :32] = torch.randint(0, 2048, (120, 32), generator=g); ctx_m[30:, :32] = True
+
+    def prompt(n_text, seed):
+        t = torch.zeros(n_text, 33, dtype=torch.long); mk = torch.zeros(n_text, 33, dtype=torch.bool)
+        t[:, 32] = torch.randint(0, 128256, (n_text,), generator=torch.Generator().manual_seed(seed)); mk[:, 32] = True
+        return torch.cat([ctx_t, t]), torch.cat([ctx_m, mk])
+
+    p1, p2 = prompt(20, 1), prompt(24, 2)
+    m.prefix_reuse = True
+    m._kv_prompt = None
+    gen.generate_codes(*p1, 3, 1.0, 1)
+    warm = gen.generate_codes(*p2, 3, 1.0, 1)
+    assert m.last_prefill_rows == 24
+    m.prefix_reuse = False
+    cold = gen.generate_codes(*p2, 3, 1.0, 1)
+    assert m.last_prefill_rows == 174
+    assert torch.equal(warm, cold)

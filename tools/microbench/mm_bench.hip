@@ -14,11 +14,18 @@ int main() {
     CK(hipMalloc(&y, 4 << 20)); CK(hipMemset(y, 0, 4 << 20));
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    struct Case { const char* name; int kind; int K, Nn; size_t wbytes; };
+    struct Case { const char* name; int kind; int K, Nn; size_t wbytes; int kg = 1; };
+    float* slab; CK(hipMalloc(&slab, 8u * 32 * 2048 * 4));
     std::vector<Case> cases = {
         {"swiglu  K1024 N8192 (33.5MB)", 4, 1024, 8192, 33554432}, 
         {"resid   K8192 N1024 NW4", 1, 8192, 1024, 16777216}, {"resid   K1024 N1024 (2MB)", 1, 1024, 1024, 2097152},
         {"store   K1024 N2051 (4.2MB)", 0, 1024, 2051, 4259840}, {"swiglu  K2048 N8192 (67MB)", 4, 2048, 8192, 67108864},
+        {"slab    K1024 N1024 kg1", 5, 1024, 1024, 2097152, 1}, {"slab    K1024 N1024 kg2", 5, 1024, 1024, 2097152, 2},
+        {"slab    K1024 N1024 kg4", 5, 1024, 1024, 2097152, 4},
+        {"slab    K8192 N1024 kg8", 5, 8192, 1024, 16777216, 8},
+        {"slab    K2048 N2048 kg2", 5, 2048, 2048, 8388608, 2}, {"slab    K2048 N2048 kg4", 5, 2048, 2048, 8388608, 4},
+        {"slab    K2048 N2048 kg8", 5, 2048, 2048, 8388608, 8},
+        {"slab    K8192 N2048 kg8", 5, 8192, 2048, 33554432, 8},
     };
     for (auto& c : cases) {
         hipGraph_t g; hipGraphExec_t ge;
@@ -28,7 +35,9 @@ int main() {
             const bf16_t* wl = w + (size_t)(i % 8) * (c.wbytes / 2);
             a.x = (i & 1) ? y : x; a.x_row_stride = c.K; a.M = 32; a.w0 = wl; a.w1 = wl + c.wbytes / 4; a.N = c.Nn;
             a.out = (i & 1) ? x : y; a.ldo = c.kind == 4 ? c.Nn : (c.Nn + 31) / 32 * 32; a.resid = a.out;
-            dim3 grid((c.Nn + 31) / 32, 1);
+            dim3 grid((c.Nn + 31) / 32, 1, c.kg);
+            a.slab = slab;
+            if (c.kind == 5) { hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4>), grid, dim3(256), 0, st, a, c.K); continue; }
             if (c.kind == 4) hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4>), grid, dim3(256), 0, st, a, c.K);
             else if (c.kind == 1) hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4>), grid, dim3(256), 0, st, a, c.K);
             else hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4>), grid, dim3(256), 0, st, a, c.K);
