@@ -15,6 +15,8 @@ extern "C" {
  * interleaved RoPE + KV append; 4 RMSNorm + gate/up + SiLU*up.  K = 512*{1,2,4,16}.
  * kind + 10 (10, 11, 13, 14): the wide-M matrix-core kernels (M >= 16 rows, prompt prefill and
  * batched decode) of kinds 0, 1, 3, 4; x must already be normalised, K % 256 == 0.
+ * kind + 20 (20, 21, 23, 24): the same through the 128 x 128 LDS-tiled kernel that long prompts (M >= 512 rows)
+ * take; bit-identical to kind + 10.
  * Replaces torchtune's RMSNorm / nn.Linear / Llama3ScaledRoPE / KVCache.update / FeedForward
  * as called from sesameai/models.py:158,173.                          */
 int csm_op_gemv(int kind, int M, int K, int N, const void* x, long x_row_stride, long x_row_offset,

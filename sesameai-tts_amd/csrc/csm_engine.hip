@@ -17,6 +17,7 @@
 #include "attn.cuh"
 #include "gemv.cuh"
 #include "mm.cuh"
+#include "gemm128.cuh"
 #include "sampler.cuh"
 
 #define BB_NSPLIT_MAX 8
@@ -159,26 +160,62 @@ static hipError_t launch_gemv8(int kind, int K, int hd, const GemvArgs& a, hipSt
 }
 
 // wide-M projections on the matrix cores; kind as in launch_gemv (0 store, 1 +residual, 3 qkv/rope, 4 swiglu)
+#define XCD_TILING_MIN_ROWS 256     // prompts with >= 8 row tiles: XCD-aware 1-D tile order (mm.cuh)
+static void mm_grid(const GemvArgs& a, int kg, dim3* grid, int* mt8) {
+    const int nt = (a.N + 31) / 32, mt = (a.M + 31) / 32;
+    if (a.M >= XCD_TILING_MIN_ROWS) { *mt8 = (mt + 7) / 8; *grid = dim3((unsigned)(8L * nt * kg * *mt8)); }
+    else { *mt8 = 0; *grid = dim3(nt, mt, kg); }
+}
 static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
     if (K % 256 != 0) return hipErrorInvalidValue;
-    dim3 grid((a.N + 31) / 32, (a.M + 31) / 32);
+    dim3 grid; int mt8;
+    mm_grid(a, 1, &grid, &mt8);
     switch (kind) {
-        case 0: hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4>), grid, dim3(256), 0, st, a, K); break;
-        case 1: hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4>), grid, dim3(256), 0, st, a, K); break;
-        case 3: if (hd == 64) hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 64, 4>), grid, dim3(256), 0, st, a, K);
-                else hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 128, 4>), grid, dim3(256), 0, st, a, K);
+        case 0: hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4>), grid, dim3(256), 0, st, a, K, mt8, 1); break;
+        case 1: hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4>), grid, dim3(256), 0, st, a, K, mt8, 1); break;
+        case 3: if (hd == 64) hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 64, 4>), grid, dim3(256), 0, st, a, K, mt8, 1);
+                else hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 128, 4>), grid, dim3(256), 0, st, a, K, mt8, 1);
                 break;
-        case 4: hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4>), grid, dim3(256), 0, st, a, K); break;
+        case 4: hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4>), grid, dim3(256), 0, st, a, K, mt8, 1); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
+// long prompts / batched prefill: LDS-tiled 128 x 128 kernel (gemm128.cuh); weights UNPACKED [N][K]
+#define G128_MIN_ROWS 512
+template <int EPI, int HD>
+static hipError_t launch_g128_t(const GemvArgs& a, int K, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipGetLastError();
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm128<EPI, HD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G128_SMEM);
+        if (e != hipSuccess) { fprintf(stderr, "k_gemm128: hipFuncSetAttribute(%d B LDS): %s\n", G128_SMEM, hipGetErrorString(e)); return e; }
+        attr_set = true;
+    }
+    const int nout = EPI == EPI_SWIGLU ? 64 : 128;
+    const int mt8 = ((a.M + 127) / 128 + 7) / 8, ntiles = (a.N + nout - 1) / nout;
+    hipLaunchKernelGGL((k_gemm128<EPI, HD>), dim3((unsigned)(8L * ntiles * mt8)), dim3(256), G128_SMEM, st, a, K, mt8, (long)K);
+    return hipGetLastError();
+}
+static hipError_t launch_g128(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
+    if (K % 256 != 0) return hipErrorInvalidValue;
+    switch (kind) {
+        case 0: return launch_g128_t<EPI_STORE, 64>(a, K, st);
+        case 1: return launch_g128_t<EPI_RESID, 64>(a, K, st);
+        case 3: return hd == 64 ? launch_g128_t<EPI_QKV_ROPE, 64>(a, K, st) : launch_g128_t<EPI_QKV_ROPE, 128>(a, K, st);
+        case 4: return launch_g128_t<EPI_SWIGLU, 64>(a, K, st);
+    }
+    return hipErrorInvalidValue;
+}
+
 // residual projections of the wide path: fp32 partial tiles into a.slab, K split over `kg` blocks
 static int slab_groups(int K, bool prompt) {
     // Prompt rows must not depend on how many rows share the call (prefix-KV reuse is bit-identical to a cold
-    // prefill), so the split is a function of K alone there; prompts have row tiles to fill the chip with.
-    if (prompt) return K >= 4096 ? 4 : 1;
+    // prefill): no split there -- the four K quarters of a block's waves are the canonical summation order that
+    // k_gemm128 reproduces for long prompts.
+    if (prompt) return 1;
     // Decode steps (M <= a few row tiles): one block pulls its bytes through ONE CU at ~70 GB/s, so spread K over
     // up to 8 blocks of >= 256 k each (measured at M = 32: K 1024 -> kg 1/2/4 = 5.1/3.9/3.3 us, K 2048 N 2048 ->
     // kg 2/4/8 = 5.4/4.3/4.4 us; K 8192 -> 8 x 1024: blocks of 2048 or 4096 k are 3 % / 12 % slower end to end)
@@ -188,8 +225,9 @@ static int slab_groups(int K, bool prompt) {
 }
 static hipError_t launch_mm_slab(int K, int kg, const GemvArgs& a, hipStream_t st) {
     if (K % (256 * kg) != 0) return hipErrorInvalidValue;
-    dim3 grid((a.N + 31) / 32, (a.M + 31) / 32, kg);
-    hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4>), grid, dim3(256), 0, st, a, K);
+    dim3 grid; int mt8;
+    mm_grid(a, kg, &grid, &mt8);
+    hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4>), grid, dim3(256), 0, st, a, K, mt8, kg);
     return hipGetLastError();
 }
 static hipError_t launch_resid_norm(bf16_t* h, const float* slab, int kg, int M, int N, long row_step, long row_first, int M_out,
@@ -233,12 +271,47 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
     // norm -> MFMA gate/up(SiLU*up) -> MFMA down(+res).  `att` doubles as the normalised-activation buffer.
     const int d = S.d.dim;
     hipError_t e;
+    const bool big = M >= G128_MIN_ROWS;      // 128 x 128 LDS-tiled kernels, direct epilogues (same bits as the path below)
     for (int l = 0; l < S.d.n_layers; ++l) {
         const CsmLayerWeights& w = S.lw[l];
         const CsmLayerWeights& pk = S.pk[l];
         bf16_t* kc = S.kc + (long)l * S.layer_stride;
         bf16_t* vc = S.vc + (long)l * S.layer_stride;
         GemvArgs a;
+        if (big) {
+            if (l == 0 && !x_normed && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+            memset(&a, 0, sizeof a);
+            a.x = att; a.x_row_stride = d; a.M = M;
+            a.w0 = (const bf16_t*)w.wq; a.w1 = (const bf16_t*)w.wk; a.w2 = (const bf16_t*)w.wv;
+            a.N = S.nq + 2 * S.nkv; a.out = q; a.ldo = S.nq;
+            a.nq = S.nq; a.nkv = S.nkv; a.smax = S.cache_len; a.rows_per_seq = rows_per_seq; a.kv_heads = S.d.n_kv_heads;
+            a.pos = pos; a.rope = S.rope; a.kcache = kc; a.vcache = vc;
+            if ((e = launch_g128(3, d, S.hd, a, st)) != hipSuccess) return e;
+            AttnArgs t;
+            t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
+            t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = 1;
+            t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
+            if ((e = launch_attn(S.hd, t, st)) != hipSuccess) return e;
+            memset(&a, 0, sizeof a);
+            a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)w.wo; a.N = d; a.out = h; a.ldo = d; a.resid = h;
+            if ((e = launch_g128(1, S.nq, S.hd, a, st)) != hipSuccess) return e;
+            if ((e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+            memset(&a, 0, sizeof a);
+            a.x = att; a.x_row_stride = d; a.M = M; a.w0 = (const bf16_t*)w.w1; a.w1 = (const bf16_t*)w.w3; a.N = S.d.ffn;
+            a.out = act; a.ldo = S.d.ffn;
+            if ((e = launch_g128(4, d, S.hd, a, st)) != hipSuccess) return e;
+            memset(&a, 0, sizeof a);
+            a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)w.w2; a.N = d; a.out = h; a.ldo = d; a.resid = h;
+            if ((e = launch_g128(1, S.d.ffn, S.hd, a, st)) != hipSuccess) return e;
+            if (l + 1 < S.d.n_layers) {
+                if ((e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)S.lw[l + 1].sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+            } else {
+                const int nseq = M / rows_per_seq;
+                if ((e = launch_rmsnorm_rows(h, (long)rows_per_seq * d, (long)(rows_per_seq - 1) * d, nseq, d, fin.scale, S.d.norm_eps,
+                                             fin.out, fin.out_stride, st)) != hipSuccess) return e;
+            }
+            continue;
+        }
         // layer 0 normalises h directly; later layers got xn from the previous down-projection's finisher
         if (l == 0 && !x_normed && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
         memset(&a, 0, sizeof a);
@@ -779,8 +852,11 @@ extern "C" int csm_op_gemv(int kind, int M, int K, int N, const void* x, long x_
     a.rope = (const bf16_t*)rope; a.kcache = (bf16_t*)kcache; a.vcache = (bf16_t*)vcache;
     // kinds 10/11/13/14: the wide-M matrix-core path (mm.cuh) of kinds 0/1/3/4 (x already normalised);
     // the hook re-tiles the row-major test weights into the matrix-core operand order first
+    // kinds 20/21/23/24: the same through the 128 x 128 LDS-tiled kernel of long prompts (gemm128.cuh, row-major weights)
     hipError_t e;
-    if (kind >= 10) {
+    if (kind >= 20) {
+        e = launch_g128(kind - 20, K, head_dim, a, (hipStream_t)stream);
+    } else if (kind >= 10) {
         std::vector<void*> tmp;
         auto pack = [&](const bf16_t* w, int n) -> const bf16_t* {
             if (!w) return nullptr;

@@ -1,0 +1,144 @@
+// Long prompts / batched prefill (M >= 512 token rows): LDS-tiled bf16 GEMM on the matrix cores.
+//
+//   out[M][N] = x[M][K] . W[N][K]^T       W in its ORIGINAL row-major layout (no packed copy needed)
+//
+// k_mm32 (mm.cuh) gives every 32 x 32 output tile its own block, which is right for a handful of row
+// tiles but re-reads x N/32 times and W M/32 times; at thousands of rows that traffic (and the
+// 64-cache-line x gathers feeding the MFMAs) is what bounds it.  Here a block owns a 128 x 128 tile
+// (SwiGLU: 128 rows x 64 gate + 64 up columns), stages 64-deep K slices of both operands through LDS
+// with coalesced 128-byte row reads (8 lanes per row), and its four waves (2 x 2) each run 2 x 2
+// v_mfma_f32_32x32x16_bf16 tiles from conflict-free ds_read_b128 fragments (segment s of row t is stored at
+// s ^ ((t >> 1) & 7): the 16 lanes of a read phase then cover all 64 banks once).
+// Global loads of slice c+1 are in flight while slice c feeds the MFMAs (LDS double buffer, one
+// barrier per slice).
+//
+// BIT-IDENTICAL to k_mm32's prompt mode by construction: the same MFMA instruction with the same
+// operand-to-k mapping inside each 64-chunk (lane half h, step q <- k = 32h + 8q .. +8), chained in
+// the same order, and the same association of the four K-quarter partial sums
+// (((0 + p0) + p1) + p2) + p3 -- k_mm32 spreads the quarters over its four waves and adds them through
+// LDS, this kernel runs them back to back and folds each into `tot`.  A prompt row therefore has the
+// same bits whether it was prefilled cold with 1,500 others or alone after a prefix-KV hit
+// (tests/test_ops_gpu.py::test_gemm128_equals_mm32_bitwise).
+#pragma once
+#include "mm.cuh"
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4_t& v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+#define G128_LD 64                        // LDS row = one 64-deep K slice (128 B); 16-byte segments XOR-swizzled
+#define G128_SMEM (2 * 256 * G128_LD * 2) // two buffers of (128 A rows + 128 B rows) = 64 KB
+
+template <int EPI, int HD, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void k_gemm128(const GemvArgs a, const int K, const int mt8, const long ldw) {
+    extern __shared__ __align__(16) unsigned char g128_smem[];
+    bf16_t* lds = reinterpret_cast<bf16_t*>(g128_smem);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order (see k_mm32): XCD c owns row tiles {c, c+8, ...}; consecutive blocks of one XCD
+    // walk those row tiles for one column tile, so W tiles are fetched once per XCD and the XCD's share of x
+    // stays in its L2
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int mt = (j % mt8) * 8 + xcd, nt = j / mt8;
+    if (mt * 128 >= a.M) return;
+    constexpr int NOUT = EPI == EPI_SWIGLU ? 64 : 128;      // output columns per block
+    const int m0 = mt * 128, n0 = nt * NOUT;
+
+    // this thread's four 16-byte pieces of each operand slice: rows (tid >> 3) + 32 i, segment tid & 7
+    const int seg = tid & 7, row0 = tid >> 3;
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tr = row0 + 32 * i;
+        pa[i] = a.x + (long)min(m0 + tr, a.M - 1) * a.x_row_stride + a.x_row_offset + seg * 8;
+        const bf16_t* wsrc;
+        int n;
+        if (EPI == EPI_SWIGLU) {                            // B rows: [wave column][gate 32 | up 32]
+            n = min(n0 + (tr >> 6) * 32 + (tr & 31), a.N - 1);
+            wsrc = ((tr >> 5) & 1) ? a.w1 : a.w0;
+        } else if (EPI == EPI_QKV_ROPE) {
+            n = min(n0 + tr, a.N - 1);
+            if (n < a.nq) wsrc = a.w0;
+            else if (n < a.nq + a.nkv) { wsrc = a.w1; n -= a.nq; }
+            else { wsrc = a.w2; n -= a.nq + a.nkv; }
+        } else {
+            n = min(n0 + tr, a.N - 1);
+            wsrc = a.w0;
+        }
+        pb[i] = wsrc + (long)n * ldw + seg * 8;
+    }
+    u32x4_t ra[4], rb[4];                 // compiler vector type: HIP's uint4 struct kept these in scratch memory
+#define G128_GLOAD(kc)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
+        ra[i] = *reinterpret_cast<const u32x4_t*>(pa[i] + (kc));                          \
+        rb[i] = *reinterpret_cast<const u32x4_t*>(pb[i] + (kc));                          \
+    }
+    // rows row0 + 32 i share (row >> 1) & 7, so one swizzled segment serves all four pieces
+    const int wseg = seg ^ ((row0 >> 1) & 7);
+    bf16_t* const wbase = lds + row0 * G128_LD + wseg * 8;
+#define G128_LWRITE(buf)                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
+        *reinterpret_cast<u32x4_t*>(wbase + (buf) * (256 * G128_LD) + (32 * i) * G128_LD) = ra[i];      \
+        *reinterpret_cast<u32x4_t*>(wbase + (buf) * (256 * G128_LD) + (128 + 32 * i) * G128_LD) = rb[i];  \
+    }
+    const int sw = (r >> 1) & 7;              // fragment rows are wm*64 + mi*32 + r: (row >> 1) & 7 == (r >> 1) & 7
+
+    f32x16_t tot[2][2], acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { tot[mi][ni][i] = 0.f; acc[mi][ni][i] = 0.f; }
+
+    const int nk = K / 64, per_quarter = nk / 4;
+    G128_GLOAD(0)
+    G128_LWRITE(0)
+    __syncthreads();
+    int in_quarter = 0;
+    for (int c = 0; c < nk; ++c) {
+        // unconditional (the last iteration re-loads its own slice into the idle buffer): no control flow around the
+        // register staging
+        if (DBG != 1) { G128_GLOAD(min(c + 1, nk - 1) * 64) }
+        const bf16_t* A = lds + (c & 1) * (256 * G128_LD) + (wm * 64 + r) * G128_LD;
+        const bf16_t* B = lds + (c & 1) * (256 * G128_LD) + (128 + wn * 64 + r) * G128_LD;
+#pragma unroll
+        for (int q = 0; q < (DBG == 2 ? 0 : 4); ++q) {
+            const int so = ((4 * h + q) ^ sw) * 8;
+            const u32x4_t a0 = *reinterpret_cast<const u32x4_t*>(A + so);
+            const u32x4_t a1 = *reinterpret_cast<const u32x4_t*>(A + 32 * G128_LD + so);
+            const u32x4_t b0 = *reinterpret_cast<const u32x4_t*>(B + so);
+            const u32x4_t b1 = *reinterpret_cast<const u32x4_t*>(B + 32 * G128_LD + so);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(b0), acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(b1), acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(b0), acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(b1), acc[1][1], 0, 0, 0);
+        }
+        if (++in_quarter == per_quarter) {                 // end of a K quarter: fold the partial, restart the chain
+            in_quarter = 0;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { tot[mi][ni][i] += acc[mi][ni][i]; acc[mi][ni][i] = 0.f; }
+        }
+        G128_LWRITE((c + 1) & 1)
+        __syncthreads();
+    }
+    // epilogue: acc register i of lane (r, h) is row 8 (i / 4) + 4 h + (i % 4), column r of its 32 x 32 tile
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < (EPI == EPI_SWIGLU ? 1 : 2); ++ni) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + wm * 64 + mi * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+                if (EPI == EPI_SWIGLU) mm_finish<EPI, HD>(a, m, n0 + wn * 32 + r, tot[mi][0][i], tot[mi][1][i]);
+                else mm_finish<EPI, HD>(a, m, n0 + wn * 64 + ni * 32 + r, tot[mi][ni][i], 0.f);
+            }
+        }
+    }
+}
+#undef G128_GLOAD
+#undef G128_LWRITE

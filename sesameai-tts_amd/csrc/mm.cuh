@@ -111,14 +111,64 @@ __global__ void k_pack_w(const bf16_t* w, int N, int K, bf16_t* wt) {
     reinterpret_cast<uint4*>(wt)[piece] = v;
 }
 
+// Epilogue of one output element (row m, column n) of the wide-M kernels; s0 = fp32 dot product (s1 = the
+// up-projection's for SwiGLU).  Same rounding points as the GEMV path.  QKV: every lane of the wave must call
+// this together (the RoPE partner column n^1 sits in the neighbouring lane).
+template <int EPI, int HD>
+__device__ __forceinline__ void mm_finish(const GemvArgs& a, const int m, const int n, const float s0, const float s1) {
+#pragma clang fp contract(off)
+    float y = round_bf(s0);
+    if (EPI == EPI_QKV_ROPE) {
+        const float other = __shfl_xor(y, 1, WAVE);
+        if (m < a.M && n < a.N) {
+            const int p = row_pos(a, m);
+            const int b = m / a.rows_per_seq;
+            if (n < a.nq + a.nkv) {
+                const int e = (n < a.nq ? n : n - a.nq) % HD;
+                const uint32_t cs = reinterpret_cast<const uint32_t*>(a.rope)[(long)p * (HD / 2) + e / 2];
+                const float c = lo2f(cs), s = hi2f(cs);
+                y = (n & 1) ? (y * c + other * s) : (y * c - other * s);
+            }
+            if (n < a.nq) a.out[(long)m * a.ldo + n] = f2bf(y);
+            else {
+                const bool isk = n < a.nq + a.nkv;
+                const int rk = n - a.nq - (isk ? 0 : a.nkv);
+                (isk ? a.kcache : a.vcache)[(((long)b * a.kv_heads + rk / HD) * a.smax + p) * HD + rk % HD] = f2bf(y);
+            }
+        }
+    } else if (m < a.M && n < a.N) {
+        if (EPI == EPI_SWIGLU) {
+            const float u = round_bf(s1);
+            const float sg = round_bf(y / (1.0f + __expf(-y)));
+            y = sg * u;
+        } else if (EPI == EPI_RESID) {
+            y = y + bf2f(a.resid[(long)m * a.ldo + n]);
+        }
+        a.out[(long)m * a.ldo + n] = f2bf(y);
+    }
+}
+
 // GemvArgs is reused: x (row stride x_row_stride), M, w0/w1/w2, N, out/ldo, resid, QKV fields.
 // K is a runtime argument (multiple of 64 * NW).  NW = waves per block = K split (4, or 16 for the
 // K = 8192 down projections so that a 32-row stripe of a 16 MB matrix is pulled by 16 waves).
+//
+// Tile mapping.  mt8 == 0: grid (n tiles, row tiles, K groups) -- decode steps, a handful of row tiles.
+// mt8 > 0 (prompts, M >= 256): 1-D grid, XCD-aware.  Workgroups are placed round-robin over the 8 XCDs, each with
+// its own 4 MB L2, so block L runs on XCD L % 8.  XCD c owns the row tiles {c, c+8, ...} (mt8 of them): its share of
+// x (M/8 rows) stays L2-resident, and consecutive blocks of one XCD walk those row tiles for ONE n tile, so a
+// weight tile is fetched from HBM once per XCD instead of once per row tile.
 template <int EPI, int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K) {
+__global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K, const int mt8, const int kgroups) {
     __shared__ float red[EPI == EPI_SWIGLU ? 2 : 1][NW][16][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    int n0, m0, kz;
+    if (mt8 == 0) { n0 = blockIdx.x * 32; m0 = blockIdx.y * 32; kz = blockIdx.z; }
+    else {
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        const int rest = j / mt8, mt = (j % mt8) * 8 + xcd;
+        if (mt * 32 >= a.M) return;
+        kz = rest % kgroups; n0 = (rest / kgroups) * 32; m0 = mt * 32;
+    }
     const int mrow = min(m0 + r, a.M - 1);
     // w0/w1/w2 are PACKED (k_pack_w): tile pointer = base + ntile * (K/64) * 4 KB; a wave-level load of
     // step q in chunk c is the contiguous 1 KB at  tile + ((c*4 + q)*64 + lane) * 16 bytes
@@ -135,8 +185,8 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K)
     }
     const bf16_t* xa = a.x + (long)mrow * a.x_row_stride + a.x_row_offset;
     // EPI_SLAB: gridDim.z blocks split K further; each writes its fp32 partial tile to slab[blockIdx.z]
-    const int kblk = K / gridDim.z;
-    const int kspan = kblk / NW, kbeg = blockIdx.z * kblk + wave * kspan, kend = kbeg + kspan;
+    const int kblk = K / kgroups;
+    const int kspan = kblk / NW, kbeg = kz * kblk + wave * kspan, kend = kbeg + kspan;
     f32x16_t acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
@@ -217,42 +267,15 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K)
 #pragma unroll
             for (int w = 0; w < NW; ++w) s0 += red[0][w][reg][lane];       // fixed order: deterministic
             if (EPI == EPI_SLAB) {
-                if (m < a.M && n < a.N) a.slab[((long)blockIdx.z * a.M + m) * a.N + n] = s0;
+                if (m < a.M && n < a.N) a.slab[((long)kz * a.M + m) * a.N + n] = s0;
                 continue;
             }
-            float y = round_bf(s0);
-            if (EPI == EPI_QKV_ROPE) {
-                // partner column n^1 lives in the neighbouring lane; every lane must take part in the shuffle
-                const float other = __shfl_xor(y, 1, WAVE);
-                if (m < a.M && n < a.N) {
-                    const int p = row_pos(a, m);
-                    const int b = m / a.rows_per_seq;
-                    if (n < a.nq + a.nkv) {
-                        const int e = (n < a.nq ? n : n - a.nq) % HD;
-                        const uint32_t cs = reinterpret_cast<const uint32_t*>(a.rope)[(long)p * (HD / 2) + e / 2];
-                        const float c = lo2f(cs), s = hi2f(cs);
-                        y = (n & 1) ? (y * c + other * s) : (y * c - other * s);
-                    }
-                    if (n < a.nq) a.out[(long)m * a.ldo + n] = f2bf(y);
-                    else {
-                        const bool isk = n < a.nq + a.nkv;
-                        const int rk = n - a.nq - (isk ? 0 : a.nkv);
-                        (isk ? a.kcache : a.vcache)[(((long)b * a.kv_heads + rk / HD) * a.smax + p) * HD + rk % HD] = f2bf(y);
-                    }
-                }
-            } else if (m < a.M && n < a.N) {
-                if (EPI == EPI_SWIGLU) {
-                    float s1 = 0.f;
+            float s1 = 0.f;
+            if (EPI == EPI_SWIGLU) {
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) s1 += red[1][w][reg][lane];
-                    const float u = round_bf(s1);
-                    const float sg = round_bf(y / (1.0f + __expf(-y)));
-                    y = sg * u;
-                } else if (EPI == EPI_RESID) {
-                    y = y + bf2f(a.resid[(long)m * a.ldo + n]);
-                }
-                a.out[(long)m * a.ldo + n] = f2bf(y);
+                for (int w = 0; w < NW; ++w) s1 += red[1][w][reg][lane];
             }
+            mm_finish<EPI, HD>(a, m, n, s0, s1);
         }
     }
 }

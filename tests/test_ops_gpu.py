@@ -158,6 +158,44 @@ def test_wide_mfma_path(abi, M):
     assert_bf16_close(vc[0, :, 3:3 + M].transpose(0, 1), v[0], abs_floor=5e-5, what="mfma v cache")
 
 
+@pytest.mark.parametrize("M,K,hd", [(200, 1024, 128), (513, 2048, 64), (130, 512, 64), (129, 8192, 64)])
+def test_gemm128_equals_mm32_bitwise(abi, M, K, hd):
+    """The 128 x 128 LDS-tiled kernel of long prompts (kinds 20+) must give the SAME BITS as the 32 x 32 kernel
+    (kinds 10+): same MFMA k-mapping, same chain order, same association of the four K-quarter partials.  That is
+    what keeps a prompt row independent of how many rows share its prefill call (prefix-KV reuse)."""
+    from oracle.csm_ref import LlamaShape, rope_table
+    g = torch.Generator().manual_seed(M + K)
+    H, KV, smax = (8, 2, 640) if hd == 128 else (16, 4, 640)
+    x = dev(rnd((M, K), g))
+    w = dev(rnd((2051, K), g, 0.02))
+    o1 = torch.zeros(M, 2560, dtype=torch.bfloat16, device="cuda"); o2 = torch.zeros_like(o1)
+    op_gemv(abi, 10, x, w, out=o1, ldo=2560); op_gemv(abi, 20, x, w, out=o2, ldo=2560)
+    assert torch.equal(o1, o2), "linear"
+    assert_bf16_close(o2[:, :2051], F.linear(x.cpu(), w.cpu()), abs_floor=2e-4, what="gemm128 linear vs oracle")
+    r = rnd((M, 2051), g)
+    r1, r2 = dev(r), dev(r)
+    op_gemv(abi, 11, x, w, out=r1, resid=r1); op_gemv(abi, 21, x, w, out=r2, resid=r2)
+    assert torch.equal(r1, r2), "linear + residual"
+    ffn = 1088                                                     # not a multiple of 64: exercises the column tail
+    w1, w3 = dev(rnd((ffn, K), g, 0.05)), dev(rnd((ffn, K), g, 0.05))
+    a1 = torch.zeros(M, ffn, dtype=torch.bfloat16, device="cuda"); a2 = torch.zeros_like(a1)
+    op_gemv(abi, 14, x, w1, w1=w3, out=a1, N=ffn); op_gemv(abi, 24, x, w1, w1=w3, out=a2, N=ffn)
+    assert torch.equal(a1, a2), "swiglu"
+    table = dev(rope_table(LlamaShape(1, H, KV, H * hd, 1024, max_seq_len=smax)))
+    wq, wk, wv = dev(rnd((H * hd, K), g, 0.02)), dev(rnd((KV * hd, K), g, 0.02)), dev(rnd((KV * hd, K), g, 0.02))
+    pos = dev(torch.arange(5, 5 + M), torch.int32)
+    outs = []
+    for kind in (13, 23):
+        q = torch.zeros(M, H * hd, dtype=torch.bfloat16, device="cuda")
+        kc = torch.zeros(1, KV, smax, hd, dtype=torch.bfloat16, device="cuda"); vc = torch.zeros_like(kc)
+        op_gemv(abi, kind, x, wq, w1=wk, w2=wv, out=q, ldo=H * hd, N=(H + 2 * KV) * hd, head_dim=hd, nq=H * hd,
+                nkv=KV * hd, kv_heads=KV, smax=smax, rows_per_seq=M, pos=pos, rope=table, kcache=kc, vcache=vc)
+        outs.append((q, kc, vc))
+    for t1, t2, what in zip(outs[0], outs[1], ("q", "k cache", "v cache")):
+        assert torch.equal(t1, t2), what
+    assert outs[1][1].abs().sum() > 0
+
+
 @pytest.mark.parametrize("H,KV,hd,nsplit", [(32, 8, 64, 1), (32, 8, 64, 8), (8, 2, 128, 1), (8, 2, 128, 3)])
 def test_attention(abi, H, KV, hd, nsplit):
     g = torch.Generator().manual_seed(H + hd + nsplit)

@@ -37,10 +37,10 @@ int main() {
             a.out = (i & 1) ? x : y; a.ldo = c.kind == 4 ? c.Nn : (c.Nn + 31) / 32 * 32; a.resid = a.out;
             dim3 grid((c.Nn + 31) / 32, 1, c.kg);
             a.slab = slab;
-            if (c.kind == 5) { hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4>), grid, dim3(256), 0, st, a, c.K); continue; }
-            if (c.kind == 4) hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4>), grid, dim3(256), 0, st, a, c.K);
-            else if (c.kind == 1) hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4>), grid, dim3(256), 0, st, a, c.K);
-            else hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4>), grid, dim3(256), 0, st, a, c.K);
+            if (c.kind == 5) { hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4>), grid, dim3(256), 0, st, a, c.K, 0, c.kg); continue; }
+            if (c.kind == 4) hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4>), grid, dim3(256), 0, st, a, c.K, 0, 1);
+            else if (c.kind == 1) hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4>), grid, dim3(256), 0, st, a, c.K, 0, 1);
+            else hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4>), grid, dim3(256), 0, st, a, c.K, 0, 1);
         }
         CK(hipStreamEndCapture(st, &g));
         CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
