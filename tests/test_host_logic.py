@@ -159,3 +159,14 @@ def test_wav_loading_mono_and_resample(tmp_path):
     assert x.dim() == 1 and abs(x.shape[0] - 12000) <= 1 and x.dtype == torch.float32
     want = 0.375 * np.sin(2 * np.pi * 440 * np.arange(x.shape[0]) / 24000)
     assert np.abs(x.numpy()[200:-200] - want[200:-200]).max() < 5e-3
+
+
+def test_watermark_hook_passes_audio_through_without_silentcipher():
+    """reference tts_service.py:23 imports these names from sesameai.watermarking; without the third-party model the
+    hook must be a no-op, not an ImportError."""
+    from sesameai.watermarking import CSM_1B_GH_WATERMARK, load_watermarker, verify, watermark
+    wm = load_watermarker("cpu")
+    x = torch.linspace(-1, 1, 2400)
+    if wm is None:
+        y, sr = watermark(wm, x, 24000, CSM_1B_GH_WATERMARK)
+        assert sr == 24000 and torch.equal(x, y) and verify(wm, y, sr, CSM_1B_GH_WATERMARK) is False

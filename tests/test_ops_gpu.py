@@ -303,6 +303,38 @@ def test_sampler_golden(abi):
         assert (frame[:, :7] == -1).all() and (frame[:, 8:] == -1).all()
 
 
+@pytest.mark.parametrize("V", [2051, 1000])
+def test_sampler_random_parameters_vs_oracle(abi, V):
+    """Random (temperature, top-k) pairs, logits on a coarse bf16 grid (many exact ties at the kth value): the HIP
+    sampler must pick the oracle's index given the oracle's Exp(1) noise.  Integer-exact except where one
+    probability sits within a bf16 ulp of the decision (fp32 order of <= k exp-sums), as in the golden cases."""
+    from oracle.csm_ref import sample_topk
+    g = torch.Generator().manual_seed(V)
+    B, ldl = 64, 2560
+    total, agree = 0, 0
+    for case in range(24):
+        T = float(torch.empty(1).uniform_(0.2, 1.6, generator=g))
+        k = int(torch.randint(1, 120, (1,), generator=g)) if case else V           # case 0: top-k = V (nothing removed)
+        scale = (0.5, 1.0, 3.0)[case % 3]
+        logits = (torch.randn(B, V, generator=g) * scale).to(torch.bfloat16)
+        if case % 4 == 1:
+            logits = (logits.float() * 4).round().div(4).to(torch.bfloat16)            # quarter-steps: ties everywhere
+        noise = torch.empty(B, V).exponential_(1, generator=g).to(torch.bfloat16).clamp_min(1e-30)
+        want = sample_topk(logits, k, T, q=noise)[:, 0]
+        lg = torch.full((B, ldl), 99.0, dtype=torch.bfloat16); lg[:, :V] = logits
+        lgd, nd = dev(lg), dev(noise)
+        frame = torch.full((B, 32), -1, dtype=torch.int32, device="cuda")
+        _ck(abi, abi.lib.csm_op_sample(B, V, ldl, lgd.data_ptr(), T, k, nd.data_ptr(), None, 3, 32, frame.data_ptr(), stream()))
+        torch.cuda.synchronize()
+        got = frame[:, 3].cpu()
+        assert int(got.min()) >= 0 and int(got.max()) < V
+        # every pick must at least be a kept (top-k) index
+        kth = torch.topk((logits / T), k)[0][:, -1]
+        assert bool(((logits / T)[torch.arange(B), got.long()] >= kth).all()), f"case {case}: picked a removed index"
+        total += B; agree += int((got == want).sum())
+    assert agree / total >= 0.95, f"agreement {agree / total:.3f}"
+
+
 def test_sampler_philox_distribution(abi):
     """without supplied noise the on-device Philox Exp(1) draws must reproduce the softmax
     distribution of the kept logits (statistical parity)."""
