@@ -60,6 +60,7 @@ class Generator:
         self.device = model.device
         self._stream_buffer_size = 10          # generator.py:61
         self._eos_poll = 8                     # frames launched between EOS polls
+        self._mimi_stream = None               # side HIP stream for Mimi in generate_stream
 
     # -- prompt assembly (generator.py:63-109) ------------------------------------------------
     def _text_ids(self, text: Union[str, Sequence[int]], speaker: int) -> List[int]:
@@ -109,46 +110,62 @@ class Generator:
         return torch.cat(toks, 0).long().to(self.device), torch.cat(masks, 0).bool().to(self.device)
 
     # -- the frame loop -----------------------------------------------------------------------
+    def _frame_blocks(self, prompt_tokens: torch.Tensor, prompt_mask: torch.Tensor, max_generation_len: int,
+                      temperature: float, topk: int, poll: int) -> PyGenerator[torch.Tensor, None, None]:
+        """Yields the generated frames in blocks [n][B][32] int32 (CPU) of about ``poll`` frames, cut at EOS for
+        B == 1.  The NEXT block's frame steps are already enqueued on the GPU when a block is yielded, so whatever
+        the consumer does with it (Mimi decode on another stream, playback) overlaps the language model."""
+        B = prompt_tokens.shape[0]
+        m = self._model
+        m.reset_caches()
+        self.last_eos_at = torch.full((B,), -1, dtype=torch.int32)
+        if max_generation_len <= 0:
+            return
+        m.prefill_prompt(prompt_tokens, prompt_mask)        # reuses the cached KV of a shared voice-prompt prefix
+        m.depth(B, temperature, topk, commit=True)
+        launched, delivered = 1, 0
+
+        def enqueue() -> int:
+            n = min(poll, max_generation_len - launched)
+            for _ in range(n):
+                m.step(B, temperature, topk)
+            return n
+
+        launched += enqueue()
+        while True:
+            upto = launched
+            fr, eos = m.read_frames(B, delivered, upto - delivered)          # waits for the frames launched so far
+            self.last_eos_at = eos
+            done = bool((eos >= 0).all()) or launched >= max_generation_len
+            if not done:
+                launched += enqueue()                                       # keep the GPU busy before handing out
+            if B == 1 and eos[0] >= 0:
+                fr = fr[: max(int(eos[0]) - delivered, 0)]
+            delivered = upto
+            if fr.shape[0]:
+                yield fr
+            if done:
+                return
+
     @torch.inference_mode()
     def generate_codes(self, prompt_tokens: torch.Tensor, prompt_mask: torch.Tensor, max_generation_len: int,
                        temperature: float, topk: int, on_frames: Optional[Callable[[torch.Tensor], None]] = None,
                        poll: Optional[int] = None) -> torch.Tensor:
         """prompt (S,33) or (B,S,33) -> frames [n][B][32] int32 (CPU), cut at each sequence's EOS
         for B == 1 (the reference is batch-1: generator.py:47).  For B > 1 all sequences run
-        ``max_generation_len`` frames unless every one hit EOS; the caller trims with eos_at."""
+        ``max_generation_len`` frames unless every one hit EOS; the caller trims with ``last_eos_at``."""
         if prompt_tokens.dim() == 2:
             prompt_tokens, prompt_mask = prompt_tokens.unsqueeze(0), prompt_mask.unsqueeze(0)
         B, S, _ = prompt_tokens.shape
         max_context_len = MAX_SEQ_LEN - max_generation_len
         if S >= max_context_len:
             raise ValueError(f"Inputs too long, must be below max_seq_len - max_generation_len: {max_context_len}")
-        m = self._model
-        m.reset_caches()
-        if max_generation_len <= 0:
-            return torch.empty(0, B, 32, dtype=torch.int32)
-        m.prefill_prompt(prompt_tokens, prompt_mask)        # reuses the cached KV of a shared voice-prompt prefix
-        m.depth(B, temperature, topk, commit=True)
-        poll = poll or self._eos_poll
-        done, launched, delivered = False, 1, 0
-        while not done:
-            n = min(poll, max_generation_len - launched)
-            for _ in range(n):
-                m.step(B, temperature, topk)
-            launched += n
-            _, eos = m.read_frames(B, 0, 0)
-            if bool((eos >= 0).all()) or launched >= max_generation_len:
-                done = True
+        blocks = []
+        for fr in self._frame_blocks(prompt_tokens, prompt_mask, max_generation_len, temperature, topk, poll or self._eos_poll):
             if on_frames is not None:
-                upto = launched if not (B == 1 and eos[0] >= 0) else int(eos[0])
-                if upto > delivered:
-                    fr, _ = m.read_frames(B, delivered, upto - delivered)
-                    on_frames(fr)
-                    delivered = upto
-        frames, eos = m.read_frames(B, 0, launched)
-        self.last_eos_at = eos
-        if B == 1 and eos[0] >= 0:
-            frames = frames[: int(eos[0])]
-        return frames
+                on_frames(fr)
+            blocks.append(fr)
+        return torch.cat(blocks) if blocks else torch.empty(0, B, 32, dtype=torch.int32)
 
     def _decode_frames(self, frames: torch.Tensor) -> torch.Tensor:
         """frames [n][1][32] -> audio (n*1920,) (reference: _decode_frames, generator.py:111-117)."""
@@ -159,33 +176,50 @@ class Generator:
         codes = frames.to(self.device).permute(1, 2, 0).contiguous()          # (B, 32, T)
         return self._audio_tokenizer.decode(codes).squeeze(0).squeeze(0)
 
-    @torch.inference_mode()
     def generate_stream(self, text, speaker: int, context: List[Segment], max_audio_length_ms: float = 90_000,
                         temperature: float = 0.7, topk: int = 30,
                         on_chunk_generated: Optional[Callable[[torch.Tensor], None]] = None
                         ) -> PyGenerator[torch.Tensor, None, None]:
-        """reference: generator.py:119-210 -- yields audio every ``_stream_buffer_size`` frames,
-        each buffer decoded statelessly like the reference."""
+        """reference: generator.py:119-210 -- yields audio every ``_stream_buffer_size`` frames as soon as it exists,
+        each buffer decoded statelessly like the reference.  Mimi runs on its own HIP stream while the frame steps
+        of the next buffer (already enqueued) run on the caller's stream."""
         max_generation_len = int(max_audio_length_ms / FRAME_MS)
-        tokens, mask = self._build_prompt(text, speaker, context)
+        with torch.inference_mode():
+            tokens, mask = self._build_prompt(text, speaker, context)
+        if tokens.dim() == 2:
+            tokens, mask = tokens.unsqueeze(0), mask.unsqueeze(0)
+        if tokens.shape[1] >= MAX_SEQ_LEN - max_generation_len:
+            raise ValueError(f"Inputs too long, must be below max_seq_len - max_generation_len: {MAX_SEQ_LEN - max_generation_len}")
+        if getattr(self, "_mimi_stream", None) is None:
+            self._mimi_stream = torch.cuda.Stream(device=self.device)
+        side = self._mimi_stream
         pending: List[torch.Tensor] = []
-        chunks: List[torch.Tensor] = []
+        size = self._stream_buffer_size
 
-        def on_frames(fr: torch.Tensor) -> None:
+        def decode(n: int) -> torch.Tensor:
+            buf = torch.stack(pending[:n]); del pending[:n]
+            with torch.inference_mode(), torch.cuda.stream(side):
+                pcm = self._decode_frames(buf)
+            side.synchronize()
+            return pcm
+
+        blocks = self._frame_blocks(tokens, mask, max_generation_len, temperature, topk, size)
+        while True:
+            with torch.inference_mode():
+                fr = next(blocks, None)
+            if fr is None:
+                break
             pending.extend(fr.unbind(0))
-            while len(pending) >= self._stream_buffer_size:
-                buf = torch.stack(pending[: self._stream_buffer_size]); del pending[: self._stream_buffer_size]
-                chunks.append(self._decode_frames(buf))
-
-        # frames are produced in polls of _stream_buffer_size so chunks flow as they complete
-        self.generate_codes(tokens, mask, max_generation_len, temperature, topk, on_frames=on_frames,
-                            poll=self._stream_buffer_size)
+            while len(pending) >= size:
+                chunk = decode(size)
+                if on_chunk_generated:
+                    on_chunk_generated(chunk)
+                yield chunk
         if pending:
-            chunks.append(self._decode_frames(torch.stack(pending)))
-        for c in chunks:
+            chunk = decode(len(pending))
             if on_chunk_generated:
-                on_chunk_generated(c)
-            yield c
+                on_chunk_generated(chunk)
+            yield chunk
 
     @torch.inference_mode()
     def generate(self, text, speaker: int, context: List[Segment], max_audio_length_ms: float = 90_000,

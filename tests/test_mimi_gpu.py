@@ -151,5 +151,19 @@ def test_generator_end_to_end_tiny(tiny_codec):
     # same seed -> same codes; first chunk of the stream == first 10 frames decoded statelessly
     first = codec.decode(gen._model.read_frames(1)[0][:10].permute(1, 2, 0).contiguous())
     assert torch.allclose(chunks[0], first.reshape(-1).to(chunks[0].device))
+    # it streams: the first buffer is handed out while later frames are still being generated, and the chunks of a
+    # seeded run equal the one-shot generation decoded in stateless 10-frame buffers
+    model.seed(5)
+    it = gen.generate_stream(text, 1, ctx, max_audio_length_ms=2400, temperature=0.9, topk=50)
+    c0 = next(it)
+    assert gen._model.num_frames() < 30, "generate_stream produced everything before yielding its first chunk"
+    rest = list(it)
+    assert c0.shape[0] == 19200 and [c.shape[0] for c in rest] == [19200, 19200]
+    frames = gen._model.read_frames(1)[0]
+    assert frames.shape[0] == 30
+    want = codec.decode(frames[10:20].permute(1, 2, 0).contiguous()).reshape(-1)
+    assert torch.allclose(rest[0], want.to(rest[0].device))
     with pytest.raises(ValueError, match="Inputs too long"):
         gen.generate(list(range(300)), 1, [], max_audio_length_ms=150_000)
+    with pytest.raises(ValueError, match="Inputs too long"):
+        next(gen.generate_stream(list(range(300)), 1, [], max_audio_length_ms=150_000))
