@@ -282,6 +282,29 @@ def main():
                 "ms_per_10_frame_chunk": round(stream_ms / max((T + 9) // 10, 1), 3),
                 "end_to_end_ms": round(gen_ms + whole_ms, 2),
                 "end_to_end_rtf": round(T * 80.0 / (gen_ms + whole_ms), 2)}
+        # streaming surface end to end (Generator.generate_stream: prompt prefill -> frames -> Mimi on a side stream),
+        # same prompt shape; time to the first 10-frame chunk and whole-utterance wall time
+        if B == 1:
+            from sesameai.generator import Generator, Segment
+            gen = Generator(model, audio_tokenizer=codec)
+            gq = torch.Generator().manual_seed(99)
+            ctx = [Segment(speaker=1, text=torch.randint(0, margs.text_vocab_size, (args.ctx_text,), generator=gq).tolist(),
+                           audio_codes=torch.randint(0, 2048, (32, args.ctx_frames), generator=gq))]
+            text = torch.randint(0, margs.text_vocab_size, (args.gen_text,), generator=gq).tolist()
+            model.prefix_reuse = False
+            for rep in range(2):                                   # rep 0 warms the hipGraph of this (T, top-k)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                first_ms, n_samples = None, 0
+                for chunk in gen.generate_stream(text, 1, ctx, max_audio_length_ms=args.steps * 80.0,
+                                                 temperature=args.temperature, topk=args.topk):
+                    if first_ms is None:
+                        first_ms = (time.perf_counter() - t0) * 1e3
+                    n_samples += chunk.shape[0]
+                torch.cuda.synchronize()
+                total_ms = (time.perf_counter() - t0) * 1e3
+            mimi["stream"] = {"frames": n_samples // 1920, "first_chunk_ms": round(first_ms, 2), "wall_ms": round(total_ms, 2),
+                              "rtf": round(n_samples / 24.0 / total_ms, 2)}
         log(f"mimi: {mimi}")
         del codec
 

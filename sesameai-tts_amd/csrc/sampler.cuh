@@ -85,6 +85,11 @@ struct SampleArgs {
     float xn_eps;
     bf16_t* xn_out;           // row b at xn_out + b*xn_stride
     long xn_stride;
+    // optional: layer-0 q | k | v of the next decoder step, one table row per token of this codebook (csm_engine.hip,
+    // build_qkv0_table): q -> q_out row b, k/v -> the decoder's layer-0 cache of sequence b at next_pos
+    const bf16_t* qkv0;       // [audio_vocab][nq + 2 nkv]
+    int nq, nkv, kv_heads, smax, hd, next_pos;
+    bf16_t *q_out, *k0, *v0;
 };
 
 __device__ __forceinline__ uint32_t order_key(float t) {     // monotone map of a bf16-valued float
@@ -302,6 +307,19 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
         for (int c = tid; c < a.d / 8; c += 256) dst[c] = src[c];
         if (a.xn_out && wave == 0)
             rmsnorm_row_wave(reinterpret_cast<const bf16_t*>(src), a.d, a.xn_scale, a.xn_eps, a.xn_out + (long)b * a.xn_stride, lane);
+        if (a.qkv0) {
+            const int ld = a.nq + 2 * a.nkv, per_head = a.hd / 8;
+            const uint4* row = reinterpret_cast<const uint4*>(a.qkv0 + (long)fed * ld);
+            for (int c = tid; c < ld / 8; c += 256) {
+                const uint4 v = row[c];
+                if (c < a.nq / 8) reinterpret_cast<uint4*>(a.q_out + (long)b * a.nq)[c] = v;
+                else {
+                    const int ck = c - a.nq / 8, isv = ck >= a.nkv / 8, cc = isv ? ck - a.nkv / 8 : ck;
+                    bf16_t* dstc = (isv ? a.v0 : a.k0) + (((long)b * a.kv_heads + cc / per_head) * a.smax + a.next_pos) * a.hd;
+                    reinterpret_cast<uint4*>(dstc)[cc % per_head] = v;
+                }
+            }
+        }
     }
 }
 

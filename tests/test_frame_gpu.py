@@ -428,3 +428,35 @@ def test_long_prompt_kernel_keeps_rows_independent_of_row_count():
         res.append((logits.cpu(), frames))
     assert torch.equal(res[0][0][:, :4], res[1][0]), "logits differ between the 600-row and the 480-row prefill"
     assert torch.equal(res[0][1][:, :4], res[1][1])
+
+
+def test_layer0_qkv_table_gives_the_same_bits_as_computing_it(monkeypatch):
+    """The depth decoder's layer-0 q/k/v of steps >= 2 come from a table precomputed with the production kernel
+    (csm_engine.hip build_qkv0_table); CSM_QKV0_TABLE=0 computes them per step.  Same logits, same frames, bit for bit,
+    for B = 1 and B = 2 (the GEMV path)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sesameai.models import Model, csm_tiny_args, synthetic_state_dict
+    sd = synthetic_state_dict(csm_tiny_args(), seed=1234)
+    g = torch.Generator().manual_seed(3)
+    S = 12
+    tok = torch.zeros(2, S, 33, dtype=torch.long); msk = torch.zeros(2, S, 33, dtype=torch.bool)
+    tok[:, :5, 32] = torch.randint(0, 1000, (2, 5), generator=g); msk[:, :5, 32] = True
+    tok[:, 5:, :32] = torch.randint(0, 2048, (2, S - 5, 32), generator=g); msk[:, 5:, :32] = True
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CSM_QKV0_TABLE", flag)
+        m = Model(csm_tiny_args(), sd, max_frames=16, max_prefill_rows=64)
+        m.setup_caches(2)
+        out = []
+        for B in (1, 2):
+            m.reset_caches(); m.seed(11)
+            m.prefill(tok[:B], msk[:B], torch.arange(S).unsqueeze(0).repeat(B, 1))
+            _, logits = m.depth(B, 0.9, 50, want_logits=True, commit=True)
+            for _ in range(3):
+                m.step(B, 0.9, 50)
+            out.append((logits.cpu(), m.read_frames(B)[0]))
+        res[flag] = out
+        del m
+    for (l1, f1), (l0, f0) in zip(res["1"], res["0"]):
+        assert torch.equal(l1, l0) and torch.equal(f1, f0)
