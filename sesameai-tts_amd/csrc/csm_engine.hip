@@ -268,7 +268,7 @@ struct FinalNorm { const bf16_t* scale; bf16_t* out; long out_stride; };
 
 static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t* att, bf16_t* act,
                                  int M, int rows_per_seq, const int* pos, hipStream_t st, bool prompt, const FinalNorm& fin,
-                                 bool x_normed) {
+                                 bool x_normed, bool qkv0_done) {
     // unfused wide-M layer: norm -> MFMA qkv(+rope, KV append) -> attention -> MFMA o-proj(+res) ->
     // norm -> MFMA gate/up(SiLU*up) -> MFMA down(+res).  `att` doubles as the normalised-activation buffer.
     const int d = S.d.dim;
@@ -314,15 +314,18 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
             }
             continue;
         }
-        // layer 0 normalises h directly; later layers got xn from the previous down-projection's finisher
-        if (l == 0 && !x_normed && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
-        memset(&a, 0, sizeof a);
-        a.x = att; a.x_row_stride = d; a.M = M;
-        a.w0 = (const bf16_t*)pk.wq; a.w1 = (const bf16_t*)pk.wk; a.w2 = (const bf16_t*)pk.wv;
-        a.N = S.nq + 2 * S.nkv; a.out = q; a.ldo = S.nq;
-        a.nq = S.nq; a.nkv = S.nkv; a.smax = S.cache_len; a.rows_per_seq = rows_per_seq; a.kv_heads = S.d.n_kv_heads;
-        a.pos = pos; a.rope = S.rope; a.kcache = kc; a.vcache = vc;
-        if ((e = launch_mm(3, d, S.hd, a, st)) != hipSuccess) return e;
+        // layer 0 normalises h directly; later layers got xn from the previous down-projection's finisher.
+        // (layer 0 of a depth-decoder step >= 2: q/k/v were gathered from the precomputed table by the sampler)
+        if (!(l == 0 && qkv0_done)) {
+            if (l == 0 && !x_normed && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+            memset(&a, 0, sizeof a);
+            a.x = att; a.x_row_stride = d; a.M = M;
+            a.w0 = (const bf16_t*)pk.wq; a.w1 = (const bf16_t*)pk.wk; a.w2 = (const bf16_t*)pk.wv;
+            a.N = S.nq + 2 * S.nkv; a.out = q; a.ldo = S.nq;
+            a.nq = S.nq; a.nkv = S.nkv; a.smax = S.cache_len; a.rows_per_seq = rows_per_seq; a.kv_heads = S.d.n_kv_heads;
+            a.pos = pos; a.rope = S.rope; a.kcache = kc; a.vcache = vc;
+            if ((e = launch_mm(3, d, S.hd, a, st)) != hipSuccess) return e;
+        }
         AttnArgs t;
         t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
         t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = 1;
@@ -365,7 +368,7 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
         FinalNorm fin;
         if (&S == &m->bb) { fin.scale = (const bf16_t*)m->w.bb_norm; fin.out = m->dec_in; fin.out_stride = 2L * S.d.dim; }
         else { fin.scale = (const bf16_t*)m->w.dec_norm; fin.out = att; fin.out_stride = S.d.dim; }
-        return run_stack_wide(m, S, h, q, att, act, M, rows_per_seq, pos_arr, st, force_wide, fin, x_normed);
+        return run_stack_wide(m, S, h, q, att, act, M, rows_per_seq, pos_arr, st, force_wide, fin, x_normed, qkv0_done);
     }
     const int* pos = pos_const >= 0 ? nullptr : pos_arr;
     const int pos_base = pos_const >= 0 ? pos_const : 0;
@@ -472,8 +475,8 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             const int* pos = m->dec_pos + (long)(cb == 1 ? 0 : cb) * 2 * m->max_batch;
             // cb >= 2 on the wide path: the previous sampler already wrote sa_norm(row) into attd
             const bool wide_next = B >= m->wide_min && m->wide_path;
-            const bool x_normed = cb >= 2 && wide_next;
-            const bool qkv0_done = cb >= 2 && !wide_next && m->qkv0_tab != nullptr;
+            const bool qkv0_done = cb >= 2 && m->qkv0_tab != nullptr;
+            const bool x_normed = cb >= 2 && wide_next && !qkv0_done;
             if ((e = run_stack(m, m->dec, m->hdec, m->qd, m->attd, m->actd, rows, cb == 1 ? 2 : 1, pos, cb == 1 ? 0 : cb, st, false, x_normed,
                                qkv0_done)) != hipSuccess) return e;
         }
@@ -520,9 +523,9 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
         if (cb == 0) { s.emb_out = m->hdec + dd; s.emb_stride = 2L * dd; }
         else if (cb < ncb - 1) {
             s.emb_out = m->hdec; s.emb_stride = dd;
-            if (B >= m->wide_min && m->wide_path) {       // next decoder step runs wide: hand it layer 0's normalised input too
+            if (m->qkv0_tab == nullptr && B >= m->wide_min && m->wide_path) {   // wide next step without the table: hand it layer 0's normalised input
                 s.xn_scale = (const bf16_t*)m->dec.lw[0].sa_norm; s.xn_eps = c.decoder.norm_eps; s.xn_out = m->attd; s.xn_stride = dd;
-            } else if (m->qkv0_tab) {                     // GEMV path: layer 0's q/k/v of the next step are a table row
+            } else if (m->qkv0_tab) {                     // layer 0's q/k/v of the next step are a table row
                 s.qkv0 = m->qkv0_tab + (long)(cb - 1) * V * (m->dec.nq + 2 * m->dec.nkv);
                 s.nq = m->dec.nq; s.nkv = m->dec.nkv; s.q_out = m->qd; s.k0 = m->dec.kc; s.v0 = m->dec.vc;
                 s.kv_heads = c.decoder.n_kv_heads; s.smax = m->dec.cache_len; s.hd = m->dec.hd; s.next_pos = cb + 1;
