@@ -1,0 +1,157 @@
+// Prompt-prefill attention on the matrix cores (head_dim 64, GQA group of 4): the attention of every PROMPT row.
+//
+// attn.cuh gives each (row, kv head) its own block that walks keys [0, pos]: right for decode steps, but over a
+// prompt every row re-reads its whole key range from L2 (1.8 GB per layer at 1,334 rows, as long as all the
+// prompt's GEMMs together).  Here a block owns 32 consecutive rows of one sequence for one KV head; its four waves
+// are the four query heads of the group and share each 32-key K/V tile through LDS.
+//
+// Per wave, per key tile (all on v_mfma_f32_32x32x16_bf16):
+//   S^T[key][query] = K . Q^T            A = K fragments (ds_read_b128 from a swizzled row-major tile), B = Q (registers)
+//     -> the 32 scores of a query sit in ONE lane pair (lane r: 16 keys, lane r+32: the other 16), so the online
+//        softmax is in-register plus one half-swap; scores, max, exp and the running sum stay fp32
+//   O^T[d][query]  += V^T . P^T          B = P^T = the accumulator registers of S^T, rounded to bf16, with NO lane
+//        movement (an accumulator tile is a valid operand of an MFMA that sums over its row index); A = V^T by
+//        ds_read_b64_tr_b16 transposed reads of the row-major V tile
+// This is the arithmetic of torch's CPU flash kernel that the oracle follows (fp32 scores / softmax, probabilities
+// rounded to bf16 for the P.V product).  A row's result depends only on its own q, position and keys -- not on which
+// rows share its tile or how many key tiles the block walks (a fully masked tile is an exact no-op) -- so prompt rows
+// keep their bits however a prompt is cut into prefill calls (prefix-KV reuse).
+#pragma once
+#include "attn.cuh"
+#include "mm.cuh"
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+#define AF_KLD 64            // K tile row = 64 d (128 B), 16-byte segments XOR-swizzled like gemm128
+#define AF_VLD 96            // V tile row stride 192 B: the 4 rows of a transposed read land on 4 distinct bank quarters
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_flash(const AttnArgs a) {
+    static_assert(HD == 64, "k_attn_flash: head_dim 64");
+    __shared__ __align__(16) bf16_t Ks[2][32 * AF_KLD];
+    __shared__ __align__(16) bf16_t Vs[2][32 * AF_VLD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int kvh = blockIdx.y, G = a.H / a.KV;
+    const int groups = (a.rows_per_seq + 31) / 32;
+    const int b = blockIdx.x / groups, r0 = (blockIdx.x % groups) * 32;
+    const int nr = min(32, a.rows_per_seq - r0);                       // valid query rows of this tile
+    const int m_base = b * a.rows_per_seq + r0;
+    const int mq = m_base + min(r, nr - 1);                            // this lane's query row (padding repeats the last)
+    const int pq = min(max(a.pos[mq], 0), a.smax - 1);
+    const int pmax = (int)wave_max((float)pq);                          // same for the 4 waves (same 32 queries)
+    const int ntiles = pmax / 32 + 1;
+    const bf16_t* kb = a.kcache + ((long)b * a.KV + kvh) * a.smax * HD;
+    const bf16_t* vb = a.vcache + ((long)b * a.KV + kvh) * a.smax * HD;
+
+    // staging: thread t moves segment (t & 7) of key row (t >> 3) of both tiles
+    const int skey = tid >> 3, sseg = tid & 7;
+    u32x4_t kreg, vreg;
+    const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+#define AF_GLOAD(t)                                                                                     \
+    {                                                                                                   \
+        const int j = (t) * 32 + skey;                                                                  \
+        const long off = (long)min(j, pmax) * HD + sseg * 8;                                            \
+        kreg = *reinterpret_cast<const u32x4_t*>(kb + off);                                             \
+        vreg = *reinterpret_cast<const u32x4_t*>(vb + off);                                             \
+        if (j > pmax) { kreg = zero4; vreg = zero4; }   /* never-written cache rows may hold NaN bit patterns */ \
+    }
+#define AF_LWRITE(buf)                                                                                  \
+    {                                                                                                   \
+        *reinterpret_cast<u32x4_t*>(&Ks[buf][skey * AF_KLD + ((sseg ^ ((skey >> 1) & 7)) * 8)]) = kreg; \
+        *reinterpret_cast<u32x4_t*>(&Vs[buf][skey * AF_VLD + sseg * 8]) = vreg;                         \
+    }
+
+    for (int g = wave; g < G; g += 4) {
+        const int hq = kvh * G + g;
+        // Q fragments (B operand): lane (r = query, h) holds q[32h + 8s .. +8] of its row for k-step s = 0..3
+        u32x4_t qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[s] = *reinterpret_cast<const u32x4_t*>(a.q + ((long)mq * a.H + hq) * HD + 32 * h + 8 * s);
+        f32x16_t o0, o1;                                               // O^T rows d = 0..31 / 32..63, column = query
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+        float mrun = -INFINITY, lrun = 0.f;
+
+        __syncthreads();                                               // previous head's readers are done with LDS
+        AF_GLOAD(0)
+        AF_LWRITE(0)
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            AF_GLOAD(min(t + 1, ntiles - 1))                           // in flight while this tile is computed
+            const bf16_t* Kt = Ks[t & 1];
+            const bf16_t* Vt = Vs[t & 1];
+            // ---- S^T = K . Q^T ------------------------------------------------------------------------
+            f32x16_t sacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+            const int sw = (r >> 1) & 7;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(Kt + r * AF_KLD + (((4 * h + s) ^ sw) * 8));
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf), as_bf16x8(qf[s]), sacc, 0, 0, 0);
+            }
+            // ---- online softmax over this lane pair's 32 keys -------------------------------------------
+            float p[16];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int j = t * 32 + 8 * (i >> 2) + 4 * h + (i & 3);  // key of accumulator register i
+                p[i] = (j <= pq) ? sacc[i] * a.scale : -INFINITY;
+                tmax = fmaxf(tmax, p[i]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, WAVE));
+            const float mnew = fmaxf(mrun, tmax);                       // finite: key 0 is visible to every row
+            const float corr = __expf(mrun - mnew);                     // 0 on the first tile
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { p[i] = __expf(p[i] - mnew); psum += p[i]; }
+            psum += __shfl_xor(psum, 32, WAVE);
+            lrun = lrun * corr + psum;
+            mrun = mnew;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= corr; o1[i] *= corr; }
+            // ---- O^T += V^T . P^T ---------------------------------------------------------------------
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                u32x4_t pf;                                             // P^T fragment: registers 8s .. 8s+7 as bf16
+                pf[0] = pack_bf(p[8 * s + 0], p[8 * s + 1]); pf[1] = pack_bf(p[8 * s + 2], p[8 * s + 3]);
+                pf[2] = pack_bf(p[8 * s + 4], p[8 * s + 5]); pf[3] = pack_bf(p[8 * s + 6], p[8 * s + 7]);
+                // V^T fragment of lane (r = d, h): element j <- key 16s + 8(j>>2) + 4h + (j&3): two transposed reads
+                // of 4 keys x 16 d per 16-lane group; lane 4q+p of a group addresses key row q, columns 4p..4p+3
+                const int grp_d = 16 * ((lane >> 4) & 1), qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16_t* base = Vt + (16 * s + 4 * h + qq) * AF_VLD + 32 * dt + grp_d + 4 * pp;
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4_t __attribute__((address_space(3)))*)(base));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4_t __attribute__((address_space(3)))*)(base + 8 * AF_VLD));
+                    u32x4_t vf;
+                    const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+                    vf[0] = l2[0]; vf[1] = l2[1]; vf[2] = h2[0]; vf[3] = h2[1];
+                    if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf), as_bf16x8(pf), o0, 0, 0, 0);
+                    else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf), as_bf16x8(pf), o1, 0, 0, 0);
+                }
+            }
+            AF_LWRITE((t + 1) & 1)
+            __syncthreads();
+        }
+        // ---- out[query][hq][d] = O^T / l: registers 4g4 .. 4g4+3 are 4 consecutive d -> one 8-byte store ---------
+        if (r < nr) {
+            const float inv = 1.0f / lrun;
+            bf16_t* dst = a.out + ((long)(m_base + r) * a.H + hq) * HD;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2_t w0, w1;
+                w0[0] = pack_bf(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv); w0[1] = pack_bf(o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv);
+                w1[0] = pack_bf(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv); w1[1] = pack_bf(o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv);
+                *reinterpret_cast<u32x2_t*>(dst + 8 * g4 + 4 * h) = w0;
+                *reinterpret_cast<u32x2_t*>(dst + 32 + 8 * g4 + 4 * h) = w1;
+            }
+        }
+    }
+#undef AF_GLOAD
+#undef AF_LWRITE
+}

@@ -18,6 +18,7 @@
 #include "gemv.cuh"
 #include "mm.cuh"
 #include "gemm128.cuh"
+#include "attn_flash.cuh"
 #include "sampler.cuh"
 
 #define BB_NSPLIT_MAX 8
@@ -263,6 +264,20 @@ static hipError_t launch_attn(int hd, const AttnArgs& a, hipStream_t st, bool co
 // ---------------------------------------------------------------------------------------
 // one Llama stack over M token rows (in place on h)
 // ---------------------------------------------------------------------------------------
+// prompt rows: matrix-core flash kernel (attn_flash.cuh) where the shape allows, else the per-row kernel.  The choice
+// depends only on the model's shape and on prompt/not-prompt, never on the row count, so a prompt row's bits do not
+// depend on how the prompt was cut into calls.
+#define FLASH_MIN_ROWS 16
+static bool flash_ok(const Stack& S) { return S.hd == 64 && S.d.n_heads % S.d.n_kv_heads == 0; }
+static hipError_t launch_attn_auto(const Stack& S, const AttnArgs& t, bool prompt, hipStream_t st) {
+    if (flash_ok(S) && t.nsplit == 1 && (prompt || t.rows_per_seq >= FLASH_MIN_ROWS)) {
+        dim3 grid((t.M / t.rows_per_seq) * ((t.rows_per_seq + 31) / 32), t.KV);
+        hipLaunchKernelGGL((k_attn_flash<64>), grid, dim3(256), 0, st, t);
+        return hipGetLastError();
+    }
+    return launch_attn(S.hd, t, st);
+}
+
 // where the stack's final RMSNorm of each sequence's LAST row goes on the wide path (fused into the last finisher)
 struct FinalNorm { const bf16_t* scale; bf16_t* out; long out_stride; };
 
@@ -293,7 +308,7 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
             t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
             t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = 1;
             t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
-            if ((e = launch_attn(S.hd, t, st)) != hipSuccess) return e;
+            if ((e = launch_attn_auto(S, t, prompt, st)) != hipSuccess) return e;
             memset(&a, 0, sizeof a);
             a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)w.wo; a.N = d; a.out = h; a.ldo = d; a.resid = h;
             if ((e = launch_g128(1, S.nq, S.hd, a, st)) != hipSuccess) return e;
@@ -330,7 +345,7 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
         t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = 1;
         t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
-        if ((e = launch_attn(S.hd, t, st)) != hipSuccess) return e;
+        if ((e = launch_attn_auto(S, t, prompt, st)) != hipSuccess) return e;
         // o-proj -> fp32 slabs; finisher: h += sum(slabs), xn = mlp_norm(h)
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)pk.wo; a.N = d; a.slab = m->slab;
@@ -955,9 +970,16 @@ extern "C" int csm_op_attn(int M, int rows_per_seq, int H, int KV, int head_dim,
                            const void* kcache, const void* vcache, const int32_t* pos, void* out, float* part, void* stream) {
     AttnArgs t;
     t.q = (const bf16_t*)q; t.kcache = (const bf16_t*)kcache; t.vcache = (const bf16_t*)vcache; t.pos = pos; t.M = M;
-    t.rows_per_seq = rows_per_seq; t.H = H; t.KV = KV; t.smax = smax; t.nsplit = nsplit;
+    // nsplit == 0: the matrix-core prompt kernel (attn_flash.cuh; head_dim 64); nsplit >= 1: one row per block
+    t.rows_per_seq = rows_per_seq; t.H = H; t.KV = KV; t.smax = smax; t.nsplit = nsplit < 1 ? 1 : nsplit;
     t.scale = 1.0f / sqrtf((float)head_dim); t.out = (bf16_t*)out; t.part = part;
-    hipError_t e = launch_attn(head_dim, t, (hipStream_t)stream);
+    hipError_t e;
+    if (nsplit < 1) {
+        if (head_dim != 64 || H % KV != 0) return CSM_E_INVALID;
+        dim3 grid((M / rows_per_seq) * ((rows_per_seq + 31) / 32), KV);
+        hipLaunchKernelGGL((k_attn_flash<64>), grid, dim3(256), 0, (hipStream_t)stream, t);
+        e = hipGetLastError();
+    } else e = launch_attn(head_dim, t, (hipStream_t)stream);
     if (e != hipSuccess) { g_create_err = std::string("csm_op_attn: ") + hipGetErrorString(e); return CSM_E_HIP; }
     return CSM_OK;
 }

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K,
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         red[0][wave][i][lane] = acc0[i];
-        if (EPI == EPI_SWIGLU) red[1][wave][i][lane] = acc1[i];
+        if constexpr (EPI == EPI_SWIGLU) red[1][wave][i][lane] = acc1[i];
     }
     __syncthreads();
     if (wave >= 4) return;                                // waves 0..3 finish the tile
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K,
                 continue;
             }
             float s1 = 0.f;
-            if (EPI == EPI_SWIGLU) {
+            if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
                 for (int w = 0; w < NW; ++w) s1 += red[1][w][reg][lane];
             }

@@ -231,6 +231,70 @@ def test_attention(abi, H, KV, hd, nsplit):
     assert diff <= err_ref + err_hip + 1e-6
 
 
+@pytest.mark.parametrize("H,KV,S,start", [(32, 8, 77, (0, 5, 100)), (8, 2, 33, (0, 0, 190)), (16, 4, 1, (0, 63, 64))])
+def test_prompt_flash_attention_vs_exact_and_oracle(abi, H, KV, S, start):
+    """attn_flash.cuh (prompt rows, hd 64): S^T = K.Q^T and O^T += V^T.P^T on the matrix cores, fp32 softmax, P rounded
+    to bf16 like torch's CPU flash kernel.  Graded like test_attention: against exact fp64 attention of the same bf16
+    inputs and against the oracle's SDPA."""
+    hd, smax = 64, 320
+    g = torch.Generator().manual_seed(H + S)
+    B = len(start)
+    M = B * S
+    q = rnd((B, S, H, hd), g)
+    kc, vc = rnd((B, KV, smax, hd), g), rnd((B, KV, smax, hd), g)
+    pos = torch.tensor(start)[:, None] + torch.arange(S)[None, :]
+    # cache rows that a prompt has not written yet hold arbitrary bits, NaN patterns included: they must not leak
+    for b in range(B):
+        kc[b, :, int(pos[b].max()) + 1:] = float("nan"); vc[b, :, int(pos[b].max()) + 1:] = float("nan")
+    rep = H // KV
+    kk = kc.unsqueeze(2).expand(B, KV, rep, smax, hd).reshape(B, H, smax, hd)
+    vv = vc.unsqueeze(2).expand(B, KV, rep, smax, hd).reshape(B, H, smax, hd)
+    mask = torch.arange(smax)[None, None, :] <= pos[:, :, None]
+    kz, vz = torch.nan_to_num(kk, nan=0.0), torch.nan_to_num(vv, nan=0.0)
+    want = F.scaled_dot_product_attention(q.transpose(1, 2), kz, vz, attn_mask=mask[:, None]).transpose(1, 2)
+    sc = (q.double().transpose(1, 2) @ kz.double().transpose(-1, -2)) / hd ** 0.5
+    exact = (sc.masked_fill(~mask[:, None], float("-inf")).softmax(-1) @ vz.double()).transpose(1, 2)
+    out = torch.zeros(M, H * hd, dtype=torch.bfloat16, device="cuda")
+    part = torch.zeros(16, dtype=torch.float32, device="cuda")
+    qd, kd, vd, pd = dev(q), dev(kc), dev(vc), dev(pos.reshape(-1), torch.int32)
+    _ck(abi, abi.lib.csm_op_attn(M, S, H, KV, hd, smax, 0, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), pd.data_ptr(),
+                                 out.data_ptr(), part.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().float().view(B, S, H, hd).double()
+    assert torch.isfinite(got).all()
+    err_hip = (got - exact).abs().max().item()
+    err_ref = (want.double() - exact).abs().max().item()
+    print(f"flash attention H{H} S{S}: |hip-exact|={err_hip:.4g} |oracle-exact|={err_ref:.4g}")
+    ulp = 2.0 ** -8 * max(1.0, exact.abs().max().item())
+    assert err_hip <= 1.5 * ulp, f"flash attention error vs exact {err_hip}"          # bf16 P adds up to half an ulp
+    assert (got - want.double()).abs().max().item() <= err_ref + err_hip + 1e-6
+
+
+def test_prompt_flash_attention_rows_do_not_depend_on_the_tiling(abi):
+    """The same prompt rows attended in one call of 90 rows, or as the last 37 rows on their own (different 32-row
+    tiles, fewer key tiles walked by the early blocks): identical bits.  This is what lets a warm prefill of a few new
+    rows reproduce a cold prefill exactly."""
+    H, KV, hd, smax, S = 32, 8, 64, 256, 90
+    g = torch.Generator().manual_seed(9)
+    q = dev(rnd((S, H, hd), g))
+    kc, vc = dev(rnd((1, KV, smax, hd), g)), dev(rnd((1, KV, smax, hd), g))
+    pos = dev(torch.arange(7, 7 + S), torch.int32)
+    part = torch.zeros(16, dtype=torch.float32, device="cuda")
+
+    def run(first, n):
+        out = torch.zeros(n, H * hd, dtype=torch.bfloat16, device="cuda")
+        qs, ps = q[first:first + n].contiguous(), pos[first:first + n].contiguous()
+        _ck(abi, abi.lib.csm_op_attn(n, n, H, KV, hd, smax, 0, qs.data_ptr(), kc.data_ptr(), vc.data_ptr(), ps.data_ptr(),
+                                     out.data_ptr(), part.data_ptr(), stream()))
+        torch.cuda.synchronize()
+        return out
+
+    whole = run(0, S)
+    assert torch.equal(whole[53:], run(53, 37))
+    assert torch.equal(whole[89:], run(89, 1))
+    assert torch.equal(whole[:5], run(0, 5))
+
+
 @pytest.mark.parametrize("H,KV,rows_per_seq", [(8, 2, 1), (8, 2, 2), (4, 2, 1)])
 def test_fused_decoder_attention_oproj(abi, H, KV, rows_per_seq):
     """depth-decoder "SDPA + output_proj + residual" fused into one kernel (hd 128, <= 32 keys)."""
