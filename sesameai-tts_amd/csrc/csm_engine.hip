@@ -47,7 +47,8 @@ struct CsmModel {
     Stack bb, dec;
     // workspaces (bf16 unless noted)
     bf16_t *h, *q, *att, *act;          // backbone rows [max_rows][..]
-    float* part;                        // [PART_ROWS][H][NSPLIT][hd+2]
+    float* part;                        // [max(PART_ROWS, max_batch)][H][NSPLIT][hd+4] split-K attention partials
+    int part_rows;
     bf16_t *dec_in;                     // [B][2][d_bb]   row0 = last_h, row1 = c0 embedding
     float* slab;                        // [8][max_rows][max(d_bb, d_dec)] fp32 split-K partials of the wide path
     bf16_t *pk_projection, *pk_c0_head, *pk_audio_head;   // packed copies for the wide-M path
@@ -345,6 +346,12 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
         t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = 1;
         t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
+        // batched backbone decode step (one row per sequence, long key ranges): a (row, KV head) block alone walks
+        // its ~200+ keys in ~8 dependent round trips -- split the keys over up to 8 blocks like the B = 1 path
+        if (!prompt && rows_per_seq == 1 && &S == &m->bb && M <= m->part_rows) {
+            int ns = 1024 / (M * S.d.n_kv_heads);
+            t.nsplit = ns < 1 ? 1 : (ns > BB_NSPLIT_MAX ? BB_NSPLIT_MAX : ns);
+        }
         if ((e = launch_attn_auto(S, t, prompt, st)) != hipSuccess) return e;
         // o-proj -> fp32 slabs; finisher: h += sum(slabs), xn = mlp_norm(h)
         memset(&a, 0, sizeof a);
@@ -710,7 +717,8 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     ALLOC(m->q, (size_t)max_rows * m->bb.nq * 2);
     ALLOC(m->att, (size_t)max_rows * m->bb.nq * 2);
     ALLOC(m->act, (size_t)max_rows * cfg->backbone.ffn * 2);
-    ALLOC(m->part, (size_t)PART_ROWS * cfg->backbone.n_heads * BB_NSPLIT_MAX * (m->bb.hd + 4) * 4);
+    m->part_rows = max_batch > PART_ROWS ? max_batch : PART_ROWS;
+    ALLOC(m->part, (size_t)m->part_rows * cfg->backbone.n_heads * BB_NSPLIT_MAX * (m->bb.hd + 4) * 4);
     ALLOC(m->dec_in, (size_t)max_batch * 2 * dbb * 2);
     ALLOC(m->proj_emb, (size_t)ncb * cfg->audio_vocab * dd * 2);
     ALLOC(m->slab, (size_t)8 * max_rows * (dbb > dd ? dbb : dd) * 4);
