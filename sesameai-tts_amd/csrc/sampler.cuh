@@ -139,6 +139,8 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
     __shared__ int s_n, s_tok, s_wtot[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16_t* lg = a.logits + (long)b * a.ldl;
+    // issued now, consumed by wave 0 three barriers later (a dependent load there would sit on the critical path)
+    const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
     uint32_t w[ITERS][4];
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
@@ -172,6 +174,9 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
             }
         s_max[tid] = lmax;
         __syncthreads();
+#if defined(SB_STOP) && SB_STOP == 1
+        if (tid == 0) a.frame[b] = (int)lmax; return;
+#endif
         uint32_t L = 0;
         if (k <= 256) {
             const uint4 mv = reinterpret_cast<const uint4*>(s_max)[lane];
@@ -217,6 +222,9 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
             }
         __syncthreads();
         const int n = s_n;
+#if defined(SB_STOP) && SB_STOP == 2
+        if (tid == 0) a.frame[b] = n; return;
+#endif
         if (wave == 0) {
             // ---- exact kth-largest t among the candidates -> keep t >= kth (ties kept) ---------
             uint32_t kth = 0;
@@ -260,7 +268,6 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
             }
             s2 = wave_sum(s2);
             // ---- argmax(p / q), q ~ Exp(1); first index wins ties ----------------------------------
-            const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
             for (int c = lane; c < n; c += 64) {
                 const float v = cand_t[c];
                 if (order_key(v) < kth) continue;
@@ -281,6 +288,9 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
             }
         }
     }
+#if defined(SB_STOP) && SB_STOP == 3
+    if (tid == 0) a.frame[b] = best_idx; return;
+#endif
     // argmax over the wave (lowest index on ties), then over the 4 waves
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
