@@ -641,7 +641,7 @@ static hipError_t build_qkv0_table(CsmModel* m) {
     bf16_t *kt = nullptr, *vt = nullptr;                 // scratch caches: one "sequence" per vocabulary entry
     const size_t kv_bytes = (size_t)V * c.decoder.n_kv_heads * S.cache_len * S.hd * 2;
     if ((e = hipMalloc((void**)&kt, kv_bytes)) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&vt, kv_bytes)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&vt, kv_bytes)) != hipSuccess) { (void)hipFree(kt); return e; }
     for (int cb = 1; cb <= ncb - 2 && e == hipSuccess; ++cb) {
         bf16_t* tab = m->qkv0_tab + (long)(cb - 1) * V * ld;
         GemvArgs a;

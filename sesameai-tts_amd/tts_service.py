@@ -40,9 +40,11 @@ def discover_voices(voice_dir: str) -> dict:
                 voices[os.path.splitext(f)[0]] = os.path.join(voice_dir, f)
         sp = os.path.join(voice_dir, "samples.py")
         if os.path.exists(sp):
-            ns: dict = {}
-            exec(compile(open(sp).read(), sp, "exec"), ns)      # user-provided voice registry, like the reference's `import samples`
-            for name, obj in ns.items():
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("csm_voice_samples", sp)     # the reference does `import samples`
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            for name, obj in vars(mod).items():
                 if not name.startswith("__") and isinstance(obj, dict):
                     voices[name] = obj
     return voices

@@ -170,3 +170,20 @@ def test_watermark_hook_passes_audio_through_without_silentcipher():
     if wm is None:
         y, sr = watermark(wm, x, 24000, CSM_1B_GH_WATERMARK)
         assert sr == 24000 and torch.equal(x, y) and verify(wm, y, sr, CSM_1B_GH_WATERMARK) is False
+
+
+def test_voice_registry_discovers_pt_prompts_and_samples_module(tmp_path):
+    """reference tts_service.py:36-42 builds its voice list from the dicts of `samples.py`; ours also accepts
+    pre-tokenised <voice>.pt prompt files."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tts_service_amd2", os.path.join(ROOT, "sesameai-tts_amd", "tts_service.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    (tmp_path / "samples.py").write_text("alice = {'/tmp/a.wav': 'hello there'}\n_private = 3\n")
+    torch.save([("hi", torch.zeros(32, 4, dtype=torch.long))], tmp_path / "bob.pt")
+    voices = mod.discover_voices(str(tmp_path))
+    assert set(voices) == {"alice", "bob"}
+    assert voices["alice"] == {"/tmp/a.wav": "hello there"} and voices["bob"].endswith("bob.pt")
+    tts = mod.TTS(voice_dir=str(tmp_path))
+    assert tts.list_voices() == ["bob", "alice"] or set(tts.list_voices()) == {"alice", "bob"}
+    with pytest.raises(ValueError, match="not found"):
+        tts.load_voice("carol")
