@@ -235,7 +235,13 @@ static hipError_t launch_mm_slab(int K, int kg, const GemvArgs& a, hipStream_t s
     return hipGetLastError();
 }
 static hipError_t launch_resid_norm(bf16_t* h, const float* slab, int kg, int M, int N, long row_step, long row_first, int M_out,
-                                    const bf16_t* scale, float eps, bf16_t* xn, long xn_stride, hipStream_t st) {
+                                    const bf16_t* scale, float eps, bf16_t* xn, long xn_stride, hipStream_t st, bool prompt = true) {
+    if (!prompt && M_out <= 64 && (N == 1024 || N == 2048 || N == 512)) {
+        // decode steps: one block per row (mm.cuh k_resid_norm_row)
+        if (N == 2048) hipLaunchKernelGGL((k_resid_norm_row<8>), dim3(M_out), dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, scale, eps, xn, xn_stride);
+        else hipLaunchKernelGGL((k_resid_norm_row<4>), dim3(M_out), dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, scale, eps, xn, xn_stride);
+        return hipGetLastError();
+    }
     dim3 grid((M_out + 3) / 4);
     if (N <= 512) hipLaunchKernelGGL((k_resid_norm<1>), grid, dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, M_out, scale, eps, xn, xn_stride);
     else if (N <= 1024) hipLaunchKernelGGL((k_resid_norm<2>), grid, dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, M_out, scale, eps, xn, xn_stride);
@@ -358,7 +364,7 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)pk.wo; a.N = d; a.slab = m->slab;
         int kg = slab_groups(S.nq, prompt);
         if ((e = launch_mm_slab(S.nq, kg, a, st)) != hipSuccess) return e;
-        if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+        if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st, prompt)) != hipSuccess) return e;
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = d; a.M = M; a.w0 = (const bf16_t*)pk.w1; a.w1 = (const bf16_t*)pk.w3; a.N = S.d.ffn;
         a.out = act; a.ldo = S.d.ffn;
@@ -369,13 +375,13 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         kg = slab_groups(S.d.ffn, prompt);
         if ((e = launch_mm_slab(S.d.ffn, kg, a, st)) != hipSuccess) return e;
         if (l + 1 < S.d.n_layers) {
-            if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)S.lw[l + 1].sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+            if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)S.lw[l + 1].sa_norm, S.d.norm_eps, att, d, st, prompt)) != hipSuccess) return e;
         } else {
             // last layer: only each sequence's last row is read again (heads / last_h); its finisher applies the
             // stack's final norm
             const int nseq = M / rows_per_seq;
             if ((e = launch_resid_norm(h, m->slab, kg, M, d, rows_per_seq, rows_per_seq - 1, nseq, fin.scale, S.d.norm_eps,
-                                       fin.out, fin.out_stride, st)) != hipSuccess) return e;
+                                       fin.out, fin.out_stride, st, prompt)) != hipSuccess) return e;
         }
     }
     return hipSuccess;

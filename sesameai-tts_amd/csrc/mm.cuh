@@ -89,6 +89,70 @@ __global__ __launch_bounds__(256) void k_resid_norm(bf16_t* h, const float* slab
     }
 }
 
+// The same finisher for DECODE steps (a handful of rows): one 256-thread block per row instead of one wave, so a
+// lane has KG 16-byte slab loads in flight instead of 4 KG and the row's bytes come through four waves' worth of
+// memory pipes -- the kernel is one dependent round trip on remote-L2 slabs, not bandwidth.  Thread t owns columns
+// [CPT t, CPT t + CPT).  Sum order over slabs is fixed (deterministic); the sum of squares is reduced in a different
+// order than k_resid_norm, which is why prompt rows (bit-identical across prefill sizes) never use this kernel.
+template <int CPT>
+__global__ __launch_bounds__(256) void k_resid_norm_row(bf16_t* h, const float* slab, int KG, int M, int N, long row_step, long row_first,
+                                                        const bf16_t* scale, float eps, bf16_t* xn, long xn_stride) {
+    __shared__ float s_part[4];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long r = (long)i * row_step + row_first;
+    const int col = tid * CPT;
+    const bool in = col < N;
+    float acc[CPT], v[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
+    float4 p[8][CPT / 4];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int gg = g < KG ? g : 0;
+#pragma unroll
+        for (int q = 0; q < CPT / 4; ++q)
+            p[g][q] = in ? *reinterpret_cast<const float4*>(slab + ((long)gg * M + r) * N + col + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    uint32_t hw[CPT / 2];
+#pragma unroll
+    for (int q = 0; q < CPT / 2; ++q) hw[q] = in ? reinterpret_cast<const uint32_t*>(h + r * N + col)[q] : 0u;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if (g < KG) {
+#pragma unroll
+            for (int q = 0; q < CPT / 4; ++q) {
+                acc[4 * q] += p[g][q].x; acc[4 * q + 1] += p[g][q].y; acc[4 * q + 2] += p[g][q].z; acc[4 * q + 3] += p[g][q].w;
+            }
+        }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const float hj = (j & 1) ? hi2f(hw[j >> 1]) : lo2f(hw[j >> 1]);
+        v[j] = round_bf(hj + round_bf(acc[j]));
+        ss += v[j] * v[j];
+    }
+    if (in) {
+#pragma unroll
+        for (int q = 0; q < CPT / 2; ++q) reinterpret_cast<uint32_t*>(h + r * N + col)[q] = pack_bf(v[2 * q], v[2 * q + 1]);
+    }
+    if (scale == nullptr) return;
+    uint32_t gw[CPT / 2];
+#pragma unroll
+    for (int q = 0; q < CPT / 2; ++q) gw[q] = in ? reinterpret_cast<const uint32_t*>(scale + col)[q] : 0u;
+    ss = wave_sum(ss);
+    if (lane == 0) s_part[wave] = ss;
+    __syncthreads();
+    ss = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
+    const float rs = 1.0f / sqrtf(ss / (float)N + eps);
+    if (in) {
+#pragma unroll
+        for (int q = 0; q < CPT / 2; ++q)
+            reinterpret_cast<uint32_t*>(xn + (long)i * xn_stride + col)[q] =
+                pack_bf(round_bf(v[2 * q] * rs) * lo2f(gw[q]), round_bf(v[2 * q + 1] * rs) * hi2f(gw[q]));
+    }
+}
+
 __device__ __forceinline__ bf16x8_t as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
 
 // Matrix-core operand order for the weight stream ("memory laid out for the hardware"): W [N][K]
