@@ -24,7 +24,8 @@ struct AttnArgs {
     float* part;            // [M][H][nsplit][HD + 4]    (nsplit  > 1): o[HD], m, l
 };
 
-template <int HD>
+// U = key rows per lane in flight per batch (hd 128 / depth decoder: 8, so its <= 32 keys are ONE round trip)
+template <int HD, int U = 4>
 __global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
     constexpr int LPK = HD / 8;          // lanes per key
     constexpr int KPI = 64 / LPK;        // keys per wave-iteration
@@ -47,17 +48,17 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = 0.f;
 
-        // 4 key rows per lane in flight: all loads of a batch are issued before the first is consumed
-        for (int jb = j0 + slot; jb < j1; jb += 4 * KPI) {
-            uint4 kv[4], vv[4];
+        // U key rows per lane in flight: all loads of a batch are issued before the first is consumed
+        for (int jb = j0 + slot; jb < j1; jb += U * KPI) {
+            uint4 kv[U], vv[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int j = min(jb + u * KPI, j1 - 1);
                 kv[u] = *reinterpret_cast<const uint4*>(kb + (long)j * HD + e * 8);
                 vv[u] = *reinterpret_cast<const uint4*>(vb + (long)j * HD + e * 8);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 float s = dot8(qv, kv[u], 0.f);
 #pragma unroll
                 for (int off = 1; off < LPK; off <<= 1) s += __shfl_xor(s, off, WAVE);

@@ -259,7 +259,10 @@ static hipError_t launch_rmsnorm_rows(const bf16_t* x, long stride, long offset,
 static hipError_t launch_attn(int hd, const AttnArgs& a, hipStream_t st, bool combine = true) {
     dim3 grid(a.M, a.KV, a.nsplit);
     if (hd == 64) hipLaunchKernelGGL((k_attn<64>), grid, dim3(256), 0, st, a);
-    else if (hd == 128) hipLaunchKernelGGL((k_attn<128>), grid, dim3(256), 0, st, a);
+    else if (hd == 128) {
+        if (a.smax <= 32) hipLaunchKernelGGL((k_attn<128, 8>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_attn<128>), grid, dim3(256), 0, st, a);
+    }
     else return hipErrorInvalidValue;
     if (a.nsplit > 1 && combine) {
         if (hd == 64) hipLaunchKernelGGL((k_attn_combine<64>), dim3(a.M, a.H), dim3(64), 0, st, a.part, a.nsplit, a.out, a.H);

@@ -15,14 +15,15 @@ int main() {
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     struct Case { const char* name; int kind; int K, Nn; size_t wbytes; int kg = 1; };
-    float* slab; CK(hipMalloc(&slab, 8u * 32 * 2048 * 4));
+    float* slab; CK(hipMalloc(&slab, 32u * 32 * 2048 * 4));
     std::vector<Case> cases = {
         {"swiglu  K1024 N8192 (33.5MB)", 4, 1024, 8192, 33554432}, 
         {"resid   K8192 N1024 NW4", 1, 8192, 1024, 16777216}, {"resid   K1024 N1024 (2MB)", 1, 1024, 1024, 2097152},
         {"store   K1024 N2051 (4.2MB)", 0, 1024, 2051, 4259840}, {"swiglu  K2048 N8192 (67MB)", 4, 2048, 8192, 67108864},
         {"slab    K1024 N1024 kg1", 5, 1024, 1024, 2097152, 1}, {"slab    K1024 N1024 kg2", 5, 1024, 1024, 2097152, 2},
         {"slab    K1024 N1024 kg4", 5, 1024, 1024, 2097152, 4},
-        {"slab    K8192 N1024 kg8", 5, 8192, 1024, 16777216, 8},
+        {"slab    K8192 N1024 kg8", 5, 8192, 1024, 16777216, 8}, {"slab    K8192 N1024 kg16", 5, 8192, 1024, 16777216, 16},
+        {"slab    K8192 N1024 kg32", 5, 8192, 1024, 16777216, 32}, {"slab    K8192 N2048 kg16", 5, 8192, 2048, 33554432, 16},
         {"slab    K2048 N2048 kg2", 5, 2048, 2048, 8388608, 2}, {"slab    K2048 N2048 kg4", 5, 2048, 2048, 8388608, 4},
         {"slab    K2048 N2048 kg8", 5, 2048, 2048, 8388608, 8},
         {"slab    K8192 N2048 kg8", 5, 8192, 2048, 33554432, 8},
