@@ -38,6 +38,8 @@ struct Stack {
     int nt_attn, nt_mlp;        // cache policy of the q/k/v/o and of the gate/up/down weight streams
     const CsmLayerWeights *w8, *w8s;      // fp8 weight stream + scales (nullptr = bf16)
     CsmLayerWeights pk[CSM_MAX_LAYERS];   // matrix-core operand-order copies of wq..w3 (k_pack_w) for the wide-M path
+    CsmLayerWeights pk8[CSM_MAX_LAYERS];  // the same for the e4m3 weight stream (k_pack_w8); valid when has_pk8
+    bool has_pk8;
 };
 
 struct CsmModel {
@@ -52,6 +54,7 @@ struct CsmModel {
     bf16_t *dec_in;                     // [B][2][d_bb]   row0 = last_h, row1 = c0 embedding
     float* slab;                        // [8][max_rows][max(d_bb, d_dec)] fp32 split-K partials of the wide path
     bf16_t *pk_projection, *pk_c0_head, *pk_audio_head;   // packed copies for the wide-M path
+    uint8_t *pk8_c0_head, *pk8_audio_head;                // e4m3 heads in operand order (fp8 mode)
     long pk_head_stride;                // elements between packed audio heads
     std::vector<void*> pk_allocs;
     bf16_t *qkv0_tab;                   // [(n_codebooks-2)*audio_vocab][nq + 2 nkv]: layer-0 q | k | v of the depth decoder for every
@@ -66,6 +69,7 @@ struct CsmModel {
     int host_frames;                    // frames launched since reset (host mirror)
     int wide_path;                      // MFMA path for M >= wide_min (env CSM_WIDE=0 disables)
     int wide_min;                       // WIDE_MIN_ROWS unless env CSM_WIDE_MIN overrides (tuning knob)
+    int fp8_wide;                       // fp8 mode: batched decode steps stream e4m3 on the matrix-core path too (env CSM_FP8_WIDE=0 disables)
     int fuse_dec_attn;                  // depth-decoder attention fused into the O-projection (env CSM_FUSE_DEC_ATTN=0 disables)
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
     int last_S;                         // rows per sequence of the h buffer feeding csm_depth
@@ -170,20 +174,25 @@ static void mm_grid(const GemvArgs& a, int kg, dim3* grid, int* mt8) {
     if (a.M >= XCD_TILING_MIN_ROWS) { *mt8 = (mt + 7) / 8; *grid = dim3((unsigned)(8L * nt * kg * *mt8)); }
     else { *mt8 = 0; *grid = dim3(nt, mt, kg); }
 }
-static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
+template <int WT>
+static hipError_t launch_mm_t(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
     if (K % 256 != 0) return hipErrorInvalidValue;
     dim3 grid; int mt8;
     mm_grid(a, 1, &grid, &mt8);
     switch (kind) {
-        case 0: hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4>), grid, dim3(256), 0, st, a, K, mt8, 1); break;
-        case 1: hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4>), grid, dim3(256), 0, st, a, K, mt8, 1); break;
-        case 3: if (hd == 64) hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 64, 4>), grid, dim3(256), 0, st, a, K, mt8, 1);
-                else hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 128, 4>), grid, dim3(256), 0, st, a, K, mt8, 1);
+        case 0: hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mt8, 1); break;
+        case 1: hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mt8, 1); break;
+        case 3: if (hd == 64) hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mt8, 1);
+                else hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 128, 4, WT>), grid, dim3(256), 0, st, a, K, mt8, 1);
                 break;
-        case 4: hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4>), grid, dim3(256), 0, st, a, K, mt8, 1); break;
+        case 4: hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mt8, 1); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+// f8: w0/w1/w2 are k_pack_w8 copies of the e4m3 stream and s0/s1/s2 the per-row scales
+static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStream_t st, bool f8 = false) {
+    return f8 ? launch_mm_t<1>(kind, K, hd, a, st) : launch_mm_t<0>(kind, K, hd, a, st);
 }
 
 // long prompts / batched prefill: LDS-tiled 128 x 128 kernel (gemm128.cuh); weights UNPACKED [N][K]
@@ -227,11 +236,12 @@ static int slab_groups(int K, bool prompt) {
     int kg = K / per_block;
     return kg < 1 ? 1 : (kg > 8 ? 8 : kg);
 }
-static hipError_t launch_mm_slab(int K, int kg, const GemvArgs& a, hipStream_t st) {
+static hipError_t launch_mm_slab(int K, int kg, const GemvArgs& a, hipStream_t st, bool f8 = false) {
     if (K % (256 * kg) != 0) return hipErrorInvalidValue;
     dim3 grid; int mt8;
     mm_grid(a, kg, &grid, &mt8);
-    hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4>), grid, dim3(256), 0, st, a, K, mt8, kg);
+    if (f8) hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4, 1>), grid, dim3(256), 0, st, a, K, mt8, kg);
+    else hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4, 0>), grid, dim3(256), 0, st, a, K, mt8, kg);
     return hipGetLastError();
 }
 static hipError_t launch_resid_norm(bf16_t* h, const float* slab, int kg, int M, int N, long row_step, long row_first, int M_out,
@@ -339,6 +349,10 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
             }
             continue;
         }
+        // decode steps in fp8 mode stream the e4m3 copies (same values as the bf16 weights, which are their
+        // dequantisation: identical bits, half the bytes); prompts keep the bf16 stream they share with k_gemm128
+        const bool f8 = S.has_pk8 && !prompt && m->fp8_wide;
+        const CsmLayerWeights& p8 = S.pk8[l];
         // layer 0 normalises h directly; later layers got xn from the previous down-projection's finisher.
         // (layer 0 of a depth-decoder step >= 2: q/k/v were gathered from the precomputed table by the sampler)
         if (!(l == 0 && qkv0_done)) {
@@ -349,7 +363,11 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
             a.N = S.nq + 2 * S.nkv; a.out = q; a.ldo = S.nq;
             a.nq = S.nq; a.nkv = S.nkv; a.smax = S.cache_len; a.rows_per_seq = rows_per_seq; a.kv_heads = S.d.n_kv_heads;
             a.pos = pos; a.rope = S.rope; a.kcache = kc; a.vcache = vc;
-            if ((e = launch_mm(3, d, S.hd, a, st)) != hipSuccess) return e;
+            if (f8) {
+                a.w0 = (const bf16_t*)p8.wq; a.w1 = (const bf16_t*)p8.wk; a.w2 = (const bf16_t*)p8.wv;
+                a.s0 = (const float*)S.w8s[l].wq; a.s1 = (const float*)S.w8s[l].wk; a.s2 = (const float*)S.w8s[l].wv;
+            }
+            if ((e = launch_mm(3, d, S.hd, a, st, f8)) != hipSuccess) return e;
         }
         AttnArgs t;
         t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
@@ -366,17 +384,20 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)pk.wo; a.N = d; a.slab = m->slab;
         int kg = slab_groups(S.nq, prompt);
-        if ((e = launch_mm_slab(S.nq, kg, a, st)) != hipSuccess) return e;
+        if (f8) { a.w0 = (const bf16_t*)p8.wo; a.s0 = (const float*)S.w8s[l].wo; }
+        if ((e = launch_mm_slab(S.nq, kg, a, st, f8)) != hipSuccess) return e;
         if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st, prompt)) != hipSuccess) return e;
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = d; a.M = M; a.w0 = (const bf16_t*)pk.w1; a.w1 = (const bf16_t*)pk.w3; a.N = S.d.ffn;
         a.out = act; a.ldo = S.d.ffn;
-        if ((e = launch_mm(4, d, S.hd, a, st)) != hipSuccess) return e;
+        if (f8) { a.w0 = (const bf16_t*)p8.w1; a.w1 = (const bf16_t*)p8.w3; a.s0 = (const float*)S.w8s[l].w1; a.s1 = (const float*)S.w8s[l].w3; }
+        if ((e = launch_mm(4, d, S.hd, a, st, f8)) != hipSuccess) return e;
         // down-proj -> slabs; finisher applies the NEXT layer's sa_norm (or nothing after the last layer)
         memset(&a, 0, sizeof a);
         a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)pk.w2; a.N = d; a.slab = m->slab;
         kg = slab_groups(S.d.ffn, prompt);
-        if ((e = launch_mm_slab(S.d.ffn, kg, a, st)) != hipSuccess) return e;
+        if (f8) { a.w0 = (const bf16_t*)p8.w2; a.s0 = (const float*)S.w8s[l].w2; }
+        if ((e = launch_mm_slab(S.d.ffn, kg, a, st, f8)) != hipSuccess) return e;
         if (l + 1 < S.d.n_layers) {
             if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)S.lw[l + 1].sa_norm, S.d.norm_eps, att, d, st, prompt)) != hipSuccess) return e;
         } else {
@@ -533,7 +554,12 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             // (the final norm was applied by the stack's last finisher: run_stack_wide)
             a.x = xn; a.x_row_stride = xs; a.x_row_offset = 0;
             a.w0 = cb == 0 ? m->pk_c0_head : m->pk_audio_head + (long)(cb - 1) * m->pk_head_stride;
-            if ((e = launch_mm(0, Kh, 0, a, st)) != hipSuccess) return e;
+            const bool f8h = m->pk8_c0_head != nullptr && m->fp8_wide;
+            if (f8h) {
+                a.w0 = (const bf16_t*)(cb == 0 ? m->pk8_c0_head : m->pk8_audio_head + (long)(cb - 1) * m->pk_head_stride);   // 1 byte per element
+                a.s0 = cb == 0 ? (const float*)m->w.c0_head8s : (const float*)m->w.audio_head8s + (long)(cb - 1) * V;
+            }
+            if ((e = launch_mm(0, Kh, 0, a, st, f8h)) != hipSuccess) return e;
         } else if (m->w.fp8) {
             if (cb == 0) { a.w0 = (const bf16_t*)m->w.c0_head8; a.s0 = (const float*)m->w.c0_head8s; }
             else { a.w0 = (const bf16_t*)((const char*)m->w.audio_head8 + (long)(cb - 1) * V * dd); a.s0 = (const float*)m->w.audio_head8s + (long)(cb - 1) * V; }
@@ -595,6 +621,34 @@ static hipError_t pack_weight(CsmModel* m, const void* w, int N, int K, bf16_t**
     m->pk_allocs.push_back(*out);
     hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, nullptr, (const bf16_t*)w, N, K, *out);
     return hipGetLastError();
+}
+
+static hipError_t pack_weight8(CsmModel* m, const void* w, int N, int K, uint8_t** out) {
+    const long pieces = (long)((N + 31) / 32) * (K / 64) * 256;
+    hipError_t e = hipMalloc((void**)out, (size_t)pieces * 8);
+    if (e != hipSuccess) return e;
+    m->pk_allocs.push_back(*out);
+    hipLaunchKernelGGL(k_pack_w8, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, nullptr, (const uint8_t*)w, N, K, (uint2*)*out);
+    return hipGetLastError();
+}
+
+static hipError_t pack_stack8(CsmModel* m, Stack& S) {
+    hipError_t e;
+    const int d = S.d.dim;
+    for (int l = 0; l < S.d.n_layers; ++l) {
+        const CsmLayerWeights& w = S.w8[l];
+        CsmLayerWeights& p = S.pk8[l];
+        uint8_t* t;
+        if ((e = pack_weight8(m, w.wq, S.nq, d, &t)) != hipSuccess) return e; p.wq = t;
+        if ((e = pack_weight8(m, w.wk, S.nkv, d, &t)) != hipSuccess) return e; p.wk = t;
+        if ((e = pack_weight8(m, w.wv, S.nkv, d, &t)) != hipSuccess) return e; p.wv = t;
+        if ((e = pack_weight8(m, w.wo, d, S.nq, &t)) != hipSuccess) return e; p.wo = t;
+        if ((e = pack_weight8(m, w.w1, S.d.ffn, d, &t)) != hipSuccess) return e; p.w1 = t;
+        if ((e = pack_weight8(m, w.w3, S.d.ffn, d, &t)) != hipSuccess) return e; p.w3 = t;
+        if ((e = pack_weight8(m, w.w2, d, S.d.ffn, &t)) != hipSuccess) return e; p.w2 = t;
+    }
+    S.has_pk8 = true;
+    return hipSuccess;
 }
 
 static hipError_t pack_stack(CsmModel* m, Stack& S) {
@@ -698,10 +752,12 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     m->max_rows = max_rows;
     m->ldl = ((cfg->audio_vocab + 511) / 512) * 512;
     m->gexec = nullptr; m->graph = nullptr; m->g_B = -1; m->cap_stream = nullptr;
+    m->pk8_c0_head = nullptr; m->pk8_audio_head = nullptr; m->bb.has_pk8 = false; m->dec.has_pk8 = false;
     m->host_frames = 0; m->have_last = false; m->last_S = 1;
     { const char* ev = getenv("CSM_FUSE_DEC_ATTN"); m->fuse_dec_attn = !(ev && ev[0] == '0'); }
     { const char* ev = getenv("CSM_WIDE"); m->wide_path = !(ev && ev[0] == '0'); }
     { const char* ev = getenv("CSM_WIDE_MIN"); m->wide_min = ev && atoi(ev) > 0 ? atoi(ev) : WIDE_MIN_ROWS; }
+    { const char* ev = getenv("CSM_FP8_WIDE"); m->fp8_wide = !(ev && ev[0] == '0'); }
     // Cache policy (measured, tools/microbench/gemv_bench.hip): a depth-decoder step touches
     // ~230 MB, about the size of the 256 MB Infinity Cache, so with default-policy loads the
     // 31-step cycle thrashes it and even the 2-3 MB q/k/v/o streams come from HBM (4.9 us per
@@ -773,6 +829,20 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
                                m->pk_audio_head + (long)i * m->pk_head_stride);
         }
         HIPCHK((CsmModel*)nullptr, hipGetLastError());
+        if (w->fp8) {                                     // e4m3 stream in operand order for batched decode steps
+            HIPCHK((CsmModel*)nullptr, pack_stack8(m, m->bb));
+            HIPCHK((CsmModel*)nullptr, pack_stack8(m, m->dec));
+            HIPCHK((CsmModel*)nullptr, pack_weight8(m, w->c0_head8, cfg->audio_vocab, dbb, &m->pk8_c0_head));
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pk8_audio_head, (size_t)m->pk_head_stride * (ncb - 1)));
+            m->pk_allocs.push_back(m->pk8_audio_head);
+            for (int i = 0; i < ncb - 1; ++i) {
+                const long pieces = m->pk_head_stride / 8;
+                hipLaunchKernelGGL(k_pack_w8, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, nullptr,
+                                   (const uint8_t*)w->audio_head8 + (long)i * cfg->audio_vocab * dd, cfg->audio_vocab, dd,
+                                   (uint2*)(m->pk8_audio_head + (long)i * m->pk_head_stride));
+            }
+            HIPCHK((CsmModel*)nullptr, hipGetLastError());
+        }
     }
     {   // proj_emb = Linear(projection)(audio_embeddings), with the production GEMV kernel (same rounding as at run time)
         GemvArgs a;

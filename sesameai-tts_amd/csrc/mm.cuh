@@ -175,6 +175,45 @@ __global__ void k_pack_w(const bf16_t* w, int N, int K, bf16_t* wt) {
     reinterpret_cast<uint4*>(wt)[piece] = v;
 }
 
+// Weight fragments of the wide-M kernels: WT = 0 bf16 (16 bytes = 8 k values per lane), WT = 1 OCP-e4m3 bytes (8 bytes
+// per lane; converted to bf16 in registers right before the MFMA, the power-of-two row scale applied to the fp32 sum,
+// which is exact -- the result equals the bf16 kernel's on the dequantised weights bit for bit).
+template <int WT> struct WFrag { typedef uint4 type; };
+template <> struct WFrag<1> { typedef uint2 type; };
+template <bool NT> __device__ __forceinline__ uint2 ldg8(const uint2* p) {
+    if (NT) {
+        typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+        const u32x2v v = __builtin_nontemporal_load(reinterpret_cast<const u32x2v*>(p));
+        return make_uint2(v.x, v.y);
+    }
+    return *p;
+}
+__device__ __forceinline__ uint4 wld(const uint4* p) { return ldg16<true>(p); }
+__device__ __forceinline__ uint2 wld(const uint2* p) { return ldg8<true>(p); }
+__device__ __forceinline__ bf16x8_t wfrag_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8_t, v); }
+__device__ __forceinline__ bf16x8_t wfrag_bf16x8(const uint2& v) {
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    const bf16x2v a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v.x, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v.x, 1.0f, true);
+    const bf16x2v c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v.y, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v.y, 1.0f, true);
+    bf16x8_t o;
+    o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1]; o[4] = c[0]; o[5] = c[1]; o[6] = d[0]; o[7] = d[1];
+    return o;
+}
+// fp8 counterpart of k_pack_w: 8-byte pieces, same (ntile, chunk, q, lane) order
+__global__ void k_pack_w8(const uint8_t* w, int N, int K, uint2* wt) {
+    const long piece = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)((N + 31) / 32) * (K / 64) * 4 * 64;
+    if (piece >= total) return;
+    const int lane = (int)(piece & 63), q = (int)((piece >> 6) & 3);
+    const long tc = piece >> 8;
+    const int chunk = (int)(tc % (K / 64));
+    const int ntile = (int)(tc / (K / 64));
+    const int n = ntile * 32 + (lane & 31);
+    uint2 v = make_uint2(0, 0);
+    if (n < N) v = *reinterpret_cast<const uint2*>(w + (long)n * K + chunk * 64 + (lane >> 5) * 32 + q * 8);
+    wt[piece] = v;
+}
+
 // Epilogue of one output element (row m, column n) of the wide-M kernels; s0 = fp32 dot product (s1 = the
 // up-projection's for SwiGLU).  Same rounding points as the GEMV path.  QKV: every lane of the wave must call
 // this together (the RoPE partner column n^1 sits in the neighbouring lane).
@@ -221,7 +260,7 @@ __device__ __forceinline__ void mm_finish(const GemvArgs& a, const int m, const 
 // its own 4 MB L2, so block L runs on XCD L % 8.  XCD c owns the row tiles {c, c+8, ...} (mt8 of them): its share of
 // x (M/8 rows) stays L2-resident, and consecutive blocks of one XCD walk those row tiles for ONE n tile, so a
 // weight tile is fetched from HBM once per XCD instead of once per row tile.
-template <int EPI, int HD, int NW>
+template <int EPI, int HD, int NW, int WT = 0>
 __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K, const int mt8, const int kgroups) {
     __shared__ float red[EPI == EPI_SWIGLU ? 2 : 1][NW][16][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
@@ -236,16 +275,20 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K,
     const int mrow = min(m0 + r, a.M - 1);
     // w0/w1/w2 are PACKED (k_pack_w): tile pointer = base + ntile * (K/64) * 4 KB; a wave-level load of
     // step q in chunk c is the contiguous 1 KB at  tile + ((c*4 + q)*64 + lane) * 16 bytes
-    const uint4* wa;                                      // weight tile feeding accumulator 0
-    const uint4* wb = nullptr;                            // SwiGLU: the matching up-projection tile
-    const long tile_u4 = (long)(K / 64) * 256;            // uint4 per n-tile
+    typedef typename WFrag<WT>::type wfrag_t;             // 16-byte bf16 or 8-byte fp8 piece
+    const wfrag_t* wa;                                    // weight tile feeding accumulator 0
+    const wfrag_t* wb = nullptr;                          // SwiGLU: the matching up-projection tile
+    const long tile_u4 = (long)(K / 64) * 256;            // pieces per n-tile
+    float wscale0 = 1.0f, wscale1 = 1.0f;                 // WT == 1: power-of-two scale of this lane's weight row
+    const int nl = min(n0 + r, a.N - 1);
     if (EPI == EPI_QKV_ROPE) {                            // nq, nkv are multiples of 32: a tile never straddles q/k/v
-        if (n0 < a.nq) wa = reinterpret_cast<const uint4*>(a.w0) + (long)(n0 / 32) * tile_u4;
-        else if (n0 < a.nq + a.nkv) wa = reinterpret_cast<const uint4*>(a.w1) + (long)((n0 - a.nq) / 32) * tile_u4;
-        else wa = reinterpret_cast<const uint4*>(a.w2) + (long)((n0 - a.nq - a.nkv) / 32) * tile_u4;
+        if (n0 < a.nq) { wa = reinterpret_cast<const wfrag_t*>(a.w0) + (long)(n0 / 32) * tile_u4; if (WT) wscale0 = a.s0[nl]; }
+        else if (n0 < a.nq + a.nkv) { wa = reinterpret_cast<const wfrag_t*>(a.w1) + (long)((n0 - a.nq) / 32) * tile_u4; if (WT) wscale0 = a.s1[nl - a.nq]; }
+        else { wa = reinterpret_cast<const wfrag_t*>(a.w2) + (long)((n0 - a.nq - a.nkv) / 32) * tile_u4; if (WT) wscale0 = a.s2[nl - a.nq - a.nkv]; }
     } else {
-        wa = reinterpret_cast<const uint4*>(a.w0) + (long)(n0 / 32) * tile_u4;
-        if (EPI == EPI_SWIGLU) wb = reinterpret_cast<const uint4*>(a.w1) + (long)(n0 / 32) * tile_u4;
+        wa = reinterpret_cast<const wfrag_t*>(a.w0) + (long)(n0 / 32) * tile_u4;
+        if (WT) wscale0 = a.s0[nl];
+        if (EPI == EPI_SWIGLU) { wb = reinterpret_cast<const wfrag_t*>(a.w1) + (long)(n0 / 32) * tile_u4; if (WT) wscale1 = a.s1[nl]; }
     }
     const bf16_t* xa = a.x + (long)mrow * a.x_row_stride + a.x_row_offset;
     // EPI_SLAB: gridDim.z blocks split K further; each writes its fp32 partial tile to slab[blockIdx.z]
@@ -257,7 +300,8 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K,
     if (kspan <= 256) {
         // short K span (decode-step projections at K = 1024): every load of the wave is issued before the
         // first MFMA -- one memory round trip instead of one per chunk
-        uint4 av[4][4], bv[4][4], cv[4][4];
+        uint4 av[4][4];
+        wfrag_t bv[4][4], cv[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int kc = kbeg + c * 64;
@@ -265,8 +309,8 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K,
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     av[c][q] = *reinterpret_cast<const uint4*>(xa + kc + h * 32 + q * 8);
-                    bv[c][q] = ldg16<true>(wa + ((kc >> 6) * 4 + q) * 64 + lane);
-                    if (EPI == EPI_SWIGLU) cv[c][q] = ldg16<true>(wb + ((kc >> 6) * 4 + q) * 64 + lane);
+                    bv[c][q] = wld(wa + ((kc >> 6) * 4 + q) * 64 + lane);
+                    if (EPI == EPI_SWIGLU) cv[c][q] = wld(wb + ((kc >> 6) * 4 + q) * 64 + lane);
                 }
             }
         }
@@ -275,21 +319,22 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K,
             if (c * 64 < kspan) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[c][q]), as_bf16x8(bv[c][q]), acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[c][q]), wfrag_bf16x8(bv[c][q]), acc0, 0, 0, 0);
                     if (EPI == EPI_SWIGLU)
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[c][q]), as_bf16x8(cv[c][q]), acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[c][q]), wfrag_bf16x8(cv[c][q]), acc1, 0, 0, 0);
                 }
             }
         }
     } else {
     // register double buffer: the loads of chunk c+1 are in flight while chunk c feeds the MFMAs
-    uint4 av[2][4], bv[2][4], cv[2][4];
+    uint4 av[2][4];
+    wfrag_t bv[2][4], cv[2][4];
     auto load = [&](int buf, int kc) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             av[buf][q] = *reinterpret_cast<const uint4*>(xa + kc + h * 32 + q * 8);
-            bv[buf][q] = ldg16<true>(wa + ((kc >> 6) * 4 + q) * 64 + lane);
-            if (EPI == EPI_SWIGLU) cv[buf][q] = ldg16<true>(wb + ((kc >> 6) * 4 + q) * 64 + lane);
+            bv[buf][q] = wld(wa + ((kc >> 6) * 4 + q) * 64 + lane);
+            if (EPI == EPI_SWIGLU) cv[buf][q] = wld(wb + ((kc >> 6) * 4 + q) * 64 + lane);
         }
     };
     load(0, kbeg);
@@ -297,17 +342,17 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K,
         if (kc + 64 < kend) load(1, kc + 64);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[0][q]), as_bf16x8(bv[0][q]), acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[0][q]), wfrag_bf16x8(bv[0][q]), acc0, 0, 0, 0);
             if (EPI == EPI_SWIGLU)
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[0][q]), as_bf16x8(cv[0][q]), acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[0][q]), wfrag_bf16x8(cv[0][q]), acc1, 0, 0, 0);
         }
         if (kc + 64 < kend) {
             if (kc + 128 < kend) load(0, kc + 128);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[1][q]), as_bf16x8(bv[1][q]), acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[1][q]), wfrag_bf16x8(bv[1][q]), acc0, 0, 0, 0);
                 if (EPI == EPI_SWIGLU)
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[1][q]), as_bf16x8(cv[1][q]), acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[1][q]), wfrag_bf16x8(cv[1][q]), acc1, 0, 0, 0);
             }
         }
     }
@@ -330,6 +375,7 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K,
             float s0 = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) s0 += red[0][w][reg][lane];       // fixed order: deterministic
+            if (WT) s0 *= wscale0;
             if (EPI == EPI_SLAB) {
                 if (m < a.M && n < a.N) a.slab[((long)kz * a.M + m) * a.N + n] = s0;
                 continue;
@@ -338,6 +384,7 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K,
             if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
                 for (int w = 0; w < NW; ++w) s1 += red[1][w][reg][lane];
+                if (WT) s1 *= wscale1;
             }
             mm_finish<EPI, HD>(a, m, n, s0, s1);
         }

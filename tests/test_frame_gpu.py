@@ -460,3 +460,32 @@ def test_layer0_qkv_table_gives_the_same_bits_as_computing_it(monkeypatch):
         del m
     for (l1, f1), (l0, f0) in zip(res["1"], res["0"]):
         assert torch.equal(l1, l0) and torch.equal(f1, f0)
+
+
+def test_fp8_stream_on_the_batched_path_equals_its_bf16_dequantisation_bitwise(monkeypatch):
+    """fp8 mode, B = 4 (matrix-core path): decode steps stream e4m3 bytes converted in registers, with the power-of-two
+    row scale applied to the fp32 sum.  The bf16 weights of that mode ARE the dequantised bytes, so streaming either
+    must give identical logits and frames (CSM_FP8_WIDE=0 keeps the bf16 stream)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sesameai.models import Model, csm_tiny_args, synthetic_state_dict
+    sd = synthetic_state_dict(csm_tiny_args(), seed=1234)
+    g = torch.Generator().manual_seed(8)
+    B, S = 4, 20
+    tok = torch.zeros(B, S, 33, dtype=torch.long); msk = torch.zeros(B, S, 33, dtype=torch.bool)
+    tok[:, :6, 32] = torch.randint(0, 1000, (B, 6), generator=g); msk[:, :6, 32] = True
+    tok[:, 6:, :32] = torch.randint(0, 2048, (B, S - 6, 32), generator=g); msk[:, 6:, :32] = True
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CSM_FP8_WIDE", flag)
+        m = Model(csm_tiny_args(), sd, max_frames=16, max_prefill_rows=B * S, weights_dtype="fp8")
+        m.setup_caches(B)
+        m.seed(5)
+        m.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+        _, logits = m.depth(B, 0.9, 50, want_logits=True, commit=True)
+        for _ in range(3):
+            m.step(B, 0.9, 50)
+        res[flag] = (logits.cpu(), m.read_frames(B)[0])
+        del m
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
+    assert res["1"][0].float().abs().max() > 0
