@@ -8,6 +8,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: libcsm_hip.so must bind to the HIP runtime torch has already loaded (its bundled
+#                         libamdhip64); loading ours before torch puts two runtimes in the process ("no ROCm-capable device")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcsm_hip.so")
 
