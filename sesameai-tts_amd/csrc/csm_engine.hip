@@ -168,24 +168,24 @@ static hipError_t launch_gemv8(int kind, int K, int hd, const GemvArgs& a, hipSt
 }
 
 // wide-M projections on the matrix cores; kind as in launch_gemv (0 store, 1 +residual, 3 qkv/rope, 4 swiglu)
-#define XCD_TILING_MIN_ROWS 256     // prompts with >= 8 row tiles: XCD-aware 1-D tile order (mm.cuh)
-static void mm_grid(const GemvArgs& a, int kg, dim3* grid, int* mt8) {
+// k_mm32 tile order (mm.cuh): one row tile -> plain 3-D grid; more -> n tiles per XCD with the row tiles adjacent
+static void mm_grid(const GemvArgs& a, int kg, dim3* grid, int* mtiles) {
     const int nt = (a.N + 31) / 32, mt = (a.M + 31) / 32;
-    if (a.M >= XCD_TILING_MIN_ROWS) { *mt8 = (mt + 7) / 8; *grid = dim3((unsigned)(8L * nt * kg * *mt8)); }
-    else { *mt8 = 0; *grid = dim3(nt, mt, kg); }
+    if (mt > 1) { *mtiles = mt; *grid = dim3((unsigned)(8L * ((nt + 7) / 8) * kg * mt)); }
+    else { *mtiles = 0; *grid = dim3(nt, mt, kg); }
 }
 template <int WT>
 static hipError_t launch_mm_t(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
     if (K % 256 != 0) return hipErrorInvalidValue;
-    dim3 grid; int mt8;
-    mm_grid(a, 1, &grid, &mt8);
+    dim3 grid; int mtiles;
+    mm_grid(a, 1, &grid, &mtiles);
     switch (kind) {
-        case 0: hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mt8, 1); break;
-        case 1: hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mt8, 1); break;
-        case 3: if (hd == 64) hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mt8, 1);
-                else hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 128, 4, WT>), grid, dim3(256), 0, st, a, K, mt8, 1);
+        case 0: hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mtiles, 1); break;
+        case 1: hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mtiles, 1); break;
+        case 3: if (hd == 64) hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mtiles, 1);
+                else hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 128, 4, WT>), grid, dim3(256), 0, st, a, K, mtiles, 1);
                 break;
-        case 4: hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mt8, 1); break;
+        case 4: hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mtiles, 1); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -238,10 +238,10 @@ static int slab_groups(int K, bool prompt) {
 }
 static hipError_t launch_mm_slab(int K, int kg, const GemvArgs& a, hipStream_t st, bool f8 = false) {
     if (K % (256 * kg) != 0) return hipErrorInvalidValue;
-    dim3 grid; int mt8;
-    mm_grid(a, kg, &grid, &mt8);
-    if (f8) hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4, 1>), grid, dim3(256), 0, st, a, K, mt8, kg);
-    else hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4, 0>), grid, dim3(256), 0, st, a, K, mt8, kg);
+    dim3 grid; int mtiles;
+    mm_grid(a, kg, &grid, &mtiles);
+    if (f8) hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4, 1>), grid, dim3(256), 0, st, a, K, mtiles, kg);
+    else hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4, 0>), grid, dim3(256), 0, st, a, K, mtiles, kg);
     return hipGetLastError();
 }
 static hipError_t launch_resid_norm(bf16_t* h, const float* slab, int kg, int M, int N, long row_step, long row_first, int M_out,
