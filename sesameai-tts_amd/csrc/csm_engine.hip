@@ -208,8 +208,12 @@ static hipError_t launch_g128_t(const GemvArgs& a, int K, hipStream_t st) {
         attr_set = true;
     }
     const int nout = EPI == EPI_SWIGLU ? 64 : 128;
-    const int mt8 = ((a.M + 127) / 128 + 7) / 8, ntiles = (a.N + nout - 1) / nout;
-    hipLaunchKernelGGL((k_gemm128<EPI, HD>), dim3((unsigned)(8L * ntiles * mt8)), dim3(256), G128_SMEM, st, a, K, mt8, (long)K);
+    const int mtiles = (a.M + 127) / 128, ntiles = (a.N + nout - 1) / nout;
+    static const int switch_tiles = getenv("CSM_G128_ROWTILES") ? atoi(getenv("CSM_G128_ROWTILES")) : 32;
+    int mt8; unsigned blocks;
+    if (mtiles >= switch_tiles) { mt8 = (mtiles + 7) / 8; blocks = (unsigned)(8L * ntiles * mt8); }          // row tiles per XCD
+    else { mt8 = -mtiles; blocks = (unsigned)(8L * ((ntiles + 7) / 8) * mtiles); }                            // column tiles per XCD
+    hipLaunchKernelGGL((k_gemm128<EPI, HD>), dim3(blocks), dim3(256), G128_SMEM, st, a, K, mt8, (long)K);
     return hipGetLastError();
 }
 static hipError_t launch_g128(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {

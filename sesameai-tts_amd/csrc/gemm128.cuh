@@ -34,14 +34,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const GemvArgs a, const int 
     bf16_t* lds = reinterpret_cast<bf16_t*>(g128_smem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware tile order (see k_mm32): XCD c owns row tiles {c, c+8, ...}; consecutive blocks of one XCD
-    // walk those row tiles for one column tile, so W tiles are fetched once per XCD and the XCD's share of x
-    // stays in its L2
+    // XCD-aware tile order (block L runs on XCD L % 8).  mt8 > 0 (thousands of rows): XCD c owns the row tiles
+    // {c, c+8, ...} (mt8 of them) and walks them for one column tile after the other -- its share of x stays in its
+    // L2 and each W tile is fetched once per XCD.  mt8 < 0 (-mt8 = row tiles, a few hundred to ~4,000 rows): XCD c
+    // owns the column tiles {c, c+8, ...} and runs all row tiles of one column tile back to back -- every XCD is
+    // busy whatever the row-tile count, the W tile stays in L2 and x streams from the Infinity Cache.
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    const int mt = (j % mt8) * 8 + xcd, nt = j / mt8;
+    int mt, nt;
+    if (mt8 > 0) { mt = (j % mt8) * 8 + xcd; nt = j / mt8; }
+    else { mt = j % (-mt8); nt = (j / (-mt8)) * 8 + xcd; }
     if (mt * 128 >= a.M) return;
     constexpr int NOUT = EPI == EPI_SWIGLU ? 64 : 128;      // output columns per block
     const int m0 = mt * 128, n0 = nt * NOUT;
+    if (n0 >= a.N) return;
 
     // this thread's four 16-byte pieces of each operand slice: rows (tid >> 3) + 32 i, segment tid & 7
     const int seg = tid & 7, row0 = tid >> 3;
