@@ -213,6 +213,7 @@ static hipError_t launch_g128_t(const GemvArgs& a, int K, hipStream_t st) {
     int mt8; unsigned blocks;
     if (mtiles >= switch_tiles) { mt8 = (mtiles + 7) / 8; blocks = (unsigned)(8L * ntiles * mt8); }          // row tiles per XCD
     else { mt8 = -mtiles; blocks = (unsigned)(8L * ((ntiles + 7) / 8) * mtiles); }                            // column tiles per XCD
+    if (EPI == EPI_SLAB) blocks *= 4;                                                                         // one block per K quarter
     hipLaunchKernelGGL((k_gemm128<EPI, HD>), dim3(blocks), dim3(256), G128_SMEM, st, a, K, mt8, (long)K);
     return hipGetLastError();
 }
@@ -221,6 +222,7 @@ static hipError_t launch_g128(int kind, int K, int hd, const GemvArgs& a, hipStr
     switch (kind) {
         case 0: return launch_g128_t<EPI_STORE, 64>(a, K, st);
         case 1: return launch_g128_t<EPI_RESID, 64>(a, K, st);
+        case 5: return launch_g128_t<EPI_SLAB, 64>(a, K, st);
         case 3: return hd == 64 ? launch_g128_t<EPI_QKV_ROPE, 64>(a, K, st) : launch_g128_t<EPI_QKV_ROPE, 128>(a, K, st);
         case 4: return launch_g128_t<EPI_SWIGLU, 64>(a, K, st);
     }
@@ -334,20 +336,37 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
             t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
             if ((e = launch_attn_auto(S, t, prompt, st)) != hipSuccess) return e;
             memset(&a, 0, sizeof a);
+            // residual projections: d/128 column tiles only -- below ~2 tiles per CU split K into its four quarters over
+            // blocks (fp32 slabs) and let the small path's finisher add them, the residual and the next norm
+            const bool quarter_slabs = (long)((M + 127) / 128) * ((d + 127) / 128) < 512 && d <= 2048;
             a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)w.wo; a.N = d; a.out = h; a.ldo = d; a.resid = h;
-            if ((e = launch_g128(1, S.nq, S.hd, a, st)) != hipSuccess) return e;
-            if ((e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+            if (quarter_slabs) {
+                a.slab = m->slab;
+                if ((e = launch_g128(5, S.nq, S.hd, a, st)) != hipSuccess) return e;
+                if ((e = launch_resid_norm(h, m->slab, 4, M, d, 1, 0, M, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+            } else {
+                if ((e = launch_g128(1, S.nq, S.hd, a, st)) != hipSuccess) return e;
+                if ((e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+            }
             memset(&a, 0, sizeof a);
             a.x = att; a.x_row_stride = d; a.M = M; a.w0 = (const bf16_t*)w.w1; a.w1 = (const bf16_t*)w.w3; a.N = S.d.ffn;
             a.out = act; a.ldo = S.d.ffn;
             if ((e = launch_g128(4, d, S.hd, a, st)) != hipSuccess) return e;
             memset(&a, 0, sizeof a);
             a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)w.w2; a.N = d; a.out = h; a.ldo = d; a.resid = h;
+            const int nseq = M / rows_per_seq;
+            if (quarter_slabs) {
+                a.slab = m->slab;
+                if ((e = launch_g128(5, S.d.ffn, S.hd, a, st)) != hipSuccess) return e;
+                if (l + 1 < S.d.n_layers) e = launch_resid_norm(h, m->slab, 4, M, d, 1, 0, M, (const bf16_t*)S.lw[l + 1].sa_norm, S.d.norm_eps, att, d, st);
+                else e = launch_resid_norm(h, m->slab, 4, M, d, rows_per_seq, rows_per_seq - 1, nseq, fin.scale, S.d.norm_eps, fin.out, fin.out_stride, st);
+                if (e != hipSuccess) return e;
+                continue;
+            }
             if ((e = launch_g128(1, S.d.ffn, S.hd, a, st)) != hipSuccess) return e;
             if (l + 1 < S.d.n_layers) {
                 if ((e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)S.lw[l + 1].sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
             } else {
-                const int nseq = M / rows_per_seq;
                 if ((e = launch_rmsnorm_rows(h, (long)rows_per_seq * d, (long)(rows_per_seq - 1) * d, nseq, d, fin.scale, S.d.norm_eps,
                                              fin.out, fin.out_stride, st)) != hipSuccess) return e;
             }

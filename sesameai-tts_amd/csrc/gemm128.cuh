@@ -39,7 +39,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const GemvArgs a, const int 
     // L2 and each W tile is fetched once per XCD.  mt8 < 0 (-mt8 = row tiles, a few hundred to ~4,000 rows): XCD c
     // owns the column tiles {c, c+8, ...} and runs all row tiles of one column tile back to back -- every XCD is
     // busy whatever the row-tile count, the W tile stays in L2 and x streams from the Infinity Cache.
-    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    // EPI_SLAB (residual projections when the tiles alone would not fill the chip): the grid is 4x larger and block
+    // (tile, kq) runs only K quarter kq, writing its fp32 partial to slab[kq]; k_resid_norm then adds the four slabs
+    // in quarter order -- the very association the one-block version uses, so the bits are the same.
+    int L = blockIdx.x, kq = 0;
+    if (EPI == EPI_SLAB) { kq = L & 3; L >>= 2; }
+    const int xcd = L & 7, j = L >> 3;
     int mt, nt;
     if (mt8 > 0) { mt = (j % mt8) * 8 + xcd; nt = j / mt8; }
     else { mt = j % (-mt8); nt = (j / (-mt8)) * 8 + xcd; }
@@ -96,12 +101,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const GemvArgs a, const int 
 #pragma unroll
             for (int i = 0; i < 16; ++i) { tot[mi][ni][i] = 0.f; acc[mi][ni][i] = 0.f; }
 
-    const int nk = K / 64, per_quarter = nk / 4;
-    G128_GLOAD(0)
-    G128_LWRITE(0)
+    const int per_quarter = K / 256;
+    const int c_first = EPI == EPI_SLAB ? kq * per_quarter : 0, nk = EPI == EPI_SLAB ? c_first + per_quarter : K / 64;
+    G128_GLOAD(c_first * 64)
+    G128_LWRITE(c_first & 1)
     __syncthreads();
     int in_quarter = 0;
-    for (int c = 0; c < nk; ++c) {
+    for (int c = c_first; c < nk; ++c) {
         // unconditional (the last iteration re-loads its own slice into the idle buffer): no control flow around the
         // register staging
         if (DBG != 1) { G128_GLOAD(min(c + 1, nk - 1) * 64) }
@@ -139,6 +145,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const GemvArgs a, const int 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int m = m0 + wm * 64 + mi * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+                if (EPI == EPI_SLAB) {
+                    const int n = n0 + wn * 64 + ni * 32 + r;
+                    if (m < a.M && n < a.N) a.slab[((long)kq * a.M + m) * a.N + n] = tot[mi][ni][i];
+                    continue;
+                }
                 if (EPI == EPI_SWIGLU) mm_finish<EPI, HD>(a, m, n0 + wn * 32 + r, tot[mi][0][i], tot[mi][1][i]);
                 else mm_finish<EPI, HD>(a, m, n0 + wn * 64 + ni * 32 + r, tot[mi][ni][i], 0.f);
             }
