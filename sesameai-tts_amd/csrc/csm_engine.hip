@@ -413,8 +413,16 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = d; a.M = M; a.w0 = (const bf16_t*)pk.w1; a.w1 = (const bf16_t*)pk.w3; a.N = S.d.ffn;
         a.out = act; a.ldo = S.d.ffn;
-        if (f8) { a.w0 = (const bf16_t*)p8.w1; a.w1 = (const bf16_t*)p8.w3; a.s0 = (const float*)S.w8s[l].w1; a.s1 = (const float*)S.w8s[l].w3; }
-        if ((e = launch_mm(4, d, S.hd, a, st, f8)) != hipSuccess) return e;
+        static const int g128_gateup_rows = getenv("CSM_G128_GATEUP_ROWS") ? atoi(getenv("CSM_G128_GATEUP_ROWS")) : 256;   // measured: B=256 15.6 -> 13.8 ms, B=128 10.3 -> 10.5 (no gain below 2 x 128 rows)
+        if (M >= g128_gateup_rows) {
+            // 8+ row tiles: the widest projection (N = 2 ffn) has enough 128 x 128 tiles for the LDS-tiled kernel, which
+            // reads each weight tile once per 128 rows instead of once per 32 (same bits as k_mm32)
+            a.w0 = (const bf16_t*)w.w1; a.w1 = (const bf16_t*)w.w3;
+            if ((e = launch_g128(4, d, S.hd, a, st)) != hipSuccess) return e;
+        } else {
+            if (f8) { a.w0 = (const bf16_t*)p8.w1; a.w1 = (const bf16_t*)p8.w3; a.s0 = (const float*)S.w8s[l].w1; a.s1 = (const float*)S.w8s[l].w3; }
+            if ((e = launch_mm(4, d, S.hd, a, st, f8)) != hipSuccess) return e;
+        }
         // down-proj -> slabs; finisher applies the NEXT layer's sa_norm (or nothing after the last layer)
         memset(&a, 0, sizeof a);
         a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)pk.w2; a.N = d; a.slab = m->slab;
