@@ -187,3 +187,39 @@ def test_voice_registry_discovers_pt_prompts_and_samples_module(tmp_path):
     assert tts.list_voices() == ["bob", "alice"] or set(tts.list_voices()) == {"alice", "bob"}
     with pytest.raises(ValueError, match="not found"):
         tts.load_voice("carol")
+
+
+def test_prompt_assembly_properties_hypothesis():
+    """for arbitrary segments the (S,33) prompt keeps the reference's layout rules
+    (sesameai/generator.py:63-109): text rows carry the id in column 32 only; audio rows carry 32 codes in columns
+    0..31 only; every audio segment ends with an all-zero EOS frame; rows appear in segment order."""
+    from hypothesis import given, settings, strategies as st
+    from sesameai.generator import Generator, Segment
+
+    gen = Generator.__new__(Generator)
+    gen.device, gen._text_tokenizer, gen._audio_tokenizer = torch.device("cpu"), None, None
+
+    seg = st.tuples(st.lists(st.integers(0, 128255), min_size=1, max_size=12), st.integers(1, 9), st.integers(0, 2 ** 31 - 1))
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.lists(seg, min_size=0, max_size=4), st.lists(st.integers(0, 128255), min_size=1, max_size=10))
+    def check(segments, text):
+        ctx, want_rows = [], 0
+        for ids, frames, seed in segments:
+            codes = torch.randint(0, 2048, (32, frames), generator=torch.Generator().manual_seed(seed))
+            ctx.append(Segment(speaker=0, text=ids, audio_codes=codes))
+            want_rows += len(ids) + frames + 1
+        tok, msk = gen._build_prompt(text, 0, ctx)
+        assert tok.shape == msk.shape == (want_rows + len(text), 33) and tok.dtype == torch.long and msk.dtype == torch.bool
+        row = 0
+        for (ids, frames, seed), s in zip(segments, ctx):
+            t = tok[row:row + len(ids)]; m = msk[row:row + len(ids)]
+            assert t[:, 32].tolist() == ids and bool(m[:, 32].all()) and not bool(m[:, :32].any()) and int(t[:, :32].abs().sum()) == 0
+            row += len(ids)
+            a = tok[row:row + frames + 1]; am = msk[row:row + frames + 1]
+            assert torch.equal(a[:frames, :32], s.audio_codes.t()) and int(a[frames].abs().sum()) == 0      # EOS frame
+            assert bool(am[:, :32].all()) and not bool(am[:, 32].any()) and int(a[:, 32].abs().sum()) == 0
+            row += frames + 1
+        assert tok[row:, 32].tolist() == text and bool(msk[row:, 32].all()) and not bool(msk[row:, :32].any())
+
+    check()
