@@ -112,45 +112,56 @@ __device__ __forceinline__ void stage_attn(bf16_t* xs, float* ps /*[4 waves][2][
             const bf16_t* vb = a.vcache + ((long)b * a.kv_heads + kvh) * a.smax * HD;
             const uint4 qa = *reinterpret_cast<const uint4*>(a.aq + ((long)mrow * a.aH + h) * HD + sub * 8);
             const uint4 qb = *reinterpret_cast<const uint4*>(a.aq + ((long)mrow * a.aH + h + 1) * HD + sub * 8);
+            // nk (= position + 1) is the same for every lane: whole 4-key groups beyond it are skipped by uniform
+            // branches -- on average half of the loads, dots and P.V terms of a decoder step (positions 1..31)
             uint4 kv[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)                 // keys beyond the cache's written part are masked below
-                kv[i] = reinterpret_cast<const uint4*>(kb)[i * 64 + lane];
+            for (int i = 0; i < 8; ++i)
+                if (4 * i < nk) kv[i] = reinterpret_cast<const uint4*>(kb)[i * 64 + lane];
             uint32_t vv[32];
 #pragma unroll
-            for (int t = 0; t < 32; ++t) vv[t] = reinterpret_cast<const uint32_t*>(vb + (long)t * HD)[lane];
+            for (int t = 0; t < 32; ++t)
+                if ((t & ~3) < nk) vv[t] = reinterpret_cast<const uint32_t*>(vb + (long)t * HD)[lane];
             float s0[8], s1[8], mx0 = -INFINITY, mx1 = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const bool live = (4 * i + grp) < nk;
-                s0[i] = live ? row16_sum(dot8(qa, kv[i], 0.f)) * a.ascale : -INFINITY;
-                s1[i] = live ? row16_sum(dot8(qb, kv[i], 0.f)) * a.ascale : -INFINITY;
-                mx0 = fmaxf(mx0, s0[i]); mx1 = fmaxf(mx1, s1[i]);
+                s0[i] = -INFINITY; s1[i] = -INFINITY;
+                if (4 * i < nk) {
+                    const bool live = (4 * i + grp) < nk;
+                    const float d0 = row16_sum(dot8(qa, kv[i], 0.f)) * a.ascale, d1 = row16_sum(dot8(qb, kv[i], 0.f)) * a.ascale;
+                    s0[i] = live ? d0 : -INFINITY;
+                    s1[i] = live ? d1 : -INFINITY;
+                    mx0 = fmaxf(mx0, s0[i]); mx1 = fmaxf(mx1, s1[i]);
+                }
             }
             mx0 = wave_max(mx0); mx1 = wave_max(mx1);
             float l0 = 0.f, l1 = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                s0[i] = (s0[i] == -INFINITY) ? 0.f : __expf(s0[i] - mx0);
-                s1[i] = (s1[i] == -INFINITY) ? 0.f : __expf(s1[i] - mx1);
-                l0 += s0[i]; l1 += s1[i];
-                if (sub == 0) { myps[4 * i + grp] = s0[i]; myps[32 + 4 * i + grp] = s1[i]; }
+                if (4 * i < nk) {
+                    s0[i] = (s0[i] == -INFINITY) ? 0.f : __expf(s0[i] - mx0);
+                    s1[i] = (s1[i] == -INFINITY) ? 0.f : __expf(s1[i] - mx1);
+                    l0 += s0[i]; l1 += s1[i];
+                    if (sub == 0) { myps[4 * i + grp] = s0[i]; myps[32 + 4 * i + grp] = s1[i]; }
+                }
             }
             l0 = wave_sum(l0) * (1.0f / 16.0f);          // every key is replicated over the 16 lanes of its row
             l1 = wave_sum(l1) * (1.0f / 16.0f);
             float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
 #pragma unroll
             for (int t4 = 0; t4 < 8; ++t4) {            // same-address LDS reads broadcast
-                const float4 pa = *reinterpret_cast<const float4*>(myps + 4 * t4);
-                const float4 pb = *reinterpret_cast<const float4*>(myps + 32 + 4 * t4);
-                const float pav[4] = {pa.x, pa.y, pa.z, pa.w}, pbv[4] = {pb.x, pb.y, pb.z, pb.w};
+                if (4 * t4 < nk) {
+                    const float4 pa = *reinterpret_cast<const float4*>(myps + 4 * t4);
+                    const float4 pb = *reinterpret_cast<const float4*>(myps + 32 + 4 * t4);
+                    const float pav[4] = {pa.x, pa.y, pa.z, pa.w}, pbv[4] = {pb.x, pb.y, pb.z, pb.w};
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    // rows beyond nk hold stale cache data: p is exactly 0 there, but guard NaN/Inf bit patterns
-                    const uint32_t raw = (4 * t4 + u) < nk ? vv[4 * t4 + u] : 0u;
-                    const float v0 = lo2f(raw), v1 = hi2f(raw);
-                    o00 += pav[u] * v0; o01 += pav[u] * v1;
-                    o10 += pbv[u] * v0; o11 += pbv[u] * v1;
+                    for (int u = 0; u < 4; ++u) {
+                        // rows beyond nk hold stale cache data: p is exactly 0 there, but guard NaN/Inf bit patterns
+                        const uint32_t raw = (4 * t4 + u) < nk ? vv[4 * t4 + u] : 0u;
+                        const float v0 = lo2f(raw), v1 = hi2f(raw);
+                        o00 += pav[u] * v0; o01 += pav[u] * v1;
+                        o10 += pbv[u] * v0; o11 += pbv[u] * v1;
+                    }
                 }
             }
             const float i0 = 1.0f / l0, i1 = 1.0f / l1;
