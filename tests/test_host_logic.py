@@ -223,3 +223,26 @@ def test_prompt_assembly_properties_hypothesis():
         assert tok[row:, 32].tolist() == text and bool(msk[row:, 32].all()) and not bool(msk[row:, :32].any())
 
     check()
+
+
+def test_local_tokenizer_json_gets_the_reference_bos_eos_template(tmp_path):
+    """reference generator.py:24-38: the Llama-3 tokenizer with a TemplateProcessing that wraps every text in
+    <|begin_of_text|> ... <|end_of_text|>; `_tokenize_text_segment` encodes "[speaker]text" (generator.py:67).
+    No hub access here, so a small WordLevel tokenizer.json with the same special tokens stands in for the real file."""
+    from tokenizers import Tokenizer
+    from tokenizers.models import WordLevel
+    from tokenizers.pre_tokenizers import Whitespace
+    from sesameai.generator import Generator, load_llama3_tokenizer
+    vocab = {"[UNK]": 0, "<|begin_of_text|>": 1, "<|end_of_text|>": 2, "[": 3, "]": 4, "1": 5, "hello": 6, "there": 7}
+    tok = Tokenizer(WordLevel(vocab, unk_token="[UNK]")); tok.pre_tokenizer = Whitespace()
+    path = str(tmp_path / "tokenizer.json"); tok.save(path)
+    assert load_llama3_tokenizer(str(tmp_path / "missing.json")) is None
+    t = load_llama3_tokenizer(path)
+    assert t.encode("hello there").ids == [1, 6, 7, 2]
+    gen = Generator.__new__(Generator)
+    gen.device, gen._text_tokenizer, gen._audio_tokenizer = torch.device("cpu"), t, None
+    frame, mask = gen._tokenize_text_segment("hello there", 1)
+    assert frame[:, 32].tolist() == [1, 3, 5, 4, 6, 7, 2] and bool(mask[:, 32].all()) and not bool(mask[:, :32].any())
+    gen._text_tokenizer = None
+    with pytest.raises(RuntimeError, match="no text tokenizer"):
+        gen._tokenize_text_segment("hello", 1)

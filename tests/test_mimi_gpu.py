@@ -167,3 +167,52 @@ def test_generator_end_to_end_tiny(tiny_codec):
         gen.generate(list(range(300)), 1, [], max_audio_length_ms=150_000)
     with pytest.raises(ValueError, match="Inputs too long"):
         next(gen.generate_stream(list(range(300)), 1, [], max_audio_length_ms=150_000))
+
+
+def test_tts_service_cli_surface_end_to_end_tiny(tiny_codec, tmp_path):
+    """The trimmed CLI class (sesameai-tts_amd/tts_service.py) with the reference's method names: voice prompt from a
+    WAV file through the GPU Mimi encoder, context caching, sentence-wise export with silences/fades, 24 kHz int16 WAV."""
+    import importlib.util
+    import wave
+    import numpy as np
+    from tokenizers import Tokenizer
+    from tokenizers.models import WordLevel
+    from tokenizers.pre_tokenizers import Whitespace
+    from sesameai.generator import Generator, load_llama3_tokenizer
+    from dataclasses import replace
+    from sesameai.mimi import MimiCodec, mimi_tiny_args
+    from sesameai.models import FLAVORS, Model, ModelArgs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("tts_service_amd3", os.path.join(root, "sesameai-tts_amd", "tts_service.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    codec = MimiCodec(mimi_tiny_args(), None, max_frames=400)       # a segment may run its full 30 s = 375 frames
+    words = "i'm getting all warmed up for our chatting to begin hello there how are you".replace("'", " ' ").split()
+    vocab = {"[UNK]": 0, "<|begin_of_text|>": 1, "<|end_of_text|>": 2, "[": 3, "]": 4, "1": 5, ".": 6, "?": 7, "'": 8}
+    for wd in words:
+        vocab.setdefault(wd, len(vocab))
+    tok = Tokenizer(WordLevel(vocab, unk_token="[UNK]")); tok.pre_tokenizer = Whitespace()
+    tok.save(str(tmp_path / "tokenizer.json"))
+    # a 0.4 s stereo 16 kHz prompt recording
+    sr = 16000
+    t = np.arange(int(0.4 * sr)) / sr
+    pcm = (np.stack([0.3 * np.sin(2 * np.pi * 220 * t), 0.3 * np.sin(2 * np.pi * 330 * t)], 1) * 32767).astype("<i2")
+    with wave.open(str(tmp_path / "prompt.wav"), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(sr); f.writeframes(pcm.tobytes())
+    (tmp_path / "samples.py").write_text(f"alice = {{{str(tmp_path / 'prompt.wav')!r}: 'hello there'}}\n")
+    tts = mod.TTS(voice_dir=str(tmp_path))
+    FLAVORS["llama-tiny-bb-2k"] = replace(FLAVORS["llama-tiny-bb"], max_seq_len=2048)       # the CLI assumes 2048 positions
+    model = Model(ModelArgs("llama-tiny-bb-2k", "llama-tiny-dec", 1000, 2051, 32), None, max_frames=512, max_prefill_rows=128)
+    tts.generator = Generator(model, audio_tokenizer=codec, text_tokenizer=load_llama3_tokenizer(str(tmp_path / "tokenizer.json")))
+    assert tts.list_voices() == ["alice"]
+    tts.load_voice("alice")                                  # encodes the WAV with Mimi, caches the context, warms up
+    assert len(tts.cached_context_tokens) == 1 and tts.cached_context_tokens[0].shape[1] == 33
+    n_audio_rows = int(tts.cached_context_masks[0][:, 0].sum())
+    assert n_audio_rows == 5 + 1                             # ceil(0.4 s * 12.5) = 5 frames + the all-zero EOS frame
+    out = str(tmp_path / "out.wav")
+    tts.export_wav("hello there. how are you?", out, temperature=0.9, topk=20)
+    with wave.open(out, "rb") as f:
+        assert (f.getnchannels(), f.getsampwidth(), f.getframerate()) == (1, 2, 24000)
+        n = f.getnframes()
+        data = np.frombuffer(f.readframes(n), dtype="<i2")
+    assert n >= 2 * int(0.6 * 24000)                         # two sentences, each with 500 ms lead + 100 ms tail silence
+    assert int(np.abs(data[:1000]).max()) == 0 and int(np.abs(data).max()) > 1000
