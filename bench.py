@@ -185,13 +185,21 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    # BENCH_SHARE_GPU0=1 (debug only, never a valid measurement): every rank uses cuda:0 over gloo, which lets the
+    # multi-rank control flow (weight broadcast, barriers, max-over-ranks timing) be exercised on a 1-GPU box
+    share0 = os.environ.get("BENCH_SHARE_GPU0") == "1"
+    if share0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share0:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from sesameai.models import Model, csm_1b_args, csm_tiny_args, state_dict_layout, synthetic_state_dict
     log(f"rank {rank}/{world}: building weights")
@@ -326,7 +334,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.weights == "bf16" else "bf16 activations, fp8-e4m3 weights (decode step)",
-        "data": "synthetic (seeded random weights of CSM-1B shapes, seeded random prompts)",
+        "data": "synthetic (seeded random weights of CSM-1B shapes, seeded random prompts)" + (" -- DEBUG: ranks share one GPU" if share0 else ""),
         "config": {"workload": ("tiny plumbing check" if args.tiny else
                                 f"CSM-1B single utterance per GPU (B={B}), one voice-prompt segment, S={S} prompt rows, "
                                 f"{args.steps} frames, T={args.temperature} top-k {args.topk}, "
