@@ -22,6 +22,7 @@ struct AttnArgs {
     float scale;
     bf16_t* out;            // [M][H*HD]                 (nsplit == 1)
     float* part;            // [M][H][nsplit][HD + 4]    (nsplit  > 1): o[HD], m, l
+    int out_packed;         // out in matrix-core operand order (common.cuh xp_off), K = H*HD
 };
 
 // U = key rows per lane in flight per batch (hd 128 / depth decoder: 8, so its <= 32 keys are ONE round trip)
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
                 uint4 r;
                 r.x = pack_bf(o[0] * inv, o[1] * inv); r.y = pack_bf(o[2] * inv, o[3] * inv);
                 r.z = pack_bf(o[4] * inv, o[5] * inv); r.w = pack_bf(o[6] * inv, o[7] * inv);
-                *reinterpret_cast<uint4*>(a.out + ((long)m * a.H + h) * HD + e * 8) = r;
+                bf16_t* dst = a.out_packed ? a.out + xp_off(m, h * HD + e * 8, (long)a.H * HD) : a.out + ((long)m * a.H + h) * HD + e * 8;
+                *reinterpret_cast<uint4*>(dst) = r;
             } else {
                 float* dst = a.part + (((long)m * a.H + h) * a.nsplit + sp) * (HD + 4);
                 *reinterpret_cast<float4*>(dst + e * 8) = make_float4(o[0], o[1], o[2], o[3]);
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
 
 // merges the nsplit partial softmax states of one (row, head): grid (M, H), block HD threads
 template <int HD>
-__global__ void k_attn_combine(const float* part, int nsplit, bf16_t* out, int H) {
+__global__ void k_attn_combine(const float* part, int nsplit, bf16_t* out, int H, int out_packed) {
     const int m = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
     const float* src = part + ((long)m * H + h) * nsplit * (HD + 4);
     float mx = -INFINITY;
@@ -122,5 +124,5 @@ __global__ void k_attn_combine(const float* part, int nsplit, bf16_t* out, int H
         num += w * src[s * (HD + 4) + t];
         den += w * src[s * (HD + 4) + HD + 1];
     }
-    out[((long)m * H + h) * HD + t] = f2bf(num / den);
+    out[out_packed ? xp_off(m, h * HD + t, (long)H * HD) : ((long)m * H + h) * HD + t] = f2bf(num / den);
 }

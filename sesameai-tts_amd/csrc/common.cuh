@@ -128,3 +128,12 @@ __device__ __forceinline__ void rmsnorm_row_wave(const bf16_t* x, int K, const b
         reinterpret_cast<uint4*>(out)[c] = o;
     }
 }
+
+// Activations of the batched DECODE steps are stored in matrix-core operand order (like the packed weights): row m,
+// column k of a [rows][K] buffer lives at xp_off(m, k, K).  Inside a 32-row tile the 16-byte piece (chunk, q, h, r)
+// is at ((chunk*4 + q)*64 + h*32 + r), i.e. exactly the piece lane (r, h) feeds to v_mfma_f32_32x32x16_bf16 at step q
+// of chunk `chunk` -- the consumer's wave load is one contiguous 1 KB read instead of a 64-cache-line gather
+// (gate/up 9.25 -> 8.60 us, down 6.61 -> 6.23, o-proj 3.49 -> 3.32 at M = 32).
+__device__ __forceinline__ long xp_off(int m, int k, long K) {
+    return (long)(m >> 5) * 32 * K + ((((long)(k >> 6) * 4 + ((k & 31) >> 3)) * 64 + ((k >> 5) & 1) * 32 + (m & 31)) << 3) + (k & 7);
+}

@@ -69,6 +69,7 @@ struct CsmModel {
     int host_frames;                    // frames launched since reset (host mirror)
     int wide_path;                      // MFMA path for M >= wide_min (env CSM_WIDE=0 disables)
     int wide_min;                       // WIDE_MIN_ROWS unless env CSM_WIDE_MIN overrides (tuning knob)
+    int xpack;                          // batched decode steps keep activations in operand order (env CSM_XPACK=0 disables)
     int fp8_wide;                       // fp8 mode: batched decode steps stream e4m3 on the matrix-core path too (env CSM_FP8_WIDE=0 disables)
     int fuse_dec_attn;                  // depth-decoder attention fused into the O-projection (env CSM_FUSE_DEC_ATTN=0 disables)
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
@@ -174,25 +175,27 @@ static void mm_grid(const GemvArgs& a, int kg, dim3* grid, int* mtiles) {
     if (mt > 1) { *mtiles = mt; *grid = dim3((unsigned)(8L * ((nt + 7) / 8) * kg * mt)); }
     else { *mtiles = 0; *grid = dim3(nt, mt, kg); }
 }
-template <int WT>
+template <int WT, bool XP>
 static hipError_t launch_mm_t(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
     if (K % 256 != 0) return hipErrorInvalidValue;
     dim3 grid; int mtiles;
     mm_grid(a, 1, &grid, &mtiles);
     switch (kind) {
-        case 0: hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mtiles, 1); break;
-        case 1: hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mtiles, 1); break;
-        case 3: if (hd == 64) hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mtiles, 1);
-                else hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 128, 4, WT>), grid, dim3(256), 0, st, a, K, mtiles, 1);
+        case 0: hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4, WT, XP>), grid, dim3(256), 0, st, a, K, mtiles, 1); break;
+        case 1: hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4, WT, XP>), grid, dim3(256), 0, st, a, K, mtiles, 1); break;
+        case 3: if (hd == 64) hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 64, 4, WT, XP>), grid, dim3(256), 0, st, a, K, mtiles, 1);
+                else hipLaunchKernelGGL((k_mm32<EPI_QKV_ROPE, 128, 4, WT, XP>), grid, dim3(256), 0, st, a, K, mtiles, 1);
                 break;
-        case 4: hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4, WT>), grid, dim3(256), 0, st, a, K, mtiles, 1); break;
+        case 4: hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4, WT, XP>), grid, dim3(256), 0, st, a, K, mtiles, 1); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 // f8: w0/w1/w2 are k_pack_w8 copies of the e4m3 stream and s0/s1/s2 the per-row scales
-static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStream_t st, bool f8 = false) {
-    return f8 ? launch_mm_t<1>(kind, K, hd, a, st) : launch_mm_t<0>(kind, K, hd, a, st);
+// xp: a.x is in matrix-core operand order (common.cuh xp_off; x_row_stride = K), as the decode-step producers write it
+static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStream_t st, bool f8 = false, bool xp = false) {
+    if (xp) return f8 ? launch_mm_t<1, true>(kind, K, hd, a, st) : launch_mm_t<0, true>(kind, K, hd, a, st);
+    return f8 ? launch_mm_t<1, false>(kind, K, hd, a, st) : launch_mm_t<0, false>(kind, K, hd, a, st);
 }
 
 // long prompts / batched prefill: LDS-tiled 128 x 128 kernel (gemm128.cuh); weights UNPACKED [N][K]
@@ -242,22 +245,27 @@ static int slab_groups(int K, bool prompt) {
     int kg = K / per_block;
     return kg < 1 ? 1 : (kg > 8 ? 8 : kg);
 }
-static hipError_t launch_mm_slab(int K, int kg, const GemvArgs& a, hipStream_t st, bool f8 = false) {
+static hipError_t launch_mm_slab(int K, int kg, const GemvArgs& a, hipStream_t st, bool f8 = false, bool xp = false) {
     if (K % (256 * kg) != 0) return hipErrorInvalidValue;
     dim3 grid; int mtiles;
     mm_grid(a, kg, &grid, &mtiles);
-    if (f8) hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4, 1>), grid, dim3(256), 0, st, a, K, mtiles, kg);
+    if (xp) {
+        if (f8) hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4, 1, true>), grid, dim3(256), 0, st, a, K, mtiles, kg);
+        else hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4, 0, true>), grid, dim3(256), 0, st, a, K, mtiles, kg);
+    } else if (f8) hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4, 1>), grid, dim3(256), 0, st, a, K, mtiles, kg);
     else hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4, 0>), grid, dim3(256), 0, st, a, K, mtiles, kg);
     return hipGetLastError();
 }
 static hipError_t launch_resid_norm(bf16_t* h, const float* slab, int kg, int M, int N, long row_step, long row_first, int M_out,
-                                    const bf16_t* scale, float eps, bf16_t* xn, long xn_stride, hipStream_t st, bool prompt = true) {
-    if (!prompt && M_out <= 64 && (N == 1024 || N == 2048 || N == 512)) {
+                                    const bf16_t* scale, float eps, bf16_t* xn, long xn_stride, hipStream_t st, bool prompt = true,
+                                    bool xn_packed = false) {
+    if (!prompt && (M_out <= 64 || xn_packed) && (N == 1024 || N == 2048 || N == 512)) {
         // decode steps: one block per row (mm.cuh k_resid_norm_row)
-        if (N == 2048) hipLaunchKernelGGL((k_resid_norm_row<8>), dim3(M_out), dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, scale, eps, xn, xn_stride);
-        else hipLaunchKernelGGL((k_resid_norm_row<4>), dim3(M_out), dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, scale, eps, xn, xn_stride);
+        if (N == 2048) hipLaunchKernelGGL((k_resid_norm_row<8>), dim3(M_out), dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, scale, eps, xn, xn_stride, (int)xn_packed);
+        else hipLaunchKernelGGL((k_resid_norm_row<4>), dim3(M_out), dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, scale, eps, xn, xn_stride, (int)xn_packed);
         return hipGetLastError();
     }
+    if (xn_packed) return hipErrorInvalidValue;
     dim3 grid((M_out + 3) / 4);
     if (N <= 512) hipLaunchKernelGGL((k_resid_norm<1>), grid, dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, M_out, scale, eps, xn, xn_stride);
     else if (N <= 1024) hipLaunchKernelGGL((k_resid_norm<2>), grid, dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, M_out, scale, eps, xn, xn_stride);
@@ -281,8 +289,8 @@ static hipError_t launch_attn(int hd, const AttnArgs& a, hipStream_t st, bool co
     }
     else return hipErrorInvalidValue;
     if (a.nsplit > 1 && combine) {
-        if (hd == 64) hipLaunchKernelGGL((k_attn_combine<64>), dim3(a.M, a.H), dim3(64), 0, st, a.part, a.nsplit, a.out, a.H);
-        else hipLaunchKernelGGL((k_attn_combine<128>), dim3(a.M, a.H), dim3(128), 0, st, a.part, a.nsplit, a.out, a.H);
+        if (hd == 64) hipLaunchKernelGGL((k_attn_combine<64>), dim3(a.M, a.H), dim3(64), 0, st, a.part, a.nsplit, a.out, a.H, a.out_packed);
+        else hipLaunchKernelGGL((k_attn_combine<128>), dim3(a.M, a.H), dim3(128), 0, st, a.part, a.nsplit, a.out, a.H, a.out_packed);
     }
     return hipGetLastError();
 }
@@ -303,6 +311,9 @@ static hipError_t launch_attn_auto(const Stack& S, const AttnArgs& t, bool promp
     }
     return launch_attn(S.hd, t, st);
 }
+
+// rows from which batched decode runs gate/up through k_gemm128 (measured: B=256 15.6 -> 13.8 ms, B=128 10.3 -> 10.5: no gain below 2 x 128 rows)
+static const int g128_gateup_rows = getenv("CSM_G128_GATEUP_ROWS") ? atoi(getenv("CSM_G128_GATEUP_ROWS")) : 256;
 
 // where the stack's final RMSNorm of each sequence's LAST row goes on the wide path (fused into the last finisher)
 struct FinalNorm { const bf16_t* scale; bf16_t* out; long out_stride; };
@@ -333,7 +344,7 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
             AttnArgs t;
             t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
             t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = 1;
-            t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
+            t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part; t.out_packed = 0;
             if ((e = launch_attn_auto(S, t, prompt, st)) != hipSuccess) return e;
             memset(&a, 0, sizeof a);
             // residual projections: d/128 column tiles only -- below ~2 tiles per CU split K into its four quarters over
@@ -376,6 +387,11 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         // dequantisation: identical bits, half the bytes); prompts keep the bf16 stream they share with k_gemm128
         const bool f8 = S.has_pk8 && !prompt && m->fp8_wide;
         const CsmLayerWeights& p8 = S.pk8[l];
+        // decode steps keep their activations (xn, attention output, SiLU*up) in matrix-core operand order between
+        // the kernels of a layer (common.cuh xp_off): producers write it, consumers read 1 KB pieces
+        // (from 24 rows: a 1 KB piece always carries 32 rows, so for a few rows the row-major gather touches fewer lines:
+        //  B=8 5.39 vs 5.52 ms packed, B=32 6.15 vs 6.01, B=64 7.42 vs 6.93, B=128 10.29 vs 9.07)
+        const bool xp = m->xpack && !prompt && rows_per_seq <= 2 && M >= 24 && M < g128_gateup_rows && (d == 512 || d == 1024 || d == 2048);
         // layer 0 normalises h directly; later layers got xn from the previous down-projection's finisher.
         // (layer 0 of a depth-decoder step >= 2: q/k/v were gathered from the precomputed table by the sampler)
         if (!(l == 0 && qkv0_done)) {
@@ -390,12 +406,12 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
                 a.w0 = (const bf16_t*)p8.wq; a.w1 = (const bf16_t*)p8.wk; a.w2 = (const bf16_t*)p8.wv;
                 a.s0 = (const float*)S.w8s[l].wq; a.s1 = (const float*)S.w8s[l].wk; a.s2 = (const float*)S.w8s[l].wv;
             }
-            if ((e = launch_mm(3, d, S.hd, a, st, f8)) != hipSuccess) return e;
+            if ((e = launch_mm(3, d, S.hd, a, st, f8, xp && l > 0)) != hipSuccess) return e;   // layer 0's input comes row-major
         }
         AttnArgs t;
         t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
         t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = 1;
-        t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
+        t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part; t.out_packed = xp;
         // batched backbone decode step (one row per sequence, long key ranges): a (row, KV head) block alone walks
         // its ~200+ keys in ~8 dependent round trips -- split the keys over up to 8 blocks like the B = 1 path
         if (!prompt && rows_per_seq == 1 && &S == &m->bb && M <= m->part_rows) {
@@ -408,12 +424,11 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)pk.wo; a.N = d; a.slab = m->slab;
         int kg = slab_groups(S.nq, prompt);
         if (f8) { a.w0 = (const bf16_t*)p8.wo; a.s0 = (const float*)S.w8s[l].wo; }
-        if ((e = launch_mm_slab(S.nq, kg, a, st, f8)) != hipSuccess) return e;
-        if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st, prompt)) != hipSuccess) return e;
+        if ((e = launch_mm_slab(S.nq, kg, a, st, f8, xp)) != hipSuccess) return e;
+        if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st, prompt, xp)) != hipSuccess) return e;
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = d; a.M = M; a.w0 = (const bf16_t*)pk.w1; a.w1 = (const bf16_t*)pk.w3; a.N = S.d.ffn;
-        a.out = act; a.ldo = S.d.ffn;
-        static const int g128_gateup_rows = getenv("CSM_G128_GATEUP_ROWS") ? atoi(getenv("CSM_G128_GATEUP_ROWS")) : 256;   // measured: B=256 15.6 -> 13.8 ms, B=128 10.3 -> 10.5 (no gain below 2 x 128 rows)
+        a.out = act; a.ldo = S.d.ffn; a.out_packed = xp;
         if (M >= g128_gateup_rows) {
             // 8+ row tiles: the widest projection (N = 2 ffn) has enough 128 x 128 tiles for the LDS-tiled kernel, which
             // reads each weight tile once per 128 rows instead of once per 32 (same bits as k_mm32)
@@ -421,16 +436,16 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
             if ((e = launch_g128(4, d, S.hd, a, st)) != hipSuccess) return e;
         } else {
             if (f8) { a.w0 = (const bf16_t*)p8.w1; a.w1 = (const bf16_t*)p8.w3; a.s0 = (const float*)S.w8s[l].w1; a.s1 = (const float*)S.w8s[l].w3; }
-            if ((e = launch_mm(4, d, S.hd, a, st, f8)) != hipSuccess) return e;
+            if ((e = launch_mm(4, d, S.hd, a, st, f8, xp)) != hipSuccess) return e;
         }
         // down-proj -> slabs; finisher applies the NEXT layer's sa_norm (or nothing after the last layer)
         memset(&a, 0, sizeof a);
         a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)pk.w2; a.N = d; a.slab = m->slab;
         kg = slab_groups(S.d.ffn, prompt);
         if (f8) { a.w0 = (const bf16_t*)p8.w2; a.s0 = (const float*)S.w8s[l].w2; }
-        if ((e = launch_mm_slab(S.d.ffn, kg, a, st, f8)) != hipSuccess) return e;
+        if ((e = launch_mm_slab(S.d.ffn, kg, a, st, f8, xp)) != hipSuccess) return e;
         if (l + 1 < S.d.n_layers) {
-            if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)S.lw[l + 1].sa_norm, S.d.norm_eps, att, d, st, prompt)) != hipSuccess) return e;
+            if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)S.lw[l + 1].sa_norm, S.d.norm_eps, att, d, st, prompt, xp)) != hipSuccess) return e;
         } else {
             // last layer: only each sequence's last row is read again (heads / last_h); its finisher applies the
             // stack's final norm
@@ -490,7 +505,7 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
             AttnArgs t;
             t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
             t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = nsplit;
-            t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part;
+            t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part; t.out_packed = 0;
             fuse_comb = nsplit > 1 && S.hd == 64;
             if ((e = launch_attn(S.hd, t, st, !fuse_comb)) != hipSuccess) return e;
         }
@@ -780,6 +795,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     CsmModel* m = new CsmModel();
     m->cfg = *cfg; m->w = *w; m->max_batch = max_batch; m->max_frames = max_frames;
     if (max_rows < 2 * max_batch) max_rows = 2 * max_batch;
+    max_rows = (max_rows + 31) / 32 * 32;      // operand-order activations are addressed by whole 32-row tiles
     m->max_rows = max_rows;
     m->ldl = ((cfg->audio_vocab + 511) / 512) * 512;
     m->gexec = nullptr; m->graph = nullptr; m->g_B = -1; m->cap_stream = nullptr;
@@ -789,6 +805,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     { const char* ev = getenv("CSM_WIDE"); m->wide_path = !(ev && ev[0] == '0'); }
     { const char* ev = getenv("CSM_WIDE_MIN"); m->wide_min = ev && atoi(ev) > 0 ? atoi(ev) : WIDE_MIN_ROWS; }
     { const char* ev = getenv("CSM_FP8_WIDE"); m->fp8_wide = !(ev && ev[0] == '0'); }
+    { const char* ev = getenv("CSM_XPACK"); m->xpack = !(ev && ev[0] == '0'); }
     // Cache policy (measured, tools/microbench/gemv_bench.hip): a depth-decoder step touches
     // ~230 MB, about the size of the 256 MB Infinity Cache, so with default-policy loads the
     // 31-step cycle thrashes it and even the 2-3 MB q/k/v/o streams come from HBM (4.9 us per
@@ -818,10 +835,11 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     ALLOC(m->dec_in, (size_t)max_batch * 2 * dbb * 2);
     ALLOC(m->proj_emb, (size_t)ncb * cfg->audio_vocab * dd * 2);
     ALLOC(m->slab, (size_t)8 * max_rows * (dbb > dd ? dbb : dd) * 4);
-    ALLOC(m->hdec, (size_t)2 * max_batch * dd * 2);
-    ALLOC(m->qd, (size_t)2 * max_batch * m->dec.nq * 2);
-    ALLOC(m->attd, (size_t)2 * max_batch * m->dec.nq * 2);
-    ALLOC(m->actd, (size_t)2 * max_batch * cfg->decoder.ffn * 2);
+    const size_t dec_rows = (size_t)(2 * max_batch + 31) / 32 * 32;
+    ALLOC(m->hdec, dec_rows * dd * 2);
+    ALLOC(m->qd, dec_rows * m->dec.nq * 2);
+    ALLOC(m->attd, dec_rows * m->dec.nq * 2);
+    ALLOC(m->actd, dec_rows * cfg->decoder.ffn * 2);
     ALLOC(m->logits, (size_t)max_batch * m->ldl * 2);
     ALLOC(m->frame, (size_t)max_batch * ncb * 4);
     ALLOC(m->cur_tokens, (size_t)max_batch * (ncb + 1) * 4);
@@ -1090,7 +1108,7 @@ extern "C" int csm_op_attn(int M, int rows_per_seq, int H, int KV, int head_dim,
     t.q = (const bf16_t*)q; t.kcache = (const bf16_t*)kcache; t.vcache = (const bf16_t*)vcache; t.pos = pos; t.M = M;
     // nsplit == 0: the matrix-core prompt kernel (attn_flash.cuh; head_dim 64); nsplit >= 1: one row per block
     t.rows_per_seq = rows_per_seq; t.H = H; t.KV = KV; t.smax = smax; t.nsplit = nsplit < 1 ? 1 : nsplit;
-    t.scale = 1.0f / sqrtf((float)head_dim); t.out = (bf16_t*)out; t.part = part;
+    t.scale = 1.0f / sqrtf((float)head_dim); t.out = (bf16_t*)out; t.part = part; t.out_packed = 0;
     hipError_t e;
     if (nsplit < 1) {
         if (head_dim != 64 || H % KV != 0) return CSM_E_INVALID;

@@ -57,6 +57,8 @@ struct GemvArgs {
     float* slab;
     // WT == 1: w0/w1/w2 point to OCP-e4m3 bytes [N][K]; per-output-row power-of-two scales
     const float *s0, *s1, *s2;
+    // wide-M decode steps: `out` (SwiGLU) is written in operand order (xp_off)
+    int out_packed;
 };
 
 // Depth-decoder attention fused into the output projection's prologue (hd = 128, at most 32

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_resid_norm(bf16_t* h, const float* slab
 // order than k_resid_norm, which is why prompt rows (bit-identical across prefill sizes) never use this kernel.
 template <int CPT>
 __global__ __launch_bounds__(256) void k_resid_norm_row(bf16_t* h, const float* slab, int KG, int M, int N, long row_step, long row_first,
-                                                        const bf16_t* scale, float eps, bf16_t* xn, long xn_stride) {
+                                                        const bf16_t* scale, float eps, bf16_t* xn, long xn_stride, int xn_packed) {
     __shared__ float s_part[4];
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long r = (long)i * row_step + row_first;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_resid_norm_row(bf16_t* h, const float* 
     if (in) {
 #pragma unroll
         for (int q = 0; q < CPT / 2; ++q)
-            reinterpret_cast<uint32_t*>(xn + (long)i * xn_stride + col)[q] =
+            reinterpret_cast<uint32_t*>(xn + (xn_packed ? xp_off(i, col, N) : (long)i * xn_stride + col))[q] =     // CPT | 8: one piece
                 pack_bf(round_bf(v[2 * q] * rs) * lo2f(gw[q]), round_bf(v[2 * q + 1] * rs) * hi2f(gw[q]));
     }
 }
@@ -247,7 +247,7 @@ __device__ __forceinline__ void mm_finish(const GemvArgs& a, const int m, const 
         } else if (EPI == EPI_RESID) {
             y = y + bf2f(a.resid[(long)m * a.ldo + n]);
         }
-        a.out[(long)m * a.ldo + n] = f2bf(y);
+        a.out[(EPI == EPI_SWIGLU && a.out_packed) ? xp_off(m, n, a.ldo) : (long)m * a.ldo + n] = f2bf(y);
     }
 }
 
@@ -261,7 +261,7 @@ __device__ __forceinline__ void mm_finish(const GemvArgs& a, const int m, const 
 // tiles of one (n tile, K group) back to back: the weight tile comes from HBM once per XCD and from its L2 for the
 // other row tiles (B=128: 11.2 -> 10.4 ms/step, B=256: 22.4 -> 16.2; the opposite assignment, row tiles per XCD,
 // changed nothing).
-template <int EPI, int HD, int NW, int WT = 0>
+template <int EPI, int HD, int NW, int WT = 0, bool XP = false>
 __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K, const int mtiles, const int kgroups) {
     __shared__ float red[EPI == EPI_SWIGLU ? 2 : 1][NW][16][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
@@ -311,7 +311,8 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K,
             if (c * 64 < kspan) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    av[c][q] = *reinterpret_cast<const uint4*>(xa + kc + h * 32 + q * 8);
+                    av[c][q] = XP ? reinterpret_cast<const uint4*>(a.x + (long)(m0 / 32) * 32 * a.x_row_stride)[((kc >> 6) * 4 + q) * 64 + lane]
+                                  : *reinterpret_cast<const uint4*>(xa + kc + h * 32 + q * 8);
                     bv[c][q] = wld(wa + ((kc >> 6) * 4 + q) * 64 + lane);
                     if (EPI == EPI_SWIGLU) cv[c][q] = wld(wb + ((kc >> 6) * 4 + q) * 64 + lane);
                 }
@@ -335,7 +336,8 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K,
     auto load = [&](int buf, int kc) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            av[buf][q] = *reinterpret_cast<const uint4*>(xa + kc + h * 32 + q * 8);
+            av[buf][q] = XP ? reinterpret_cast<const uint4*>(a.x + (long)(m0 / 32) * 32 * a.x_row_stride)[((kc >> 6) * 4 + q) * 64 + lane]
+                            : *reinterpret_cast<const uint4*>(xa + kc + h * 32 + q * 8);
             bv[buf][q] = wld(wa + ((kc >> 6) * 4 + q) * 64 + lane);
             if (EPI == EPI_SWIGLU) cv[buf][q] = wld(wb + ((kc >> 6) * 4 + q) * 64 + lane);
         }

@@ -489,3 +489,32 @@ def test_fp8_stream_on_the_batched_path_equals_its_bf16_dequantisation_bitwise(m
         del m
     assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
     assert res["1"][0].float().abs().max() > 0
+
+
+@pytest.mark.parametrize("B", [13, 40])
+def test_operand_order_activations_are_a_pure_layout_change(monkeypatch, B):
+    """Batched decode steps keep xn / attention output / SiLU*up in matrix-core operand order between the kernels of a
+    layer (CSM_XPACK=0: row-major).  Same values in a different place: logits and frames must be bit-identical, for
+    one row tile (B = 13: 26 rows in decoder step 1, the only packed step there) and for two with a ragged tail (B = 40)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sesameai.models import Model, csm_tiny_args, synthetic_state_dict
+    sd = synthetic_state_dict(csm_tiny_args(), seed=1234)
+    g = torch.Generator().manual_seed(B)
+    S = 9
+    tok = torch.zeros(B, S, 33, dtype=torch.long); msk = torch.zeros(B, S, 33, dtype=torch.bool)
+    tok[:, :4, 32] = torch.randint(0, 1000, (B, 4), generator=g); msk[:, :4, 32] = True
+    tok[:, 4:, :32] = torch.randint(0, 2048, (B, S - 4, 32), generator=g); msk[:, 4:, :32] = True
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CSM_XPACK", flag)
+        m = Model(csm_tiny_args(), sd, max_frames=16, max_prefill_rows=B * S)
+        m.setup_caches(B)
+        m.seed(5)
+        m.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+        _, logits = m.depth(B, 0.9, 50, want_logits=True, commit=True)
+        for _ in range(3):
+            m.step(B, 0.9, 50)
+        res[flag] = (logits.cpu(), m.read_frames(B)[0])
+        del m
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])

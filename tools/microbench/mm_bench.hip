@@ -20,6 +20,8 @@ int main() {
         {"swiglu  K1024 N8192 (33.5MB)", 4, 1024, 8192, 33554432}, 
         {"resid   K8192 N1024 NW4", 1, 8192, 1024, 16777216}, {"resid   K1024 N1024 (2MB)", 1, 1024, 1024, 2097152},
         {"store   K1024 N2051 (4.2MB)", 0, 1024, 2051, 4259840}, {"swiglu  K2048 N8192 (67MB)", 4, 2048, 8192, 67108864},
+        {"swiglu  K1024 N8192 x PACKED", 6, 1024, 8192, 33554432}, {"slab    K1024 N1024 kg4 x PACKED", 7, 1024, 1024, 2097152, 4},
+        {"slab    K8192 N1024 kg8 x PACKED", 7, 8192, 1024, 16777216, 8},
         {"slab    K1024 N1024 kg1", 5, 1024, 1024, 2097152, 1}, {"slab    K1024 N1024 kg2", 5, 1024, 1024, 2097152, 2},
         {"slab    K1024 N1024 kg4", 5, 1024, 1024, 2097152, 4},
         {"slab    K8192 N1024 kg8", 5, 8192, 1024, 16777216, 8}, {"slab    K8192 N1024 kg16", 5, 8192, 1024, 16777216, 16},
@@ -39,6 +41,8 @@ int main() {
             dim3 grid((c.Nn + 31) / 32, 1, c.kg);
             a.slab = slab;
             if (c.kind == 5) { hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4>), grid, dim3(256), 0, st, a, c.K, 0, c.kg); continue; }
+            if (c.kind == 6) { hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4, 0, true>), grid, dim3(256), 0, st, a, c.K, 0, 1); continue; }
+            if (c.kind == 7) { hipLaunchKernelGGL((k_mm32<EPI_SLAB, 64, 4, 0, true>), grid, dim3(256), 0, st, a, c.K, 0, c.kg); continue; }
             if (c.kind == 4) hipLaunchKernelGGL((k_mm32<EPI_SWIGLU, 64, 4>), grid, dim3(256), 0, st, a, c.K, 0, 1);
             else if (c.kind == 1) hipLaunchKernelGGL((k_mm32<EPI_RESID, 64, 4>), grid, dim3(256), 0, st, a, c.K, 0, 1);
             else hipLaunchKernelGGL((k_mm32<EPI_STORE, 64, 4>), grid, dim3(256), 0, st, a, c.K, 0, 1);
