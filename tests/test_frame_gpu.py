@@ -471,7 +471,7 @@ def test_fp8_stream_on_the_batched_path_equals_its_bf16_dequantisation_bitwise(m
     from sesameai.models import Model, csm_tiny_args, synthetic_state_dict
     sd = synthetic_state_dict(csm_tiny_args(), seed=1234)
     g = torch.Generator().manual_seed(8)
-    B, S = 4, 20
+    B, S = 26, 12                                  # 26 rows per decode step: operand-order activations are on as well
     tok = torch.zeros(B, S, 33, dtype=torch.long); msk = torch.zeros(B, S, 33, dtype=torch.bool)
     tok[:, :6, 32] = torch.randint(0, 1000, (B, 6), generator=g); msk[:, :6, 32] = True
     tok[:, 6:, :32] = torch.randint(0, 2048, (B, S - 6, 32), generator=g); msk[:, 6:, :32] = True
