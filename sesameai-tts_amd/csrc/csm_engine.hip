@@ -312,8 +312,10 @@ static hipError_t launch_attn_auto(const Stack& S, const AttnArgs& t, bool promp
     return launch_attn(S.hd, t, st);
 }
 
-// rows from which batched decode runs gate/up through k_gemm128 (measured: B=256 15.6 -> 13.8 ms, B=128 10.3 -> 10.5: no gain below 2 x 128 rows)
-static const int g128_gateup_rows = getenv("CSM_G128_GATEUP_ROWS") ? atoi(getenv("CSM_G128_GATEUP_ROWS")) : 256;
+// rows from which batched decode runs gate/up through k_gemm128.  Off by default: it won at 256 rows against row-major
+// activations (15.6 -> 13.8 ms) but not against operand-order ones (13.7 ms with k_mm32 throughout), and it needs
+// row-major x / act around it.
+static const int g128_gateup_rows = getenv("CSM_G128_GATEUP_ROWS") ? atoi(getenv("CSM_G128_GATEUP_ROWS")) : (1 << 30);
 
 // where the stack's final RMSNorm of each sequence's LAST row goes on the wide path (fused into the last finisher)
 struct FinalNorm { const bf16_t* scale; bf16_t* out; long out_stride; };
