@@ -199,7 +199,8 @@ static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStrea
 }
 
 // long prompts / batched prefill: LDS-tiled 128 x 128 kernel (gemm128.cuh); weights UNPACKED [N][K]
-#define G128_MIN_ROWS 512
+// rows from which prefill takes the LDS-tiled kernels (measured: 190 rows 5.8 vs 6.7 ms with them, 380 rows 8.4 vs 7.8)
+static const int G128_MIN_ROWS = getenv("CSM_G128_MIN_ROWS") ? atoi(getenv("CSM_G128_MIN_ROWS")) : 256;
 template <int EPI, int HD>
 static hipError_t launch_g128_t(const GemvArgs& a, int K, hipStream_t st) {
     static bool attr_set = false;

@@ -1,4 +1,4 @@
-// Long prompts / batched prefill (M >= 512 token rows): LDS-tiled bf16 GEMM on the matrix cores.
+// Long prompts / batched prefill (M >= 256 token rows): LDS-tiled bf16 GEMM on the matrix cores.
 //
 //   out[M][N] = x[M][K] . W[N][K]^T       W in its ORIGINAL row-major layout (no packed copy needed)
 //
