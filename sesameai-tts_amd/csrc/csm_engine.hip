@@ -328,7 +328,9 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
     // norm -> MFMA gate/up(SiLU*up) -> MFMA down(+res).  `att` doubles as the normalised-activation buffer.
     const int d = S.d.dim;
     hipError_t e;
-    const bool big = M >= G128_MIN_ROWS;      // 128 x 128 LDS-tiled kernels, direct epilogues (same bits as the path below)
+    // 128 x 128 LDS-tiled kernels (same bits as the path below) for prefill; decode steps (<= 2 rows per sequence) stay on
+    // the 32-row-tile kernels with operand-order activations whatever the batch (B = 256: 13.7 vs 21 ms)
+    const bool big = M >= G128_MIN_ROWS && (prompt || rows_per_seq > 2);
     for (int l = 0; l < S.d.n_layers; ++l) {
         const CsmLayerWeights& w = S.lw[l];
         const CsmLayerWeights& pk = S.pk[l];
