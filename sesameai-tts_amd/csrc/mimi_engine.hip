@@ -48,8 +48,16 @@ struct GemmArgs {
 
 __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expf(v) - 1.0f; }
 
-__global__ __launch_bounds__(64) void k_gemm32(const GemmArgs a) {
-    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+// One block = one 32 (time) x 32 (channel) output tile; its G32_NW waves split the (tap, 32-wide k chunk) iteration space
+// round-robin and add their partial tiles through LDS in a fixed order.  (One wave per tile walked all taps x C_in/32
+// chunks serially: at 20 transformer tokens a K = 2048 linear was 64 dependent load->MFMA round trips on 16 blocks.)
+// The split depends only on (taps, C_in), never on T, so streaming decode stays bit-identical to whole decode.
+#ifndef G32_NW
+#define G32_NW 8
+#endif
+__global__ __launch_bounds__(64 * G32_NW) void k_gemm32(const GemmArgs a) {
+    __shared__ float red[G32_NW][16][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 32, p = blockIdx.z;
     f32x16 acc;
 #pragma unroll
@@ -58,47 +66,55 @@ __global__ __launch_bounds__(64) void k_gemm32(const GemmArgs a) {
     const bool nrow_ok = (n0 + r) < a.C_out;
     const int trow = trow_ok ? (t0 + r) : (a.T_in - 1);
     const int nrow = nrow_ok ? (n0 + r) : (a.C_out - 1);
-    for (int j = 0; j < a.taps; ++j) {
+    const int kchunks = a.C_in / 32, iters = a.taps * kchunks;
+    for (int it = wave; it < iters; it += G32_NW) {
+        const int j = it / kchunks, kc = (it % kchunks) * 32;
         int arow = trow * a.in_stride + a.shift[j];
         bool aok = true;
         if (a.edge == 1) { aok = arow >= a.row_lo && arow < a.row_hi; arow = min(max(arow, a.row_lo), a.row_hi - 1); }
         else if (a.edge == 2) arow = min(max(arow, a.row_lo), a.row_hi - 1);
-        const float* xa = a.x + (long)arow * a.ldx + h * 16;
-        const float* wb = a.w + (((long)p * a.taps + j) * a.C_out + nrow) * a.C_in + h * 16;
-        for (int kc = 0; kc < a.C_in; kc += 32) {
-            float4 av[4], bv[4];
+        const float* xa = a.x + (long)arow * a.ldx + h * 16 + kc;
+        const float* wb = a.w + (((long)p * a.taps + j) * a.C_out + nrow) * a.C_in + h * 16 + kc;
+        float4 av[4], bv[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                av[q] = *reinterpret_cast<const float4*>(xa + kc + q * 4);
-                bv[q] = *reinterpret_cast<const float4*>(wb + kc + q * 4);
-            }
-            float af[16], bf[16];
+        for (int q = 0; q < 4; ++q) {
+            av[q] = *reinterpret_cast<const float4*>(xa + q * 4);
+            bv[q] = *reinterpret_cast<const float4*>(wb + q * 4);
+        }
+        float af[16], bf[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                af[q * 4 + 0] = av[q].x; af[q * 4 + 1] = av[q].y; af[q * 4 + 2] = av[q].z; af[q * 4 + 3] = av[q].w;
-                bf[q * 4 + 0] = bv[q].x; bf[q * 4 + 1] = bv[q].y; bf[q * 4 + 2] = bv[q].z; bf[q * 4 + 3] = bv[q].w;
-            }
+        for (int q = 0; q < 4; ++q) {
+            af[q * 4 + 0] = av[q].x; af[q * 4 + 1] = av[q].y; af[q * 4 + 2] = av[q].z; af[q * 4 + 3] = av[q].w;
+            bf[q * 4 + 0] = bv[q].x; bf[q * 4 + 1] = bv[q].y; bf[q * 4 + 2] = bv[q].z; bf[q * 4 + 3] = bv[q].w;
+        }
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                float va = af[s];
-                if (a.elu_in) va = elu1(va);
-                if (!trow_ok || !aok) va = 0.f;
-                const float vb = nrow_ok ? bf[s] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, acc, 0, 0, 0);
-            }
+        for (int s = 0; s < 16; ++s) {
+            float va = af[s];
+            if (a.elu_in) va = elu1(va);
+            if (!trow_ok || !aok) va = 0.f;
+            const float vb = nrow_ok ? bf[s] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, acc, 0, 0, 0);
         }
     }
-    // C/D map of the 32x32 tile: col = lane & 31 (channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (time)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    // C/D map of the 32x32 tile: col = lane & 31 (channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (time);
+    // wave g finishes registers 4g .. 4g+3
     const int ch = n0 + r;
-    if (ch >= a.C_out) return;
+    if (ch >= a.C_out || wave >= 4) return;
     const float bias = a.bias ? a.bias[ch] : 0.f;
     const float cs = a.col_scale ? a.col_scale[ch] : 1.f;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
+    for (int i = 0; i < 4; ++i) {
+        const int reg = wave * 4 + i;
         const int t = t0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         if (t >= a.T_in) continue;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < G32_NW; ++w) sum += red[w][reg][lane];          // fixed order
         const long orow = (long)t * a.phases + p;
-        float v = acc[reg] + bias;
+        float v = sum + bias;
         if (a.act_out == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
         if (a.col_scale) v = cs * v;
         if (a.resid) v = a.resid[orow * a.ldr + ch] + v;
@@ -405,7 +421,7 @@ static hipError_t gemm(hipStream_t st, const float* x, long ldx, long T_in, cons
     for (int j = 0; j < taps; ++j) a.shift[j] = shifts[j];
     a.elu_in = elu_in; a.act_out = act_out; a.col_scale = col_scale; a.resid = resid; a.ldr = ldr; a.out = out; a.ldo = ldo;
     dim3 grid((unsigned)((T_in + 31) / 32), (unsigned)((C_out + 31) / 32), (unsigned)phases);
-    hipLaunchKernelGGL(k_gemm32, grid, dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_gemm32, grid, dim3(64 * G32_NW), 0, st, a);
     return hipGetLastError();
 }
 
