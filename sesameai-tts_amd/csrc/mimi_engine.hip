@@ -126,14 +126,17 @@ __global__ __launch_bounds__(64 * G32_NW) void k_gemm32(const GemmArgs a) {
 __global__ __launch_bounds__(256) void k_rvq(const int* codes, long stride_k, long stride_t, int T, int ncb, int nsem,
                                              int cbsize, int cbdim, int hidden, const float* books, const float* pf,
                                              const float* pr, float* out, long ldo) {
-    extern __shared__ float q[];                 // [2][cbdim]
+    extern __shared__ float q[];                 // [2][cbdim] sums, then [ncb] clamped codes
     const int t = blockIdx.x;
+    int* cidx = reinterpret_cast<int*>(q + 2 * cbdim);
+    for (int k = threadIdx.x; k < ncb; k += blockDim.x)                  // the frame's codes once, not once per thread
+        cidx[k] = min(max(codes[k * stride_k + t * stride_t], 0), cbsize - 1);
+    __syncthreads();
     for (int d = threadIdx.x; d < cbdim; d += blockDim.x) {
         float s1 = 0.f, s2 = 0.f;
-        for (int k = 0; k < ncb; ++k) {
-            int c = codes[k * stride_k + t * stride_t];
-            c = min(max(c, 0), cbsize - 1);
-            const float v = books[((long)k * cbsize + c) * cbdim + d];
+#pragma unroll 8
+        for (int k = 0; k < ncb; ++k) {                                   // independent row loads, summed in codebook order
+            const float v = books[((long)k * cbsize + cidx[k]) * cbdim + d];
             if (k < nsem) s1 += v; else s2 += v;
         }
         q[d] = s1; q[cbdim + d] = s2;
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(256) void k_rvq(const int* codes, long stride_k, lo
     __syncthreads();
     for (int c = threadIdx.x; c < hidden; c += blockDim.x) {
         float a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
         for (int d = 0; d < cbdim; ++d) {
             a1 = fmaf(pf[(long)d * hidden + c], q[d], a1);
             a2 = fmaf(pr[(long)d * hidden + c], q[cbdim + d], a2);
@@ -437,7 +441,7 @@ static int decode_one(MimiDecoder* m, const int32_t* codes, long stride_k, long 
     const long T2 = 2L * T;
     const int zero = 0;
     // 1. RVQ lookup-sum + output projections -> rvq [T][d]
-    hipLaunchKernelGGL(k_rvq, dim3(T), dim3(256), (size_t)2 * c.codebook_dim * 4, st, codes, stride_k, stride_t, T, c.n_codebooks,
+    hipLaunchKernelGGL(k_rvq, dim3(T), dim3(256), (size_t)(2 * c.codebook_dim + c.n_codebooks) * 4, st, codes, stride_k, stride_t, T, c.n_codebooks,
                        c.n_semantic, c.codebook_size, c.codebook_dim, d, m->w.codebooks, m->w.proj_first, m->w.proj_rest,
                        m->rvq.row0(), (long)d);
     MCHK(m, hipGetLastError());
