@@ -164,20 +164,36 @@ __global__ void k_upsample(const float* x, long ldx, int T, int C, const float* 
     out[n * ldo + c] = x[t * ldx + c] * w[(p * 2 + 0) * C + c] + x[(t - 1) * ldx + c] * w[(p * 2 + 1) * C + c];
 }
 
+// One wave per row; the row is read ONCE into registers (up to 16 values per lane, d <= 1024) with w and b loads in
+// flight beside it -- the three-pass version paid three dependent global round trips per call (6.7 us x 16 per decode).
 __global__ __launch_bounds__(64) void k_layernorm(const float* x, int d, const float* w, const float* b, float eps, float* out) {
     const long row = blockIdx.x;
     const float* xr = x + row * d;
+    const int lane = threadIdx.x;
+    float v[16], wv[16], bv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = lane + 64 * j;
+        const bool in = i < d;
+        v[j] = in ? xr[i] : 0.f; wv[j] = in ? w[i] : 0.f; bv[j] = in ? b[i] : 0.f;
+    }
     float s = 0.f;
-    for (int i = threadIdx.x; i < d; i += 64) s += xr[i];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += v[j];                     // same per-lane order as before: i = lane, lane + 64, ...
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const float mean = s / d;
-    float v = 0.f;
-    for (int i = threadIdx.x; i < d; i += 64) { const float dlt = xr[i] - mean; v += dlt * dlt; }
+    float q = 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    const float rstd = 1.0f / sqrtf(v / d + eps);
-    for (int i = threadIdx.x; i < d; i += 64) out[row * d + i] = (xr[i] - mean) * rstd * w[i] + b[i];
+    for (int j = 0; j < 16; ++j) { const float dlt = v[j] - mean; if (lane + 64 * j < d) q += dlt * dlt; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / d + eps);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = lane + 64 * j;
+        if (i < d) out[row * d + i] = (v[j] - mean) * rstd * wv[j] + bv[j];
+    }
 }
 
 // qkv [T][3d] -> q [T][d] (RoPE), K/V caches [cap][d] at rows offset+t (K with RoPE); hd = 64
@@ -355,8 +371,8 @@ static hipError_t alloc_hbuf(HBuf& b, int hist, long rows, int C) {
 extern "C" int mimi_create(const MimiConfig* cfg, const MimiWeights* w, int max_frames, int reserved, mimi_handle* out) {
     (void)reserved;
     if (!cfg || !w || !out || max_frames < 1) return mfail(nullptr, "mimi_create: null/invalid argument");
-    if (cfg->hidden % 32 || cfg->codebook_dim % 4 || cfg->tr_ffn % 32 || cfg->hidden / cfg->tr_heads != 64)
-        return mfail(nullptr, "mimi_create: hidden%32, tr_ffn%32 and head_dim==64 required");
+    if (cfg->hidden % 32 || cfg->hidden > 1024 || cfg->codebook_dim % 4 || cfg->tr_ffn % 32 || cfg->hidden / cfg->tr_heads != 64)
+        return mfail(nullptr, "mimi_create: hidden%32, hidden<=1024, tr_ffn%32 and head_dim==64 required");
     if (cfg->n_stages < 1 || cfg->n_stages > MIMI_MAX_STAGES || cfg->tr_layers > MIMI_MAX_TR_LAYERS || cfg->tr_context > 1024)
         return mfail(nullptr, "mimi_create: too many stages/layers or context > 1024");
     if (cfg->kernel > MAX_TAPS || cfg->res_kernel > MAX_TAPS) return mfail(nullptr, "mimi_create: kernel too wide");
