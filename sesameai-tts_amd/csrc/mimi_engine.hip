@@ -416,15 +416,26 @@ extern "C" void mimi_destroy(mimi_handle m) {
 
 extern "C" const char* mimi_last_error(mimi_handle m) { return m ? m->err.c_str() : g_mimi_err.c_str(); }
 
-static hipError_t zero_hist(const HBuf& b, hipStream_t st) {
-    return b.hist ? hipMemsetAsync(b.base, 0, (size_t)b.hist * b.C * 4, st) : hipSuccess;
+// the left-context rows of every activation buffer, zeroed by ONE launch (was 11 hipMemsetAsync per stateless decode)
+struct ZeroRegions { float* p[3 + 2 * MIMI_MAX_STAGES]; int n[3 + 2 * MIMI_MAX_STAGES]; int count; };
+__global__ void k_zero_regions(const ZeroRegions z) {
+    const int reg = blockIdx.y;
+    if (reg >= z.count) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < z.n[reg]; i += gridDim.x * blockDim.x) z.p[reg][i] = 0.f;
 }
 
 extern "C" int mimi_reset_stream(mimi_handle m, void* stream) {
     if (!m) return -1;
     hipStream_t st = (hipStream_t)stream;
-    MCHK(m, zero_hist(m->rvq, st)); MCHK(m, zero_hist(m->a0, st)); MCHK(m, zero_hist(m->s0, st));
-    for (int j = 0; j < m->cfg.n_stages; ++j) { MCHK(m, zero_hist(m->u[j], st)); MCHK(m, zero_hist(m->xj[j], st)); }
+    ZeroRegions z;
+    z.count = 0;
+    auto add = [&](const HBuf& b) { if (b.hist) { z.p[z.count] = b.base; z.n[z.count] = b.hist * b.C; ++z.count; } };
+    add(m->rvq); add(m->a0); add(m->s0);
+    for (int j = 0; j < m->cfg.n_stages; ++j) { add(m->u[j]); add(m->xj[j]); }
+    if (z.count) {
+        hipLaunchKernelGGL(k_zero_regions, dim3(8, z.count), dim3(256), 0, st, z);
+        MCHK(m, hipGetLastError());
+    }
     m->offset = 0;
     return 0;
 }
