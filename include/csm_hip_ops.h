@@ -13,7 +13,7 @@ extern "C" {
 
 /* kind: 0 Linear; 1 Linear + residual; 2 RMSNorm + Linear (heads); 3 RMSNorm + fused q/k/v +
  * interleaved RoPE + KV append; 4 RMSNorm + gate/up + SiLU*up.  K = 512*{1,2,4,16}.
- * kind + 10 (10, 11, 13, 14): the wide-M matrix-core kernels (M >= 16 rows, prompt prefill and
+ * kind + 10 (10, 11, 13, 14): the wide-M matrix-core kernels (M >= 3 rows, prompt prefill and
  * batched decode) of kinds 0, 1, 3, 4; x must already be normalised, K % 256 == 0.
  * kind + 20 (20, 21, 23, 24): the same through the 128 x 128 LDS-tiled kernel that long prompts (M >= 512 rows)
  * take; bit-identical to kind + 10.

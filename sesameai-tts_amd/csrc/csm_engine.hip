@@ -811,12 +811,10 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     { const char* ev = getenv("CSM_WIDE_MIN"); m->wide_min = ev && atoi(ev) > 0 ? atoi(ev) : WIDE_MIN_ROWS; }
     { const char* ev = getenv("CSM_FP8_WIDE"); m->fp8_wide = !(ev && ev[0] == '0'); }
     { const char* ev = getenv("CSM_XPACK"); m->xpack = !(ev && ev[0] == '0'); }
-    // Cache policy (measured, tools/microbench/gemv_bench.hip): a depth-decoder step touches
-    // ~230 MB, about the size of the 256 MB Infinity Cache, so with default-policy loads the
-    // 31-step cycle thrashes it and even the 2-3 MB q/k/v/o streams come from HBM (4.9 us per
-    // launch vs 3.3 us when resident).  Stream everything that is large or used once per frame
-    // non-temporally (backbone, decoder gate/up/down, heads) and keep only the small
-    // latency-critical decoder attention weights + the projection resident.
+    // Cache policy (measured, tools/microbench/gemv_bench.hip and whole frames): the backbone (1.9 GB, read once per
+    // frame) and the heads stream non-temporally so they do not evict the depth decoder, whose 222 MB are re-read on
+    // each of its 31 steps and about fit the 256 MB Infinity Cache.  The decoder itself keeps the default policy:
+    // non-temporal MLP loads made the frame slower (4.41 vs 4.24 ms), see CSM_DEC_MLP_NT.
     {
         const char* ev = getenv("CSM_DEC_MLP_NT");
         const int dec_mlp_nt = (ev && ev[0] == '1');   // measured: default policy is faster for the decoder MLP (4.24 vs 4.41 ms/frame)

@@ -1,5 +1,5 @@
-// Wide-M path (prompt prefill, batched utterances): the same projections as gemv.cuh but for
-// M >= 16 token rows, on the bf16 matrix cores.
+// Wide-M path (batched utterances from 3 rows, prompt chunks below 256 rows -- longer ones take gemm128.cuh): the same
+// projections as gemv.cuh, on the bf16 matrix cores.
 //
 //   out[M][N] = x[M][K] . W[N][K]^T        (x = already-normalised activations, bf16)
 //
