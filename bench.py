@@ -270,13 +270,15 @@ def main():
         codes = frames[:, 0, :].t().unsqueeze(0).contiguous().to(dev)          # (1, 32, T) of utterance 0
         T = codes.shape[2]
 
-        def timed(fn, reps=3):
+        def timed(fn, reps=5):
             fn(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            ts = []
             for _ in range(reps):
+                t0 = time.perf_counter()
                 fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) * 1e3 / reps
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return sorted(ts)[len(ts) // 2]                        # median: one-off allocator / clock hiccups are not the kernel's time
 
         whole_ms = timed(lambda: codec.decode(codes))
 
