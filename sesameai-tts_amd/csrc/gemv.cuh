@@ -59,7 +59,41 @@ struct GemvArgs {
     const float *s0, *s1, *s2;
     // wide-M decode steps: `out` (SwiGLU) is written in operand order (xp_off)
     int out_packed;
+#ifdef GEMV_PF_HOOKS   // tools/microbench/pfchain_bench.hip only (measured: every prefetch form made the chain slower)
+    // Optional L2 prefetch of the NEXT launch's weights: workgroups blockIdx.x >= work_blocks (when pf[0].base != nullptr)
+    // do no GEMV work; they read the byte regions the next launch's workgroups will stream (region b' of matrix i =
+    // [base + b' * bytes, + bytes)), taking the regions of the workgroups that should share their XCD (round-robin
+    // placement: b' = blockIdx.x + pf_shift mod 8).  Speed only -- the bytes are read and dropped.
+    struct { const char* base; int bytes; int nblocks; } pf[3];
+    int pf_shift, work_blocks;
+    // Optional: bumped once per launch (workgroup 0) so a concurrent weight streamer can pace itself (streamer.cuh)
+    unsigned* progress;
+#endif
 };
+
+#ifdef GEMV_PF_HOOKS
+__device__ __forceinline__ void gemv_prefetch_blocks(const GemvArgs& a) {
+    const int p = (int)blockIdx.x - a.work_blocks, P = (int)gridDim.x - a.work_blocks;
+    const int r = ((int)blockIdx.x + a.pf_shift) & 7, q = p >> 3, Pq = (P + 7) >> 3;
+    uint32_t acc = 0;
+#pragma unroll 1
+    for (int i = 0; i < 3; ++i) {
+        if (!a.pf[i].base) break;
+        const int pieces = a.pf[i].bytes >> 12;                   // 4 KB (one 16-byte piece per thread) per step
+        for (int b = r + 8 * q; b < a.pf[i].nblocks; b += 8 * Pq) {
+            const uint4* src = reinterpret_cast<const uint4*>(a.pf[i].base + (long)b * a.pf[i].bytes) + threadIdx.x;
+            for (int j = 0; j < pieces; j += 4) {
+                uint4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = (j + u < pieces) ? src[(j + u) * 256] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].w;
+            }
+        }
+    }
+    if (acc == 0x9e3779b9u && a.M < 0) a.out[0] = (bf16_t)acc;     // never true: keeps the loads alive
+}
+#endif
 
 // Depth-decoder attention fused into the output projection's prologue (hd = 128, at most 32
 // keys: the decoder cache holds one frame's codebooks, sesameai/models.py:127).  Replaces a
@@ -299,6 +333,11 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
     float* red = reinterpret_cast<float*>(smem + (size_t)MT * K * 2);
+#ifdef GEMV_PF_HOOKS
+    if (a.pf[0].base != nullptr && (int)blockIdx.x >= a.work_blocks) { gemv_prefetch_blocks(a); return; }
+    if (a.progress != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_fetch_add(a.progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * 4 + wave;              // one unit = R weight rows
