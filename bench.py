@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: audio frames/s (and real-time factor) of the CSM-1B audio-token loop.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: this process spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one generated 80 ms audio frame for every stream of the batch: one backbone step,
@@ -33,19 +33,23 @@ import torch
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def synthetic_prompt(args, batch, text_vocab, seed0=2025):
-    """config-2 shape: context segment (40 text + 125 audio + EOS rows) + 24 text rows."""
+def synthetic_prompt(args, batch, text_vocab, seed0=2025, segments=1, ctx_text=None, ctx_frames=None):
+    """`segments` context segments (ctx_text text rows + ctx_frames audio rows + the all-zero EOS row) + gen_text text
+    rows.  Defaults = config 2 (1 x (40 + 125 + 1) + 24 = 190 rows); config 5 = 10 x (30 + 100 + 1) + 24 = 1334."""
+    ctx_text = args.ctx_text if ctx_text is None else ctx_text
+    ctx_frames = args.ctx_frames if ctx_frames is None else ctx_frames
     toks, masks = [], []
     for b in range(batch):
         g = torch.Generator().manual_seed(seed0 + b)
-        rows = args.ctx_text + args.ctx_frames + 1 + args.gen_text
+        rows = segments * (ctx_text + ctx_frames + 1) + args.gen_text
         t = torch.zeros(rows, 33, dtype=torch.long)
         m = torch.zeros(rows, 33, dtype=torch.bool)
         r = 0
-        t[r:r + args.ctx_text, 32] = torch.randint(0, text_vocab, (args.ctx_text,), generator=g); m[r:r + args.ctx_text, 32] = True
-        r += args.ctx_text
-        t[r:r + args.ctx_frames, :32] = torch.randint(0, 2048, (args.ctx_frames, 32), generator=g); m[r:r + args.ctx_frames + 1, :32] = True
-        r += args.ctx_frames + 1                      # the all-zero EOS frame
+        for _ in range(segments):
+            t[r:r + ctx_text, 32] = torch.randint(0, text_vocab, (ctx_text,), generator=g); m[r:r + ctx_text, 32] = True
+            r += ctx_text
+            t[r:r + ctx_frames, :32] = torch.randint(0, 2048, (ctx_frames, 32), generator=g); m[r:r + ctx_frames + 1, :32] = True
+            r += ctx_frames + 1                       # the all-zero EOS frame
         t[r:r + args.gen_text, 32] = torch.randint(0, text_vocab, (args.gen_text,), generator=g); m[r:r + args.gen_text, 32] = True
         toks.append(t); masks.append(m)
     return torch.stack(toks), torch.stack(masks)
@@ -150,6 +154,114 @@ def cpu_baseline(args):
                        f"torch {torch.__version__}")
 
 
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: this (GPU-free) parent starts the N rank processes itself with the
+    torch.distributed environment and relays rank 0's JSON line.  Nothing here touches the GPU, and no process that has
+    initialised the GPU is ever replaced by another program."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [l for l in (out or "").splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    rc = max(abs(c) for c in rcs)
+    if rc == 0 and not lines:
+        rc = 3
+    sys.exit(rc)
+
+
+def timed_steps(model, B, n, temperature, topk, use_graph=True):
+    """n frame steps between HIP events on the launching stream -> ms per step."""
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(st)
+    for _ in range(n):
+        model.step(B, temperature, topk, use_graph)
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def extras_legs(args, margs, sd, dev):
+    """BASELINE configs 3 and 5 and the long-context single-stream step, each a short run inside this same process so
+    the driver's one bench line carries them (`extras`).  Not part of `value`."""
+    from sesameai.models import Model
+    ex = {}
+    T, K = args.temperature, args.topk
+    # ---- config 3: B=32 x the config-2 prompt, hipGraph-captured frame step ----
+    B3, n3 = 32, args.extra_steps
+    tok, msk = synthetic_prompt(args, B3, margs.text_vocab_size, seed0=4000)
+    S = tok.shape[1]
+    m3 = Model(margs, sd, device=str(dev), max_frames=n3 + 16, max_prefill_rows=B3 * S)
+    m3.setup_caches(B3); m3.seed(77)
+    pos = torch.arange(S).unsqueeze(0).repeat(B3, 1)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    m3.reset_caches(); m3.prefill(tok.to(dev), msk.to(dev), pos.to(dev)); m3.depth(B3, T, K, commit=True)
+    torch.cuda.synchronize(); pre_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(5):
+        m3.step(B3, T, K)
+    ms = timed_steps(m3, B3, n3, T, K)
+    by = m3.bytes_per_frame(B3, S + 5 + n3 / 2.0)
+    ex["config3"] = {"workload": f"CSM-1B B={B3}, S={S} prompt rows each, hipGraph frame step, {n3} timed steps", "ms_per_step": round(ms, 4),
+                     "frames_per_s": round(B3 * 1e3 / ms, 1), "rtf_aggregate": round(B3 * 1e3 / ms / 12.5, 1),
+                     "prefill_plus_frame0_ms": round(pre_ms, 1), "roofline_frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del m3
+    # ---- long context, single stream, bf16: ms per frame at p ~ 1700 (the KV stream grows by 32 KB per position) ----
+    tok, msk = synthetic_prompt(args, 1, margs.text_vocab_size, seed0=5000, segments=10, ctx_text=30, ctx_frames=100)
+    S5 = tok.shape[1]
+    n_long = 2040 - S5 - 8
+    ml = Model(margs, sd, device=str(dev), max_frames=n_long + 16, max_prefill_rows=S5)
+    ml.setup_caches(1); ml.seed(78)
+    pos = torch.arange(S5).unsqueeze(0)
+    ml.reset_caches(); ml.prefill(tok.to(dev), msk.to(dev), pos.to(dev)); ml.depth(1, T, K, commit=True)
+    for _ in range(1700 - S5 - 20):
+        ml.step(1, T, K)
+    ms = timed_steps(ml, 1, 40, T, K)
+    ex["b1_long_context"] = {"workload": f"CSM-1B B=1 bf16, S={S5} prompt rows, 40 frames timed at positions ~1680-1720", "ms_per_step": round(ms, 4),
+                             "rtf": round(80.0 / ms, 2), "roofline_frac": round(ml.bytes_per_frame(1, 1700.0) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del ml
+    # ---- config 5: fp8-e4m3 weight stream, S=1334 prompt, 375 frames, stateful Mimi decode every 10 frames ----
+    from sesameai.generator import Generator
+    from sesameai.mimi import MimiArgs, MimiCodec
+    n5 = 375
+    m5 = Model(margs, sd, device=str(dev), max_frames=n5 + 16, max_prefill_rows=S5, weights_dtype="fp8")
+    codec = MimiCodec(MimiArgs(), None, device=str(dev), max_frames=n5 + 16)
+    gen = Generator(m5, audio_tokenizer=codec)
+    m5.seed(79); m5.prefix_reuse = False
+    side = torch.cuda.Stream(device=dev)
+    for rep in range(2):                                   # rep 0 captures the graph and warms the codec
+        codec.reset_stream()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        first_ms, n_fr, pcm_n = None, 0, 0
+        for fr in gen._frame_blocks(tok.to(dev), msk.to(dev), n5, T, K, 10):
+            with torch.cuda.stream(side):
+                pcm = codec.decode_stream(fr.to(dev).permute(1, 2, 0).contiguous())
+            side.synchronize()
+            n_fr += fr.shape[0]; pcm_n += pcm.shape[-1]
+            if first_ms is None:
+                first_ms = (time.perf_counter() - t0) * 1e3
+        torch.cuda.synchronize()
+        wall_ms = (time.perf_counter() - t0) * 1e3
+    lm_ms = timed_steps(m5, 1, 40, T, K) if m5.num_frames() + 40 < n5 + 16 else None
+    ex["config5"] = {"workload": f"CSM-1B B=1, fp8-e4m3 weight stream, S={S5} prompt rows (10 segments), {n_fr} frames, stateful Mimi decode every 10 frames",
+                     "wall_ms": round(wall_ms, 1), "first_chunk_ms": round(first_ms, 1), "frames": n_fr, "pcm_samples": pcm_n,
+                     "end_to_end_rtf": round(n_fr * 80.0 / wall_ms, 2),
+                     "roofline_frac_end_to_end": round(m5.bytes_per_frame(1, S5 + n_fr / 2.0) * n_fr / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del gen, codec, m5
+    return ex
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,19 +283,21 @@ def main():
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16",
                     help="fp8 = OCP-e4m3 weight stream for the decode step (BASELINE config 5; not the headline)")
     ap.add_argument("--tiny", action="store_true", help="tiny shapes (plumbing check only; not a valid bench)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the config-3 / config-5 / long-context legs (N=1 only)")
+    ap.add_argument("--extra-steps", type=int, default=40)
     args = ap.parse_args()
     if args.cpu_worker:
         cpu_worker(args)
         return
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args, sys.argv[1:])            # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     # BENCH_SHARE_GPU0=1 (debug only, never a valid measurement): every rank uses cuda:0 over gloo, which lets the
     # multi-rank control flow (weight broadcast, barriers, max-over-ranks timing) be exercised on a 1-GPU box
@@ -213,7 +327,6 @@ def main():
         sd = synthetic_state_dict(margs, seed=1234)
     model = Model(margs, sd, device=str(dev), max_frames=args.steps + args.warmup + 8,
                   max_prefill_rows=B * (args.ctx_text + args.ctx_frames + 1 + args.gen_text), weights_dtype=args.weights)
-    del sd
     log("weights on device; creating caches")
     model.setup_caches(B)
     model.seed(1234 + rank)
@@ -326,10 +439,14 @@ def main():
     achieved = bytes_frame / t_frame / 1e9
     # HBM/fabric bytes per frame-step launch from the PMC counters (FETCH_SIZE, x2 gfx950 correction), collected
     # with a separate `rocprofv3 --pmc FETCH_SIZE` pass of this same command and committed under profiles/
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-    if os.path.exists(pmc) and B == 1 and not args.tiny and args.weights == "bf16":
-        traffic = json.load(open(pmc)).get("traffic_bytes_per_frame")
+    traffic, traffic_src = None, None
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    if pmcs and B == 1 and not args.tiny and args.weights == "bf16":
+        pj = json.load(open(pmcs[-1]))
+        traffic = pj.get("traffic_bytes_per_frame")
+        traffic_src = {"file": os.path.relpath(pmcs[-1], ROOT), "kernels_commit": pj.get("kernels_commit"),
+                       "note": "separate rocprofv3 --pmc FETCH_SIZE pass of this command (x2 gfx950 correction), not measured in this run"}
     kernels = None if (args.tiny or args.weights != "bf16") else dominant_kernels(model, dev)
     out = {
         "metric": "audio frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
@@ -345,17 +462,18 @@ def main():
         "rtf": round(value / 12.5, 2), "rtf_per_stream": round(value / 12.5 / (world * B), 2),
         "prefill_plus_frame0_ms": round(prefill_ms, 2), "mimi": mimi,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "frame step (1 backbone + 31 depth-decoder steps, unique weights + KV)",
                      "bytes_per_launch": bytes_frame, "launch_ms": round(t_frame * 1e3, 4),
                      "streamed_GBps": round((bytes_frame + 30 * 2 * 111.15e6 + 30 * 2 * 2.1e6) / t_frame / 1e9, 1),
                      "dominant_kernels": kernels},
     }
+    if world == 1 and B == 1 and not args.tiny and not args.no_extras and args.weights == "bf16":
+        del model
+        out["extras"] = extras_legs(args, margs, sd, dev)
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1 and not args.tiny:
-            out["cpu_baseline"] = cpu_baseline(args)
-        else:
-            out["cpu_baseline"] = None
+        # the oracle beside it, on this host's cores, after the timed region (the other ranks wait at the barrier below)
+        out["cpu_baseline"] = cpu_baseline(args) if not (args.no_cpu_baseline or args.tiny) else None
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
