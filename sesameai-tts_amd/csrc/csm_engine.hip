@@ -203,7 +203,9 @@ static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStrea
 static const int G128_MIN_ROWS = getenv("CSM_G128_MIN_ROWS") ? atoi(getenv("CSM_G128_MIN_ROWS")) : 256;
 template <int EPI, int HD>
 static hipError_t launch_g128_t(const GemvArgs& a, int K, hipStream_t st) {
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};              // hipFuncSetAttribute is per device
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
         (void)hipGetLastError();
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm128<EPI, HD>),
@@ -303,7 +305,9 @@ static hipError_t launch_attn(int hd, const AttnArgs& a, hipStream_t st, bool co
 // depends only on the model's shape and on prompt/not-prompt, never on the row count, so a prompt row's bits do not
 // depend on how the prompt was cut into calls.
 #define FLASH_MIN_ROWS 16
-static bool flash_ok(const Stack& S) { return S.hd == 64 && S.d.n_heads % S.d.n_kv_heads == 0; }
+// (k_attn_flash walks a KV group's heads 4 at a time with workgroup barriers inside the loop: the group size must be a
+//  multiple of 4 or waves 2-3 would skip barriers and leave tiles half staged -- other shapes take the per-row kernel)
+static bool flash_ok(const Stack& S) { return S.hd == 64 && S.d.n_heads % S.d.n_kv_heads == 0 && (S.d.n_heads / S.d.n_kv_heads) % 4 == 0; }
 static hipError_t launch_attn_auto(const Stack& S, const AttnArgs& t, bool prompt, hipStream_t st) {
     if (flash_ok(S) && t.nsplit == 1 && (prompt || t.rows_per_seq >= FLASH_MIN_ROWS)) {
         dim3 grid((t.M / t.rows_per_seq) * ((t.rows_per_seq + 31) / 32), t.KV);
@@ -649,20 +653,28 @@ static hipError_t launch_advance(CsmModel* m, int B, const int* fed, int pos_inc
     a.frame = m->frame; a.B = B; a.ncb = m->cfg.n_codebooks; a.bstride = m->max_batch; a.history = m->history;
     a.n_frames = m->n_frames; a.max_frames = m->max_frames; a.eos_at = m->eos_at; a.cur_tokens = m->cur_tokens;
     a.cur_mask = m->cur_mask; a.cur_pos = m->cur_pos; a.rng = m->rng; a.out_frame = nullptr; a.fed = fed; a.pos_inc = pos_inc;
+    a.max_seq = m->cfg.backbone.max_seq; a.overflow = m->n_frames + 1;
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
-__global__ void k_set_prefill_state(const int* pos, int B, int S, int* cur_pos) {
+// (a position outside [0, max_seq) would be clamped by the kernels: raise the device-side flag that csm_read_frames
+//  turns into CSM_E_TOO_LONG instead of letting the clamp pass silently)
+__global__ void k_set_prefill_state(const int* pos, int B, int S, int* cur_pos, int max_seq, int* overflow) {
     for (int b = threadIdx.x; b < B; b += blockDim.x) cur_pos[b] = pos[(long)b * S + S - 1] + 1;
+    for (int i = threadIdx.x; i < B * S; i += blockDim.x)
+        if (pos[i] < 0 || pos[i] >= max_seq) *overflow = 1;
 }
 __global__ void k_fill_i32(int* p, int v, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
 __global__ void k_copy_step_inputs(const int* tokens, const uint8_t* mask, const int* pos, int n_tok, int B,
-                                   int* cur_tokens, uint8_t* cur_mask, int* cur_pos) {
+                                   int* cur_tokens, uint8_t* cur_mask, int* cur_pos, int max_seq, int* overflow) {
     for (int i = threadIdx.x; i < n_tok; i += blockDim.x) { cur_tokens[i] = tokens[i]; cur_mask[i] = mask[i]; }
-    for (int b = threadIdx.x; b < B; b += blockDim.x) cur_pos[b] = pos[b];
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        cur_pos[b] = pos[b];
+        if (pos[b] < 0 || pos[b] >= max_seq) *overflow = 1;
+    }
 }
 
 static hipError_t pack_weight(CsmModel* m, const void* w, int N, int K, bf16_t** out) {
@@ -931,7 +943,7 @@ extern "C" const char* csm_last_error(csm_handle m) { return m ? m->err.c_str() 
 extern "C" int csm_reset(csm_handle m, void* stream) {
     if (!m) return CSM_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(m, hipMemsetAsync(m->n_frames, 0, 4, st));
+    HIPCHK(m, hipMemsetAsync(m->n_frames, 0, 8, st));          // frame counter + position-overflow flag
     HIPCHK(m, hipMemsetAsync(m->cur_pos, 0, (size_t)m->max_batch * 4, st));
     HIPCHK(m, hipMemsetAsync(m->eos_at, 0xff, (size_t)m->max_batch * 4, st));
     m->host_frames = 0; m->have_last = false;
@@ -954,7 +966,7 @@ extern "C" int csm_prefill(csm_handle m, const int32_t* tokens, const uint8_t* m
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(m, launch_embed(m, tokens, mask, B * S, st));
     HIPCHK(m, run_stack(m, m->bb, m->h, m->q, m->att, m->act, B * S, S, pos, -1, st, prompt_mode != 0));
-    hipLaunchKernelGGL(k_set_prefill_state, dim3(1), dim3(64), 0, st, pos, B, S, m->cur_pos);
+    hipLaunchKernelGGL(k_set_prefill_state, dim3(1), dim3(256), 0, st, pos, B, S, m->cur_pos, m->cfg.backbone.max_seq, m->n_frames + 1);
     HIPCHK(m, hipGetLastError());
     m->have_last = true; m->last_S = S;
     return CSM_OK;
@@ -1020,7 +1032,7 @@ extern "C" int csm_set_step_inputs(csm_handle m, const int32_t* tokens, const ui
                                    void* stream) {
     if (!m || !tokens || !mask || !pos || B < 1 || B > m->max_batch) return fail(m, CSM_E_INVALID, "csm_set_step_inputs: bad argument");
     hipLaunchKernelGGL(k_copy_step_inputs, dim3(1), dim3(256), 0, (hipStream_t)stream, tokens, mask, pos,
-                       B * (m->cfg.n_codebooks + 1), B, m->cur_tokens, m->cur_mask, m->cur_pos);
+                       B * (m->cfg.n_codebooks + 1), B, m->cur_tokens, m->cur_mask, m->cur_pos, m->cfg.backbone.max_seq, m->n_frames + 1);
     HIPCHK(m, hipGetLastError());
     return CSM_OK;
 }
@@ -1036,7 +1048,10 @@ extern "C" int csm_read_frames(csm_handle m, int B, int first, int n, int32_t* h
         HIPCHK(m, hipMemcpy2DAsync(host_frames, (size_t)B * ncb * 4, m->history + (size_t)first * m->max_batch * ncb,
                                    (size_t)m->max_batch * ncb * 4, (size_t)B * ncb * 4, n, hipMemcpyDeviceToHost, st));
     if (host_eos_at) HIPCHK(m, hipMemcpyAsync(host_eos_at, m->eos_at, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    int overflow = 0;
+    HIPCHK(m, hipMemcpyAsync(&overflow, m->n_frames + 1, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(m, hipStreamSynchronize(st));
+    if (overflow) return fail(m, CSM_E_TOO_LONG, "a position outside [0, max_seq) was fed to the backbone (prompt + generated frames exceed max_seq_len)");
     return CSM_OK;
 }
 
@@ -1114,7 +1129,7 @@ extern "C" int csm_op_attn(int M, int rows_per_seq, int H, int KV, int head_dim,
     t.scale = 1.0f / sqrtf((float)head_dim); t.out = (bf16_t*)out; t.part = part; t.out_packed = 0;
     hipError_t e;
     if (nsplit < 1) {
-        if (head_dim != 64 || H % KV != 0) return CSM_E_INVALID;
+        if (head_dim != 64 || H % KV != 0 || (H / KV) % 4 != 0) return CSM_E_INVALID;
         dim3 grid((M / rows_per_seq) * ((rows_per_seq + 31) / 32), KV);
         hipLaunchKernelGGL((k_attn_flash<64>), grid, dim3(256), 0, (hipStream_t)stream, t);
         e = hipGetLastError();

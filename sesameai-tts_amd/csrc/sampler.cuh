@@ -351,6 +351,8 @@ struct AdvanceArgs {
     int* out_frame;       // optional user copy [B][ncb]
     const int* fed;       // optional [B][ncb]: codes fed back instead of frame (teacher forcing)
     int pos_inc;          // 1 after a backbone step consumed cur_pos, 0 after a prefill
+    int max_seq;          // backbone positions are [0, max_seq)
+    int* overflow;        // device flag: a step ran at a position >= max_seq (csm_read_frames -> CSM_E_TOO_LONG)
 };
 
 __global__ __launch_bounds__(256) void k_advance(const AdvanceArgs a) {
@@ -372,6 +374,7 @@ __global__ __launch_bounds__(256) void k_advance(const AdvanceArgs a) {
         a.cur_tokens[b * (a.ncb + 1) + a.ncb] = 0;
         a.cur_mask[b * (a.ncb + 1) + a.ncb] = 0;
         if (nz[b] == 0 && a.eos_at[b] < 0) a.eos_at[b] = n;
+        if (a.pos_inc && a.cur_pos[b] >= a.max_seq) *a.overflow = 1;      // the step that just ran used this position
         a.cur_pos[b] += a.pos_inc;
     }
     if (threadIdx.x == 0) { *a.n_frames = n + 1; a.rng[1] += 1; }

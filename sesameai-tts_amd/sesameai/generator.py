@@ -190,14 +190,18 @@ class Generator:
             tokens, mask = tokens.unsqueeze(0), mask.unsqueeze(0)
         if tokens.shape[1] >= MAX_SEQ_LEN - max_generation_len:
             raise ValueError(f"Inputs too long, must be below max_seq_len - max_generation_len: {MAX_SEQ_LEN - max_generation_len}")
-        if getattr(self, "_mimi_stream", None) is None:
+        on_gpu = torch.device(self.device).type == "cuda"           # (a CPU device only occurs in the host-logic tests)
+        if on_gpu and getattr(self, "_mimi_stream", None) is None:
             self._mimi_stream = torch.cuda.Stream(device=self.device)
-        side = self._mimi_stream
+        side = self._mimi_stream if on_gpu else None
         pending: List[torch.Tensor] = []
         size = self._stream_buffer_size
 
         def decode(n: int) -> torch.Tensor:
             buf = torch.stack(pending[:n]); del pending[:n]
+            if side is None:
+                with torch.inference_mode():
+                    return self._decode_frames(buf)
             with torch.inference_mode(), torch.cuda.stream(side):
                 pcm = self._decode_frames(buf)
             side.synchronize()
@@ -237,13 +241,21 @@ class Generator:
 
 
 def load_csm_1b(device: str = "cuda", model_path: Optional[str] = None, mimi_path: Optional[str] = None,
-                max_batch_size: int = 1) -> Generator:
-    """reference: sesameai/generator.py:330-346.  The reference downloads ``sesame/csm-1b`` and
-    the Mimi checkpoint from the hub; here ``model_path`` / ``mimi_path`` (or $CSM_MODEL_PATH /
-    $CSM_MIMI_PATH) name local files, and without them seeded random weights of the true
-    shapes are used (benchmarks, tests)."""
+                max_batch_size: int = 1, synthetic: Optional[bool] = None) -> Generator:
+    """reference: sesameai/generator.py:330-346.  The reference downloads ``sesame/csm-1b`` and the Mimi
+    checkpoint from the hub; there is no network here, so ``model_path`` / ``mimi_path`` (or $CSM_MODEL_PATH /
+    $CSM_MIMI_PATH) must name local files.  Seeded random weights of the true shapes (benchmarks, tests)
+    are used ONLY when asked for -- ``synthetic=True`` or $CSM_SYNTHETIC=1 -- never as a silent fallback:
+    a TTS service that writes noise and exits 0 is worse than one that refuses to start."""
     model_path = model_path or os.environ.get("CSM_MODEL_PATH")
+    mimi_path = mimi_path or os.environ.get("CSM_MIMI_PATH")
+    if synthetic is None:
+        synthetic = os.environ.get("CSM_SYNTHETIC") == "1"
+    if not synthetic and not (model_path and mimi_path):
+        raise FileNotFoundError("load_csm_1b: set CSM_MODEL_PATH (sesame/csm-1b model.safetensors) and CSM_MIMI_PATH (moshi "
+                                "tokenizer safetensors) or pass model_path= / mimi_path=; for seeded random weights "
+                                "(benchmarks, tests) pass synthetic=True or set CSM_SYNTHETIC=1")
     model = Model.from_pretrained(model_path, device=device) if model_path else Model(csm_1b_args(), None, device=device)
     from .mimi import MimiCodec
-    mimi = MimiCodec.from_pretrained(mimi_path or os.environ.get("CSM_MIMI_PATH"), device=device)
+    mimi = MimiCodec.from_pretrained(mimi_path, device=device)
     return Generator(model, audio_tokenizer=mimi, max_batch_size=max_batch_size)

@@ -182,9 +182,13 @@ def _fill(w: Dict[str, torch.Tensor], names, g: torch.Generator) -> None:
 
 
 def from_moshi_state_dict(sd: Dict[str, torch.Tensor], s: MimiArgs) -> Dict[str, torch.Tensor]:
-    """Maps a moshi ``tokenizer-*.safetensors`` (kyutai/moshiko, loaders.MIMI_NAME) decode-side
-    state dict to the canonical names above.  Written from knowledge of moshi 0.2.2's module
-    tree; it could not be exercised here (no checkpoint, no network) -- see DESIGN.md."""
+    """Maps a moshi ``tokenizer-*.safetensors`` (kyutai/moshiko, loaders.MIMI_NAME) state dict to the
+    canonical names above: the decode side always, the encode side (SEANet encoder, encoder
+    transformer, stride-2 downsample, RVQ input projections -- what ``Segment.audio`` voice prompts
+    need, sesameai/generator.py:86) when the checkpoint holds it.  Written from moshi 0.2.2's module
+    tree (SEANetEncoder/Decoder ``model`` index lists, ``ProjectedTransformer``, ``SplitResidualVectorQuantizer``);
+    no checkpoint can be downloaded here, so it is pinned by a name/shape round trip
+    (tests/test_host_logic.py::test_moshi_checkpoint_name_map_round_trip)."""
     out: Dict[str, torch.Tensor] = {}
     for k in range(s.num_codebooks):
         src = ("quantizer.rvq_first.vq.layers.0" if k == 0 else f"quantizer.rvq_rest.vq.layers.{k - 1}") + "._codebook"
@@ -213,6 +217,30 @@ def from_moshi_state_dict(sd: Dict[str, torch.Tensor], s: MimiArgs) -> Dict[str,
         out[f"seanet.up.{j}.res.conv2.bias"] = sd[f"decoder.model.{rb}.block.3.conv.conv.bias"]
     last = 2 + 3 * len(s.ratios)
     out["seanet.conv_out.weight"], out["seanet.conv_out.bias"] = sd[f"decoder.model.{last}.conv.conv.weight"], sd[f"decoder.model.{last}.conv.conv.bias"]
+    if "encoder.model.0.conv.conv.weight" not in sd:
+        return out
+    # SEANetEncoder.model: [conv_in, (resblock, ELU, strided conv) x4, ELU, conv_out]
+    out["enc.conv_in.weight"], out["enc.conv_in.bias"] = sd["encoder.model.0.conv.conv.weight"], sd["encoder.model.0.conv.conv.bias"]
+    for j in range(len(s.ratios)):
+        rb, dn = 1 + 3 * j, 3 + 3 * j
+        out[f"enc.down.{j}.res.conv1.weight"] = sd[f"encoder.model.{rb}.block.1.conv.conv.weight"]
+        out[f"enc.down.{j}.res.conv1.bias"] = sd[f"encoder.model.{rb}.block.1.conv.conv.bias"]
+        out[f"enc.down.{j}.res.conv2.weight"] = sd[f"encoder.model.{rb}.block.3.conv.conv.weight"]
+        out[f"enc.down.{j}.res.conv2.bias"] = sd[f"encoder.model.{rb}.block.3.conv.conv.bias"]
+        out[f"enc.down.{j}.conv.weight"] = sd[f"encoder.model.{dn}.conv.conv.weight"]
+        out[f"enc.down.{j}.conv.bias"] = sd[f"encoder.model.{dn}.conv.conv.bias"]
+    out["enc.conv_out.weight"], out["enc.conv_out.bias"] = sd[f"encoder.model.{last}.conv.conv.weight"], sd[f"encoder.model.{last}.conv.conv.bias"]
+    for i in range(s.tr_layers):
+        p, L = f"encoder_transformer.transformer.layers.{i}", f"enc_transformer.{i}"
+        out[f"{L}.norm1.weight"], out[f"{L}.norm1.bias"] = sd[f"{p}.norm1.weight"], sd[f"{p}.norm1.bias"]
+        out[f"{L}.norm2.weight"], out[f"{L}.norm2.bias"] = sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"]
+        out[f"{L}.in_proj_weight"] = sd[f"{p}.self_attn.in_proj_weight"]
+        out[f"{L}.out_proj.weight"] = sd[f"{p}.self_attn.out_proj.weight"]
+        out[f"{L}.linear1.weight"], out[f"{L}.linear2.weight"] = sd[f"{p}.linear1.weight"], sd[f"{p}.linear2.weight"]
+        out[f"{L}.layer_scale_1.scale"], out[f"{L}.layer_scale_2.scale"] = sd[f"{p}.layer_scale_1.scale"], sd[f"{p}.layer_scale_2.scale"]
+    out["downsample.conv.weight"] = sd["downsample.conv.conv.conv.weight"]
+    out["rvq_first.input_proj.weight"] = sd["quantizer.rvq_first.input_proj.weight"]
+    out["rvq_rest.input_proj.weight"] = sd["quantizer.rvq_rest.input_proj.weight"]
     return out
 
 

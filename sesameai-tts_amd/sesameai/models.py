@@ -326,15 +326,29 @@ class Model:
     def caches_are_enabled(self) -> bool:
         return bool(self._h)
 
+    def _on_device(self):
+        """Every C-ABI call runs with this model's GPU current (kernels, streams and allocations are per device)."""
+        return torch.cuda.device(self.device)
+
     def reset_caches(self) -> None:
         """reference: Model.reset_caches (sesameai/models.py:186-188)."""
         self._require()
-        check(lib.csm_reset(self._h, _stream_ptr()), self._h)
+        with self._on_device():
+            check(lib.csm_reset(self._h, _stream_ptr()), self._h)
 
     def seed(self, seed: int) -> None:
         self._require()
-        check(lib.csm_seed(self._h, seed, _stream_ptr()), self._h)
+        with self._on_device():
+            check(lib.csm_seed(self._h, seed, _stream_ptr()), self._h)
         self._seeded = True
+
+    def _check_positions(self, input_pos: torch.Tensor) -> None:
+        """Positions must lie in [0, max_seq_len): checked here when that costs no device sync; positions that only
+        exist on the device are checked by the kernels (device flag -> CSM_E_TOO_LONG from read_frames)."""
+        if input_pos.device.type == "cpu" and input_pos.numel():
+            lo, hi = int(input_pos.min()), int(input_pos.max())
+            if lo < 0 or hi >= self.bb.max_seq_len:
+                raise ValueError(f"input_pos outside [0, {self.bb.max_seq_len}): [{lo}, {hi}]")
 
     def _require(self) -> None:
         assert self._h, "backbone caches are not enabled"     # reference: models.py:153
@@ -355,10 +369,12 @@ class Model:
         b, s, _ = tokens.shape
         if b * s > max(self._max_prefill_rows, 2 * self._max_batch):
             raise ValueError(f"prompt of {b}x{s} rows exceeds max_prefill_rows={self._max_prefill_rows}")
+        self._check_positions(input_pos)
         t = tokens.to(device=self.device, dtype=torch.int32).contiguous()
         m = tokens_mask.to(device=self.device, dtype=torch.uint8).contiguous()
         p = input_pos.to(device=self.device, dtype=torch.int32).contiguous()
-        check(lib.csm_prefill(self._h, t.data_ptr(), m.data_ptr(), p.data_ptr(), b, s, int(_keeps_prompt_prefix), _stream_ptr()), self._h)
+        with self._on_device():
+            check(lib.csm_prefill(self._h, t.data_ptr(), m.data_ptr(), p.data_ptr(), b, s, int(_keeps_prompt_prefix), _stream_ptr()), self._h)
 
     def prefill_prompt(self, tokens: torch.Tensor, tokens_mask: torch.Tensor) -> int:
         """Prefill a prompt that starts at position 0 (B,S,33), reusing the cached backbone KV of the
@@ -366,6 +382,8 @@ class Model:
         The KV entries of the reused rows were produced by the same deterministic kernels from the
         same inputs at the same positions, so the result is bit-identical to a full prefill."""
         b, s, _ = tokens.shape
+        if s > self.bb.max_seq_len:
+            raise ValueError(f"prompt of {s} rows exceeds max_seq_len={self.bb.max_seq_len}")
         t = tokens.to(device=self.device, dtype=torch.int32)
         m = tokens_mask.to(device=self.device, dtype=torch.bool)
         t = torch.where(m, t, torch.zeros_like(t))                    # masked slots do not matter
@@ -393,19 +411,22 @@ class Model:
                                  dtype=torch.bfloat16, device=self.device)
         f = forced.to(device=self.device, dtype=torch.int32).contiguous() if forced is not None else None
         n = noise.to(device=self.device, dtype=torch.bfloat16).contiguous() if noise is not None else None
-        check(lib.csm_depth(self._h, batch, float(temperature), int(topk),
-                            f.data_ptr() if f is not None else None, out.data_ptr(),
-                            logits.data_ptr() if logits is not None else None,
-                            n.data_ptr() if n is not None else None, int(commit), _stream_ptr()), self._h)
+        with self._on_device():
+            check(lib.csm_depth(self._h, batch, float(temperature), int(topk),
+                                f.data_ptr() if f is not None else None, out.data_ptr(),
+                                logits.data_ptr() if logits is not None else None,
+                                n.data_ptr() if n is not None else None, int(commit), _stream_ptr()), self._h)
         return (out, logits) if want_logits else out
 
     def step(self, batch: int, temperature: float, topk: int, use_graph: bool = True) -> None:
         """One continuing frame from on-device state (hipGraph replay); no host sync."""
-        check(lib.csm_frame_step(self._h, batch, float(temperature), int(topk), int(use_graph), _stream_ptr()), self._h)
+        with self._on_device():
+            check(lib.csm_frame_step(self._h, batch, float(temperature), int(topk), int(use_graph), _stream_ptr()), self._h)
 
     def last_frame(self, batch: int) -> torch.Tensor:
         out = torch.empty(batch, self.config.audio_num_codebooks, dtype=torch.int32, device=self.device)
-        check(lib.csm_copy_frame(self._h, batch, out.data_ptr(), _stream_ptr()), self._h)
+        with self._on_device():
+            check(lib.csm_copy_frame(self._h, batch, out.data_ptr(), _stream_ptr()), self._h)
         return out
 
     def read_frames(self, batch: int, first: int = 0, n: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -414,8 +435,9 @@ class Model:
         n = total - first if n is None else n
         frames = torch.empty(max(n, 0), batch, self.config.audio_num_codebooks, dtype=torch.int32)
         eos = torch.empty(batch, dtype=torch.int32)
-        check(lib.csm_read_frames(self._h, batch, first, max(n, 0), frames.data_ptr() if n > 0 else None,
-                                  eos.data_ptr(), _stream_ptr()), self._h)
+        with self._on_device():
+            check(lib.csm_read_frames(self._h, batch, first, max(n, 0), frames.data_ptr() if n > 0 else None,
+                                      eos.data_ptr(), _stream_ptr()), self._h)
         return frames, eos
 
     def num_frames(self) -> int:
@@ -443,10 +465,12 @@ class Model:
                 self.prefill(tokens, tokens_mask, input_pos)
             return self.depth(b, temperature, topk, commit=True)
         # S == 1 steps append beyond the prompt (the reference loop), so the cached prefix stays valid
+        self._check_positions(input_pos)
         t = tokens.to(device=self.device, dtype=torch.int32).contiguous()
         m = tokens_mask.to(device=self.device, dtype=torch.uint8).contiguous()
         p = input_pos.to(device=self.device, dtype=torch.int32).contiguous()
-        check(lib.csm_set_step_inputs(self._h, t.data_ptr(), m.data_ptr(), p.data_ptr(), b, _stream_ptr()), self._h)
+        with self._on_device():
+            check(lib.csm_set_step_inputs(self._h, t.data_ptr(), m.data_ptr(), p.data_ptr(), b, _stream_ptr()), self._h)
         self.step(b, temperature, topk)
         return self.last_frame(b)
 

@@ -26,6 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
+from sesameai.watermarking import CSM_1B_GH_WATERMARK, load_watermarker, watermark, _resample as resample_to
 from sesameai.generator import Segment, load_csm_1b  # noqa: E402  (same import line as the reference, tts_service.py:22)
 
 
@@ -91,6 +92,9 @@ class TTS:
     def load_model(self) -> None:
         print("Open Sesame...")
         self.generator = load_csm_1b(self.device)
+        # reference tts_service.py load_model: the watermarker is loaded next to the model (a pass-through hook
+        # that says so once when silentcipher is not installed)
+        self.watermarker = load_watermarker(self.device)
 
     def list_voices(self) -> list:
         return list(self.voices.keys())
@@ -119,7 +123,7 @@ class TTS:
     @torch.inference_mode()
     def generate_with_context(self, prompt, speaker: int = 1, max_audio_length_ms: float = 60_000,
                               temperature: float = 0.9, topk: int = 50) -> torch.Tensor:
-        """reference: tts_service.py:170-258 (minus the watermark)."""
+        """reference: tts_service.py:170-258, watermark included (:249-256)."""
         g = self.generator
         gen_tokens, gen_masks = g._tokenize_text_segment(prompt, speaker)
         prompt_tokens = torch.cat(self.cached_context_tokens + [gen_tokens], dim=0).long().to(g.device)
@@ -129,7 +133,12 @@ class TTS:
         if prompt_tokens.size(0) >= max_seq_len:
             raise ValueError(f"Input too long ({prompt_tokens.size(0)} tokens). Maximum is {max_seq_len} tokens.")
         frames = g.generate_codes(prompt_tokens, prompt_mask, max_audio_frames, temperature, topk)
-        return g._decode_frames(frames)
+        audio = g._decode_frames(frames)
+        if audio.numel() == 0:
+            return audio
+        # every generated clip carries the public CSM watermark, then goes back to the generator's rate
+        audio, wm_rate = watermark(getattr(self, "watermarker", None), audio, g.sample_rate, CSM_1B_GH_WATERMARK)
+        return resample_to(audio, wm_rate, g.sample_rate)
 
     def generate_audio_segment(self, prompt, fade_duration: int = 50, start_silence_duration: int = 500,
                                end_silence_duration: int = 100, temperature: float = 0.8, topk: int = 40) -> np.ndarray:

@@ -518,3 +518,156 @@ def test_operand_order_activations_are_a_pure_layout_change(monkeypatch, B):
         res[flag] = (logits.cpu(), m.read_frames(B)[0])
         del m
     assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
+
+
+# ----------------------------------------------------------------------------------------
+# the loop's stop rule ON THE DEVICE (reference: sesameai/generator.py:285, tts_service.py:228): k_advance raises
+# eos_at[b] at the first all-zero frame; Generator trims at it.  Random weights never emit such a frame, so the
+# tests make one: a frame whose Exp(1) race is rigged (q[0] tiny, q[v > 0] huge) samples code 0 in every codebook.
+# ----------------------------------------------------------------------------------------
+def _rigged_frame(model, B, S, frame_idx, zero_rows, T=1.0):
+    """Frame `frame_idx` >= 1 by hand: one backbone row per sequence (the previous frame at position S + frame_idx - 1)
+    through csm_prefill, then csm_depth with a noise tensor that makes sequences `zero_rows` sample all zeros."""
+    V = model.config.audio_vocab_size
+    dev = model.device
+    prev = model.last_frame(B).long()
+    tok = torch.zeros(B, 1, 33, dtype=torch.long, device=dev); tok[:, 0, :32] = prev
+    msk = torch.zeros(B, 1, 33, dtype=torch.bool, device=dev); msk[:, 0, :32] = True
+    pos = torch.full((B, 1), S + frame_idx - 1, dtype=torch.long)
+    model.prefill(tok, msk, pos)
+    g = torch.Generator().manual_seed(100 + frame_idx)
+    noise = (0.05 + torch.rand(32, B, V, generator=g)).to(torch.bfloat16)
+    for b in zero_rows:
+        noise[:, b, :] = 1e30
+        noise[:, b, 0] = 1e-30
+    return model.depth(B, T, V, noise=noise, commit=True)
+
+
+def _inject_eos(model, B, S, plan):
+    """Replaces model.step so that frame k of sequence b is all-zero for every (k -> [b...]) of `plan`."""
+    state = {"frame": 0}
+    real_step, real_depth, real_reset = model.step, model.depth, model.reset_caches
+
+    def reset():
+        state["frame"] = 0
+        real_reset()
+
+    def depth(*a, **kw):
+        out = real_depth(*a, **kw)
+        if kw.get("commit", True) and not state.get("inside"):
+            state["frame"] = 1                      # the prompt frame (index 0) exists now
+        return out
+
+    def step(batch, temperature, topk, use_graph=True):
+        k = state["frame"]
+        if k in plan:
+            state["inside"] = True
+            _rigged_frame(model, B, S, k, plan[k], T=1.0)
+            state["inside"] = False
+        else:
+            real_step(batch, temperature, topk, use_graph)
+        state["frame"] = k + 1
+
+    model.step, model.depth, model.reset_caches = step, depth, reset
+    return lambda: (setattr(model, "step", real_step), setattr(model, "depth", real_depth), setattr(model, "reset_caches", real_reset))
+
+
+def test_device_side_eos_flag_and_trimming_b1(tiny):
+    from sesameai.generator import Generator
+    from oracle import csm_ref as C
+    shape, w, m = tiny
+    gen = Generator.__new__(Generator)
+    gen._model, gen.device, gen._eos_poll, gen._stream_buffer_size, gen._mimi_stream = m, m.device, 4, 10, None
+    g = torch.Generator().manual_seed(5)
+    tok, msk = C.build_prompt([(torch.randint(0, shape.text_vocab_size, (9,), generator=g).tolist(), None)])
+    S = tok.shape[0]
+    for k in (1, 3, 4, 6, 11):                      # mid-block, last of a block, first of a block (poll = 4)
+        undo = _inject_eos(m, 1, S, {k: [0]})
+        try:
+            m.seed(11)
+            frames = gen.generate_codes(tok, msk, 20, 0.9, 50)
+        finally:
+            undo()
+        allf, eos = m.read_frames(1)
+        assert int(eos[0]) == k == int(gen.last_eos_at[0]), (k, eos)
+        assert int(allf[k].abs().sum()) == 0 and int((allf[:k] != 0).any(dim=2).all()) == 1        # frame k is the all-zero one
+        assert frames.shape == (k, 1, 32) and torch.equal(frames, allf[:k])                       # handed out: frames before it
+        assert allf.shape[0] <= k + 1 + 2 * 4                                                     # and the loop stopped soon after
+
+
+def test_device_side_eos_batch_of_three_different_stop_frames(tiny):
+    from sesameai.generator import Generator
+    from oracle import csm_ref as C
+    shape, w, m = tiny
+    gen = Generator.__new__(Generator)
+    gen._model, gen.device, gen._eos_poll = m, m.device, 4
+    g = torch.Generator().manual_seed(6)
+    prompts = [C.build_prompt([(torch.randint(0, shape.text_vocab_size, (7,), generator=g).tolist(), None)]) for _ in range(3)]
+    tok = torch.stack([p[0] for p in prompts]); msk = torch.stack([p[1] for p in prompts])
+    S = tok.shape[1]
+    undo = _inject_eos(m, 3, S, {2: [1], 5: [0], 9: [2]})
+    try:
+        m.seed(12)
+        frames = gen.generate_codes(tok, msk, 30, 0.9, 50)
+    finally:
+        undo()
+    assert gen.last_eos_at.tolist() == [5, 2, 9]
+    assert 10 <= frames.shape[0] <= 10 + 2 * 4, frames.shape         # all three done at frame 9: stops within the enqueued blocks
+    for b, k in enumerate([5, 2, 9]):
+        assert int(frames[k, b].abs().sum()) == 0
+        assert bool((frames[:k, b] != 0).any(dim=1).all())
+    # a sequence that already stopped keeps its FIRST stop frame even if it emits zeros again
+    undo = _inject_eos(m, 3, S, {2: [1], 4: [1, 0], 6: [2]})
+    try:
+        m.seed(13)
+        gen.generate_codes(tok, msk, 30, 0.9, 50)
+    finally:
+        undo()
+    assert gen.last_eos_at.tolist() == [4, 2, 6]
+
+
+def test_zeroed_heads_stop_at_the_prompt_frame_and_generate_returns_empty_audio():
+    """Advisor's case: head weights of zero -> every logit 0 -> greedy picks code 0 everywhere -> the very first frame is
+    the EOS frame; Generator.generate returns torch.tensor([]) like the reference (generator.py:296-297)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sesameai.generator import Generator
+    from sesameai.models import Model, csm_tiny_args, synthetic_state_dict
+    sd = synthetic_state_dict(csm_tiny_args(), seed=1234)
+    sd["codebook0_head.weight"] = torch.zeros_like(sd["codebook0_head.weight"])
+    sd["audio_head"] = torch.zeros_like(sd["audio_head"])
+    m = Model(csm_tiny_args(), sd, max_frames=32, max_prefill_rows=64)
+
+    class Codec:
+        sample_rate = 24_000
+        def decode(self, codes): raise AssertionError("nothing to decode")
+
+    gen = Generator(m, audio_tokenizer=Codec())
+    audio = gen.generate([3, 4, 5, 6], 0, [], max_audio_length_ms=800, temperature=1.0, topk=1)
+    assert audio.numel() == 0
+    frames, eos = m.read_frames(1)
+    assert int(eos[0]) == 0 and int(frames[0].abs().sum()) == 0
+    assert list(gen.generate_stream([3, 4, 5, 6], 0, [], max_audio_length_ms=800, temperature=1.0, topk=1)) == []
+
+
+def test_positions_beyond_max_seq_are_reported_not_clamped(tiny):
+    """ADVICE r1: pos >= max_seq used to be clamped silently inside the kernels.  Host-visible positions raise at once;
+    positions that only exist on the device raise CSM_E_TOO_LONG at the next read_frames."""
+    shape, w, m = tiny                     # tiny backbone: max_seq_len 256
+    tok = torch.zeros(1, 4, 33, dtype=torch.long); msk = torch.zeros(1, 4, 33, dtype=torch.bool); msk[:, :, 32] = True
+    with pytest.raises(ValueError, match="input_pos outside"):
+        m.prefill(tok, msk, torch.tensor([[253, 254, 255, 256]]))
+    m.reset_caches()
+    m.prefill(tok, msk, torch.tensor([[250, 251, 252, 253]]))
+    m.depth(1, 1.0, 1, commit=True)
+    for _ in range(2):                     # positions 254, 255: still inside
+        m.step(1, 1.0, 1)
+    frames, eos = m.read_frames(1)
+    assert frames.shape[0] == 3
+    m.step(1, 1.0, 1)                      # position 256: outside
+    with pytest.raises(RuntimeError, match="CSM_E_TOO_LONG"):
+        m.read_frames(1)
+    m.reset_caches()                       # the flag is part of the per-utterance state
+    m.prefill(tok, msk, torch.tensor([[0, 1, 2, 3]]))
+    m.depth(1, 1.0, 1, commit=True)
+    assert m.read_frames(1)[0].shape[0] == 1
