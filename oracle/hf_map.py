@@ -44,8 +44,10 @@ def _load_layers(hf_layers, w: Dict[str, torch.Tensor], pfx: str, s: LlamaShape,
         layer.load_state_dict({k: v.to(dtype) for k, v in sd.items()}, strict=True)
 
 
-def build_hf_csm(shape: CsmShape, w: Dict[str, torch.Tensor], dtype=torch.float32):
-    """Returns (backbone: CsmBackboneModel, depth: CsmDepthDecoderModel, heads [31,d,V])."""
+def build_hf_csm(shape: CsmShape, w: Dict[str, torch.Tensor], dtype=torch.float32, attn: str = "eager"):
+    """Returns (backbone: CsmBackboneModel, depth: CsmDepthDecoderModel, heads [31,d,V]).
+    ``attn``: "eager" (explicit matmul/softmax; the fp32 cross-check) or "sdpa" (F.scaled_dot_product_attention, the op
+    torchtune 0.4.0 calls -- the bf16 cross-check needs the same fused kernel on both sides)."""
     from transformers.models.csm.configuration_csm import CsmConfig, CsmDepthDecoderConfig
     from transformers.models.csm.modeling_csm import CsmBackboneModel, CsmDepthDecoderModel
 
@@ -65,8 +67,8 @@ def build_hf_csm(shape: CsmShape, w: Dict[str, torch.Tensor], dtype=torch.float3
         max_position_embeddings=bb.max_seq_len, rms_norm_eps=bb.norm_eps,
         rope_parameters=_rope_params(bb), head_dim=bb.head_dim,
         depth_decoder_config=dcfg.to_dict())
-    cfg._attn_implementation = "eager"
-    dcfg._attn_implementation = "eager"
+    cfg._attn_implementation = attn
+    dcfg._attn_implementation = attn
     with torch.no_grad():
         backbone = CsmBackboneModel(cfg).to(dtype).eval()
         depth = CsmDepthDecoderModel(dcfg).to(dtype).eval()

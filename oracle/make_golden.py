@@ -14,6 +14,12 @@ Files (all torch.save'd dicts of small tensors):
   sampler_cases.pt  sample_topk inputs/outputs incl. tie cases and supplied Exp(1) noise.
   prompt_layout.pt  (tokens, mask) of a 2-segment toy prompt (generator.py:63-109 layout).
   mimi_*.pt         Mimi decode of a seeded (1,32,10) code block: whole and stateless chunks.
+  csm1b_cfg2.pt     CSM-1B, BASELINE config 2's prompt (bench.py's seeded S=190 prompt: 40 text + 125 audio + EOS + 24 text
+                    rows): 6 greedy frames, top-8 logits, margins, bf16-vs-fp32 gap.
+  csm1b_cfg3.pt     the same shape at B=32 (bench.py's prompts of utterances 0..31): 2 frames of the batched oracle, top-8
+                    logits and margins per (frame, codebook, utterance).
+  csm1b_cfg5.pt     BASELINE config 5: fp8-e4m3-dequantised weights (oracle.csm_ref.fp8_dequantized), S=1334 prompt (10
+                    segments), 2 frames; and a 1700-row prompt: the prompt frame (p = 1699) and one step frame (p = 1700).
 """
 from __future__ import annotations
 
@@ -82,6 +88,48 @@ def frames_golden(shape: C.CsmShape, weights, prompt, n_frames: int, keep_full: 
     return out
 
 
+def bench_prompt(shape: C.CsmShape, seed: int, segments: int = 1, ctx_text: int = 40, ctx_frames: int = 125, gen_text: int = 24):
+    """bench.py::synthetic_prompt for one utterance (same generator call order), restated here so the golden files do
+    not depend on the benchmark script; tests assert the two agree."""
+    g = torch.Generator().manual_seed(seed)
+    rows = segments * (ctx_text + ctx_frames + 1) + gen_text
+    t = torch.zeros(rows, 33, dtype=torch.long)
+    m = torch.zeros(rows, 33, dtype=torch.bool)
+    r = 0
+    for _ in range(segments):
+        t[r:r + ctx_text, 32] = torch.randint(0, shape.text_vocab_size, (ctx_text,), generator=g); m[r:r + ctx_text, 32] = True
+        r += ctx_text
+        t[r:r + ctx_frames, :32] = torch.randint(0, 2048, (ctx_frames, 32), generator=g); m[r:r + ctx_frames + 1, :32] = True
+        r += ctx_frames + 1
+    t[r:r + gen_text, 32] = torch.randint(0, shape.text_vocab_size, (gen_text,), generator=g); m[r:r + gen_text, 32] = True
+    return t, m
+
+
+@torch.inference_mode()
+def frames_golden_batch(shape: C.CsmShape, weights, toks, msks, n_frames: int):
+    """Batched oracle (B utterances of equal length), greedy, teacher-forced on its own trajectory: per frame the codes
+    [B][32], top-8 logits [32][B][8] and the top-1/top-2 margin [32][B]."""
+    B = toks.shape[0]
+    m = C.OracleModel(shape, weights)
+    m.setup_caches(B)
+    cur_t, cur_m = toks, msks
+    pos = torch.arange(toks.size(1)).unsqueeze(0).repeat(B, 1)
+    codes, top_v, top_i, margin = [], [], [], []
+    for f in range(n_frames):
+        t0 = time.time()
+        tr = C.FrameTrace()
+        s = m.generate_frame(cur_t, cur_m, pos, 1.0, 1, greedy=True, trace=tr)
+        lg = torch.stack(tr.logits, 0)                           # (32, B, V) bf16
+        v, i = torch.topk(lg.float(), 8, dim=-1)
+        codes.append(s.clone()); top_v.append(v.to(torch.bfloat16)); top_i.append(i.to(torch.int16)); margin.append(v[..., 0] - v[..., 1])
+        cur_t = torch.cat([s.long(), torch.zeros(B, 1).long()], dim=1).unsqueeze(1)
+        cur_m = torch.cat([torch.ones_like(s).bool(), torch.zeros(B, 1).bool()], dim=1).unsqueeze(1)
+        pos = pos[:, -1:] + 1
+        print(f"  batch frame {f}: {time.time() - t0:.1f}s", flush=True)
+    return dict(prompt_tokens=toks, prompt_mask=msks, codes=torch.stack(codes), top_v=torch.stack(top_v), top_i=torch.stack(top_i),
+                margin=torch.stack(margin))
+
+
 def sampler_cases():
     g = torch.Generator().manual_seed(77)
     V = 2051
@@ -140,6 +188,32 @@ def main():
         gold = frames_golden(shape, w, toy_prompt(shape, 2025, 16, 0), a.frames, keep_full=False, with_fp32=True)
         gold.update(weight_seed=1234, prompt_seed=2025)
         torch.save(gold, os.path.join(OUT, "csm1b_frames.pt"))
+    if want("cfg2") or want("cfg3") or want("cfg5"):
+        shape = C.csm_1b()
+        w = C.make_weights(shape, seed=1234)
+        if want("cfg2"):
+            gold = frames_golden(shape, w, bench_prompt(shape, 2025), 6, keep_full=False, with_fp32=True)
+            gold.update(weight_seed=1234, prompt_seed=2025)
+            torch.save(gold, os.path.join(OUT, "csm1b_cfg2.pt"))
+        if want("cfg3"):
+            ps = [bench_prompt(shape, 2025 + b) for b in range(32)]
+            gold = frames_golden_batch(shape, w, torch.stack([p[0] for p in ps]), torch.stack([p[1] for p in ps]), 2)
+            gold.update(weight_seed=1234, prompt_seed=2025)
+            gold["prompt_tokens"] = gold["prompt_tokens"].to(torch.int32)
+            torch.save(gold, os.path.join(OUT, "csm1b_cfg3.pt"))
+        if want("cfg5"):
+            w8 = C.fp8_dequantized(w)
+            del w
+            g5 = frames_golden(shape, w8, bench_prompt(shape, 5000, segments=10, ctx_text=30, ctx_frames=100), 2, keep_full=False, with_fp32=True)
+            tok, msk = bench_prompt(shape, 5001, segments=12, ctx_text=30, ctx_frames=100, gen_text=128)      # 12 x 131 + 128 = 1700 rows
+            gl = frames_golden(shape, w8, (tok, msk), 2, keep_full=False, with_fp32=True)
+            gold = dict(weight_seed=1234, s1334=g5, s1700=gl,
+                        deq_checksum=torch.stack([w8["backbone.layers.3.mlp.w2.weight"].float().abs().sum(),
+                                                  w8["decoder.layers.1.attn.q_proj.weight"].float().abs().sum(),
+                                                  w8["audio_head"].float().abs().sum()]))
+            for d in (g5, gl):
+                d["prompt_tokens"] = d["prompt_tokens"].to(torch.int32)
+            torch.save(gold, os.path.join(OUT, "csm1b_cfg5.pt"))
 
 
 if __name__ == "__main__":

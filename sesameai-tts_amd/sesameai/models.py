@@ -45,6 +45,9 @@ FLAVORS: Dict[str, LlamaFlavor] = {
     # small stand-ins with the same head dims (64 / 128), used by the test-suite
     "llama-tiny-bb": LlamaFlavor(2, 8, 2, 512, 1024, max_seq_len=256),
     "llama-tiny-dec": LlamaFlavor(2, 4, 2, 512, 1024, max_seq_len=256),
+    # the tiny backbone with the real 2048-position cache: long-context paths (split-K decode attention over ~1700 keys,
+    # 1334-row prompts) against the live oracle in seconds
+    "llama-tiny-bb-2k": LlamaFlavor(2, 8, 2, 512, 1024, max_seq_len=2048),
 }
 
 
@@ -63,6 +66,10 @@ def csm_1b_args() -> ModelArgs:
 
 def csm_tiny_args() -> ModelArgs:
     return ModelArgs("llama-tiny-bb", "llama-tiny-dec", 1000, 2051, 32)
+
+
+def csm_tiny_2k_args() -> ModelArgs:
+    return ModelArgs("llama-tiny-bb-2k", "llama-tiny-dec", 1000, 2051, 32)
 
 
 # ----------------------------------------------------------------------------------------

@@ -671,3 +671,197 @@ def test_positions_beyond_max_seq_are_reported_not_clamped(tiny):
     m.prefill(tok, msk, torch.tensor([[0, 1, 2, 3]]))
     m.depth(1, 1.0, 1, commit=True)
     assert m.read_frames(1)[0].shape[0] == 1
+
+
+# ----------------------------------------------------------------------------------------
+# BASELINE configs 2, 3 and 5 at their stated size against goldens of the oracle (oracle/make_golden.py cfg2/cfg3/cfg5)
+# ----------------------------------------------------------------------------------------
+def _bench_args():
+    from types import SimpleNamespace
+    return SimpleNamespace(ctx_text=40, ctx_frames=125, gen_text=24)
+
+
+def _teacher_forced(m, gold, S, n_frames, noise, what):
+    """depth() on the current backbone state for golden frames 0..n-1, feeding the golden codes back one row at a time."""
+    max_diff, mism = 0.0, []
+    for f in range(n_frames):
+        forced = gold["codes"][f].reshape(1, -1)
+        out, logits = m.depth(1, 1.0, 1, forced=forced, want_logits=True, commit=False)
+        lg = logits[:, 0].float().cpu()
+        max_diff = max(max_diff, (torch.gather(lg, 1, gold["top_i"][f].long()) - gold["top_v"][f].float()).abs().max().item())
+        for cb in (out[0].cpu() != gold["codes"][f].reshape(-1)).nonzero().flatten().tolist():
+            mism.append((f, cb, float(gold["margin"][f, cb])))
+        if f + 1 < n_frames:
+            row = torch.zeros(1, 1, 33, dtype=torch.long); row[0, 0, :32] = gold["codes"][f].reshape(-1).long()
+            rmask = torch.ones(1, 1, 33, dtype=torch.bool); rmask[0, 0, 32] = False
+            m.prefill(row, rmask, torch.tensor([[S + f]]))
+    print(f"{what}: max|dlogit|={max_diff:.4f} (oracle bf16-vs-fp32 gap {noise:.4f}); greedy mismatches {mism}")
+    assert max_diff <= 2 * noise + 1e-3, what
+    for f, cb, margin in mism:
+        assert margin <= 2 * noise, f"{what}: greedy index differs at frame {f} codebook {cb} with margin {margin}"
+
+
+def test_csm1b_config2_prompt_vs_golden(csm1b):
+    """BASELINE config 2 = the bench workload: S = 190 prompt rows WITH audio rows (40 text + 125 audio + EOS + 24 text),
+    through both prefill forms (Generator's prompt mode and bench.py's plain csm_prefill), 6 frames."""
+    import bench
+    from oracle import csm_ref as C
+    from sesameai.models import Model, csm_1b_args
+    _, sd = csm1b
+    gold = torch.load(os.path.join(GOLD, "csm1b_cfg2.pt"))
+    tok, msk = gold["prompt_tokens"], gold["prompt_mask"]
+    bt, bm = bench.synthetic_prompt(_bench_args(), 1, C.csm_1b().text_vocab_size, seed0=2025)
+    assert torch.equal(bt[0], tok) and torch.equal(bm[0], msk), "golden prompt is not bench.py's config-2 prompt"
+    S = tok.shape[0]
+    assert S == 190
+    noise = float(gold["bf16_vs_fp32_gap"].max())
+    m = Model(csm_1b_args(), sd, max_frames=64, max_prefill_rows=256)
+    m.setup_caches(1)
+    m.prefill_prompt(tok.unsqueeze(0), msk.unsqueeze(0))
+    _teacher_forced(m, gold, S, gold["codes"].shape[0], noise, "config 2, prompt-mode prefill")
+    m.reset_caches()
+    m.prefill(tok.unsqueeze(0), msk.unsqueeze(0), torch.arange(S).unsqueeze(0))
+    _teacher_forced(m, gold, S, 2, noise, "config 2, plain prefill (bench.py)")
+    # the replayed hipGraph frame step from the golden state: greedy codes equal the oracle's up to the first near-tie
+    m.reset_caches()
+    m.prefill(tok.unsqueeze(0), msk.unsqueeze(0), torch.arange(S).unsqueeze(0))
+    m.depth(1, 1.0, 1, forced=gold["codes"][0].reshape(1, -1), commit=True)
+    n_cmp = 0
+    for f in range(1, gold["codes"].shape[0]):
+        row = torch.zeros(1, 1, 33, dtype=torch.long); row[0, 0, :32] = gold["codes"][f - 1].reshape(-1).long()
+        rmask = torch.ones(1, 1, 33, dtype=torch.bool); rmask[0, 0, 32] = False
+        got = m.generate_frame(row, rmask, torch.tensor([[S + f - 1]]), 1.0, 1)[0].cpu()
+        near = (gold["margin"][f] <= 2 * noise).nonzero().flatten()
+        upto = int(near[0]) if near.numel() else 32
+        assert torch.equal(got[:upto], gold["codes"][f].reshape(-1)[:upto].to(got.dtype)), f"graph step, frame {f}"
+        n_cmp += upto
+    assert n_cmp >= 32, "too few comparable greedy decisions"
+
+
+def test_csm1b_config3_batch32_vs_golden(csm1b):
+    """BASELINE config 3: B = 32 x the config-2 shape.  Teacher-forced logits of every utterance against the BATCHED
+    oracle (the >= 24-row operand-order decode path included -- vs the oracle, not vs itself), then a hipGraph-replayed
+    frame step whose greedy codes must equal the oracle's up to each utterance's first near-tie."""
+    import bench
+    from oracle import csm_ref as C
+    from sesameai.models import Model, csm_1b_args
+    _, sd = csm1b
+    gold = torch.load(os.path.join(GOLD, "csm1b_cfg3.pt"))
+    g2 = torch.load(os.path.join(GOLD, "csm1b_cfg2.pt"))
+    noise = float(g2["bf16_vs_fp32_gap"].max())
+    tok, msk = gold["prompt_tokens"].long(), gold["prompt_mask"]
+    B, S = tok.shape[0], tok.shape[1]
+    assert (B, S) == (32, 190)
+    bt, bm = bench.synthetic_prompt(_bench_args(), B, C.csm_1b().text_vocab_size, seed0=2025)
+    assert torch.equal(bt, tok) and torch.equal(bm, msk)
+    m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S)
+    m.setup_caches(B)
+    m.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+    codes0 = gold["codes"][0]                                                     # [B][32]
+    out, logits = m.depth(B, 1.0, 1, forced=codes0, want_logits=True, commit=True)    # logits [32][B][V]
+    lg = logits.float().cpu()
+    d0 = (torch.gather(lg, 2, gold["top_i"][0].long()) - gold["top_v"][0].float()).abs().max().item()
+    bad = (out.cpu() != codes0).nonzero()
+    for b, cb in bad.tolist():
+        assert float(gold["margin"][0][cb, b]) <= 2 * noise, f"frame 0 utterance {b} codebook {cb}"
+    # frame 1: graph replay on the golden inputs (decode-step kernels at M = 32 rows, operand-order activations)
+    row = torch.zeros(B, 1, 33, dtype=torch.long); row[:, 0, :32] = codes0.long()
+    rmask = torch.ones(B, 1, 33, dtype=torch.bool); rmask[:, 0, 32] = False
+    got = m.generate_frame(row, rmask, torch.full((B, 1), S), 1.0, 1).cpu()
+    n_cmp = 0
+    for b in range(B):
+        near = (gold["margin"][1][:, b] <= 2 * noise).nonzero().flatten()
+        upto = int(near[0]) if near.numel() else 32
+        assert torch.equal(got[b, :upto], gold["codes"][1][b, :upto].to(got.dtype)), f"graph step, utterance {b}"
+        n_cmp += upto
+    # and its logits, teacher-forced, through the same decode-step kernels
+    m2 = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S)
+    m2.setup_caches(B)
+    m2.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+    m2.prefill(row, rmask, torch.full((B, 1), S))
+    out1, logits1 = m2.depth(B, 1.0, 1, forced=gold["codes"][1], want_logits=True, commit=False)
+    d1 = (torch.gather(logits1.float().cpu(), 2, gold["top_i"][1].long()) - gold["top_v"][1].float()).abs().max().item()
+    print(f"config 3 (B=32): max|dlogit| frame 0 {d0:.4f}, frame 1 {d1:.4f} (gap {noise:.4f}); {len(bad)} near-tie index differences; "
+          f"{n_cmp} of {B * 32} graph-step decisions compared")
+    assert max(d0, d1) <= 2 * noise + 1e-3
+    assert n_cmp >= B * 8
+
+
+def test_csm1b_config5_fp8_long_context_vs_golden(csm1b):
+    """BASELINE config 5 in its stated form: fp8-e4m3 weight stream, S = 1334 prompt rows (10 segments) and positions
+    ~1700 (KV stream 55 MB per step), against the oracle running on the dequantised weights."""
+    from sesameai.models import Model, csm_1b_args
+    _, sd = csm1b
+    gold = torch.load(os.path.join(GOLD, "csm1b_cfg5.pt"))
+    m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=1700, weights_dtype="fp8")
+    got = torch.stack([m._w["backbone.layers.3.mlp.w2.weight"].float().abs().sum(), m._w["decoder.layers.1.attn.q_proj.weight"].float().abs().sum(),
+                       m._w["audio_head"].float().abs().sum()]).cpu()
+    assert torch.allclose(got, gold["deq_checksum"], rtol=1e-4), "product and oracle fp8 dequantisation differ"
+    m.setup_caches(1)
+    for key, S_want in (("s1334", 1334), ("s1700", 1700)):
+        g = gold[key]
+        tok, msk = g["prompt_tokens"].long(), g["prompt_mask"]
+        S = tok.shape[0]
+        assert S == S_want
+        noise = float(g["bf16_vs_fp32_gap"].max())
+        m.reset_caches()
+        m.prefill_prompt(tok.unsqueeze(0), msk.unsqueeze(0))
+        _teacher_forced(m, g, S, 2, noise, f"config 5 fp8, S={S}")
+        # replayed graph step at position S (fp8 GEMV stream, split-K attention over S+1 keys)
+        m.reset_caches()
+        m.prefill_prompt(tok.unsqueeze(0), msk.unsqueeze(0))
+        m.depth(1, 1.0, 1, forced=g["codes"][0].reshape(1, -1), commit=True)
+        row = torch.zeros(1, 1, 33, dtype=torch.long); row[0, 0, :32] = g["codes"][0].reshape(-1).long()
+        rmask = torch.ones(1, 1, 33, dtype=torch.bool); rmask[0, 0, 32] = False
+        got1 = m.generate_frame(row, rmask, torch.tensor([[S]]), 1.0, 1)[0].cpu()
+        near = (g["margin"][1] <= 2 * noise).nonzero().flatten()
+        upto = int(near[0]) if near.numel() else 32
+        assert torch.equal(got1[:upto], g["codes"][1].reshape(-1)[:upto].to(got1.dtype)), f"graph step at p={S}"
+
+
+@pytest.mark.parametrize("weights", ["bf16", "fp8"])
+def test_tiny_long_context_vs_live_oracle(weights):
+    """The tiny shapes with the real 2048-position cache: a 1334-row prompt (flash prompt attention over 1334 keys), then
+    frames at p = 1334.. and, from a 1990-row prompt, frames up to the LAST position (2047), HIP vs the live oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import csm_ref as C
+    from sesameai.models import Model, csm_tiny_2k_args, synthetic_state_dict
+    shape = C.csm_tiny_2k()
+    w = C.make_weights(shape, seed=1234)
+    if weights == "fp8":
+        w = C.fp8_dequantized(w)
+    sd = synthetic_state_dict(csm_tiny_2k_args(), seed=1234)
+    m = Model(csm_tiny_2k_args(), sd, max_frames=80, max_prefill_rows=2048, weights_dtype=weights)
+    m.setup_caches(1)
+    gold = torch.load(os.path.join(GOLD, "tiny_frames.pt"))
+    noise = float(gold["bf16_vs_fp32_gap"].max())
+    g = torch.Generator().manual_seed(31)
+    for S, n_frames in ((1334, 4), (1990, 59)):
+        rows_t = torch.zeros(S, 33, dtype=torch.long); rows_m = torch.zeros(S, 33, dtype=torch.bool)
+        is_text = torch.rand(S, generator=g) < 0.25
+        rows_t[is_text, 32] = torch.randint(0, shape.text_vocab_size, (int(is_text.sum()),), generator=g); rows_m[is_text, 32] = True
+        rows_t[~is_text, :32] = torch.randint(0, 2048, (int((~is_text).sum()), 32), generator=g); rows_m[~is_text, :32] = True
+        om = C.OracleModel(shape, w); om.setup_caches(1)
+        m.reset_caches()
+        m.prefill_prompt(rows_t.unsqueeze(0), rows_m.unsqueeze(0))
+        cur_t, cur_m, pos = rows_t.unsqueeze(0), rows_m.unsqueeze(0), torch.arange(S).unsqueeze(0)
+        worst = 0.0
+        for f in range(n_frames):
+            tr = C.FrameTrace()
+            ref = om.generate_frame(cur_t, cur_m, pos, 1.0, 1, greedy=True, trace=tr)
+            want = torch.stack(tr.logits, 0)[:, 0].float()
+            check_logits = f < 3 or f >= n_frames - 3
+            if check_logits:
+                out, logits = m.depth(1, 1.0, 1, forced=ref, want_logits=True, commit=False)
+                worst = max(worst, (logits[:, 0].float().cpu() - want).abs().max().item())
+                top2 = torch.topk(want, 2, dim=-1)[0]
+                for cb in (out[0].cpu() != ref[0]).nonzero().flatten().tolist():
+                    assert float(top2[cb, 0] - top2[cb, 1]) <= 2 * noise, (S, f, cb)
+            cur_t = torch.cat([ref.long(), torch.zeros(1, 1).long()], dim=1).unsqueeze(1)
+            cur_m = torch.cat([torch.ones_like(ref).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
+            pos = pos[:, -1:] + 1
+            if int(pos[0, 0]) < 2048:
+                m.prefill(cur_t, cur_m, pos)                          # one decode row at p = S + f
+        print(f"tiny-2k {weights} S={S}: {n_frames} frames up to p={int(pos[0, 0]) - 1}, max|dlogit|={worst:.4f} (noise floor {noise:.4f})")
+        assert worst <= 2 * noise + 1e-3

@@ -231,6 +231,79 @@ def test_attention(abi, H, KV, hd, nsplit):
     assert diff <= err_ref + err_hip + 1e-6
 
 
+@pytest.mark.parametrize("nsplit", [1, 8])
+def test_decode_attention_over_long_key_ranges(abi, nsplit):
+    """p in {0, 1, 63, 1500} -- plus the last tile boundary (1023) and the last slot (2047) of the
+    2048-position backbone cache, with the B=1 split-K form (8 key ranges merged by their softmax states) and the
+    single-block form.  Graded against exact fp64 attention and the oracle's SDPA like test_attention."""
+    H, KV, hd, smax = 32, 8, 64, 2048
+    g = torch.Generator().manual_seed(1000 + nsplit)
+    ps = [0, 1, 63, 1023, 1500, 2047]
+    B = len(ps)
+    q = rnd((B, 1, H, hd), g)
+    kc, vc = rnd((B, KV, smax, hd), g), rnd((B, KV, smax, hd), g)
+    pos = torch.tensor(ps)[:, None]
+    for b, p in enumerate(ps):                                   # slots past the position hold garbage, NaN bit patterns included
+        kc[b, :, p + 1:] = float("nan"); vc[b, :, p + 1:] = float("nan")
+    rep = H // KV
+    kz, vz = torch.nan_to_num(kc, nan=0.0), torch.nan_to_num(vc, nan=0.0)
+    kk = kz.unsqueeze(2).expand(B, KV, rep, smax, hd).reshape(B, H, smax, hd)
+    vv = vz.unsqueeze(2).expand(B, KV, rep, smax, hd).reshape(B, H, smax, hd)
+    mask = torch.arange(smax)[None, None, :] <= pos[:, :, None]
+    want = F.scaled_dot_product_attention(q.transpose(1, 2), kk, vv, attn_mask=mask[:, None]).transpose(1, 2)
+    sc = (q.double().transpose(1, 2) @ kk.double().transpose(-1, -2)) / hd ** 0.5
+    exact = (sc.masked_fill(~mask[:, None], float("-inf")).softmax(-1) @ vv.double()).transpose(1, 2)
+    out = torch.zeros(B, H * hd, dtype=torch.bfloat16, device="cuda")
+    part = torch.zeros(B * H * nsplit * (hd + 4), dtype=torch.float32, device="cuda")
+    qd, kd, vd, pd = dev(q), dev(kc), dev(vc), dev(pos.reshape(-1), torch.int32)
+    _ck(abi, abi.lib.csm_op_attn(B, 1, H, KV, hd, smax, nsplit, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(),
+                                 pd.data_ptr(), out.data_ptr(), part.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().float().view(B, 1, H, hd).double()
+    assert torch.isfinite(got).all()
+    for b, p in enumerate(ps):
+        err_hip = (got[b] - exact[b]).abs().max().item()
+        err_ref = (want[b].double() - exact[b]).abs().max().item()
+        ulp = 2.0 ** -8 * max(1.0, exact[b].abs().max().item())
+        print(f"decode attention p={p} nsplit={nsplit}: |hip-exact|={err_hip:.4g} |oracle-exact|={err_ref:.4g}")
+        assert err_hip <= ulp, (p, err_hip)
+        assert (got[b] - want[b].double()).abs().max().item() <= err_ref + err_hip + 1e-6, p
+
+
+@pytest.mark.parametrize("S,start", [(1334, 0), (200, 1500), (48, 2000)])
+def test_prompt_flash_attention_over_long_prompts(abi, S, start):
+    """k_attn_flash over >= 1334 keys (BASELINE config 5's prompt) and over the tail of the 2048-slot cache: the online
+    softmax walks up to 64 key tiles; same grading as the short-prompt test."""
+    H, KV, hd, smax = 32, 8, 64, 2048
+    g = torch.Generator().manual_seed(S + start)
+    q = rnd((1, S, H, hd), g)
+    kc, vc = rnd((1, KV, smax, hd), g), rnd((1, KV, smax, hd), g)
+    pos = start + torch.arange(S)[None, :]
+    kc[0, :, start + S:] = float("nan"); vc[0, :, start + S:] = float("nan")
+    rep = H // KV
+    kz, vz = torch.nan_to_num(kc, nan=0.0), torch.nan_to_num(vc, nan=0.0)
+    kk = kz.unsqueeze(2).expand(1, KV, rep, smax, hd).reshape(1, H, smax, hd)
+    vv = vz.unsqueeze(2).expand(1, KV, rep, smax, hd).reshape(1, H, smax, hd)
+    mask = torch.arange(smax)[None, None, :] <= pos[:, :, None]
+    want = F.scaled_dot_product_attention(q.transpose(1, 2), kk, vv, attn_mask=mask[:, None]).transpose(1, 2)
+    sc = (q.double().transpose(1, 2) @ kk.double().transpose(-1, -2)) / hd ** 0.5
+    exact = (sc.masked_fill(~mask[:, None], float("-inf")).softmax(-1) @ vv.double()).transpose(1, 2)
+    out = torch.zeros(S, H * hd, dtype=torch.bfloat16, device="cuda")
+    part = torch.zeros(16, dtype=torch.float32, device="cuda")
+    qd, kd, vd, pd = dev(q), dev(kc), dev(vc), dev(pos.reshape(-1), torch.int32)
+    _ck(abi, abi.lib.csm_op_attn(S, S, H, KV, hd, smax, 0, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), pd.data_ptr(),
+                                 out.data_ptr(), part.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().float().view(1, S, H, hd).double()
+    assert torch.isfinite(got).all()
+    err_hip = (got - exact).abs().max().item()
+    err_ref = (want.double() - exact).abs().max().item()
+    print(f"flash attention S{S} from {start}: |hip-exact|={err_hip:.4g} |oracle-exact|={err_ref:.4g}")
+    ulp = 2.0 ** -8 * max(1.0, exact.abs().max().item())
+    assert err_hip <= 1.5 * ulp
+    assert (got - want.double()).abs().max().item() <= err_ref + err_hip + 1e-6
+
+
 @pytest.mark.parametrize("H,KV,S,start", [(32, 8, 77, (0, 5, 100)), (8, 2, 33, (0, 0, 190)), (16, 4, 1, (0, 63, 64))])
 def test_prompt_flash_attention_vs_exact_and_oracle(abi, H, KV, S, start):
     """attn_flash.cuh (prompt rows, hd 64): S^T = K.Q^T and O^T += V^T.P^T on the matrix cores, fp32 softmax, P rounded
