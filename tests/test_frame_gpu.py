@@ -143,8 +143,16 @@ def test_tiny_graph_replay_equals_eager_and_oracle_free_run(tiny):
                                      max_seq_len=256), 0)
     same = (ref == traces[0]).all(dim=1)
     n_same = int(same.float().cumprod(0).sum())
-    print(f"free-running greedy: first {n_same}/10 frames identical to the oracle")
-    assert n_same >= 1 and torch.equal(ref[0], gold["codes"][0])
+    # The free-running trace must equal the oracle's up to (not including) the first frame in which the ORACLE's own
+    # top-1/top-2 margin drops under the rounding-noise floor (2 x its bf16-vs-fp32 gap) -- before that frame nothing
+    # is free.  The golden file holds the margins of the oracle's trajectory (= ref while they agree).
+    noise = float(gold["bf16_vs_fp32_gap"].max())
+    assert torch.equal(ref[:gold["codes"].shape[0]], gold["codes"]), "oracle free run is not the golden trajectory"
+    tie_frames = (gold["margin"] <= 2 * noise).any(dim=1).nonzero().flatten()
+    first_tie = int(tie_frames[0]) if tie_frames.numel() else gold["codes"].shape[0]
+    print(f"free-running greedy: first {n_same}/10 frames identical to the oracle; the oracle's first near-tie is in frame {first_tie}")
+    assert n_same >= min(first_tie, gold["codes"].shape[0]), (n_same, first_tie)
+    assert n_same >= 1
 
 
 def test_generate_frame_surface_matches_reference_loop(tiny):
