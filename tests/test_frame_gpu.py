@@ -689,6 +689,19 @@ def _bench_args():
     return SimpleNamespace(ctx_text=40, ctx_frames=125, gen_text=24)
 
 
+def _same_until_a_near_tie(got, want, margin, noise, what):
+    """A free-running greedy frame (each codebook conditioned on the codes picked before it): identical to the oracle's
+    up to the first difference, and that difference must sit where the ORACLE's top-1/top-2 margin is inside the
+    rounding-noise floor.  Returns the number of decisions that were compared (= matched)."""
+    want = want.to(got.dtype)
+    diff = (got != want).nonzero().flatten()
+    if diff.numel() == 0:
+        return int(got.numel())
+    first = int(diff[0])
+    assert float(margin[first]) <= 2 * noise, f"{what}: codebook {first} differs with oracle margin {float(margin[first]):.4f} > {2 * noise:.4f}"
+    return first
+
+
 def _teacher_forced(m, gold, S, n_frames, noise, what):
     """depth() on the current backbone state for golden frames 0..n-1, feeding the golden codes back one row at a time."""
     max_diff, mism = 0.0, []
@@ -778,10 +791,7 @@ def test_csm1b_config3_batch32_vs_golden(csm1b):
     got = m.generate_frame(row, rmask, torch.full((B, 1), S), 1.0, 1).cpu()
     n_cmp = 0
     for b in range(B):
-        near = (gold["margin"][1][:, b] <= 2 * noise).nonzero().flatten()
-        upto = int(near[0]) if near.numel() else 32
-        assert torch.equal(got[b, :upto], gold["codes"][1][b, :upto].to(got.dtype)), f"graph step, utterance {b}"
-        n_cmp += upto
+        n_cmp += _same_until_a_near_tie(got[b], gold["codes"][1][b], gold["margin"][1][:, b], noise, f"graph step, utterance {b}")
     # and its logits, teacher-forced, through the same decode-step kernels
     m2 = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S)
     m2.setup_caches(B)
@@ -822,9 +832,7 @@ def test_csm1b_config5_fp8_long_context_vs_golden(csm1b):
         row = torch.zeros(1, 1, 33, dtype=torch.long); row[0, 0, :32] = g["codes"][0].reshape(-1).long()
         rmask = torch.ones(1, 1, 33, dtype=torch.bool); rmask[0, 0, 32] = False
         got1 = m.generate_frame(row, rmask, torch.tensor([[S]]), 1.0, 1)[0].cpu()
-        near = (g["margin"][1] <= 2 * noise).nonzero().flatten()
-        upto = int(near[0]) if near.numel() else 32
-        assert torch.equal(got1[:upto], g["codes"][1].reshape(-1)[:upto].to(got1.dtype)), f"graph step at p={S}"
+        assert _same_until_a_near_tie(got1, g["codes"][1].reshape(-1), g["margin"][1], noise, f"graph step at p={S}") >= 1
 
 
 @pytest.mark.parametrize("weights", ["bf16", "fp8"])
