@@ -120,7 +120,26 @@ __device__ __forceinline__ uint32_t raw_key(uint32_t bits) {
     return (bits & 0x8000u) ? (~bits & 0xffffu) : (bits | 0x8000u);
 }
 
-// One block of 4 waves per sequence.  Thread t owns logits [8t, 8t+8) (+ [2048+8t, ..) for V > 2048).
+// LDS scratch of the sampler (all in the workgroup's LDS; typed so every access is a ds_ instruction -- the persistent
+// depth-decoder kernel must not emit flat loads, which wait on vmcnt(0))
+typedef __attribute__((address_space(3))) float lds_f32_t;
+typedef __attribute__((address_space(3))) int lds_i32_t;
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
+struct SampleScratch {
+    lds_f32_t* cand_t;      // [V] (up to SAMPLE_MAX_ITERS * 512)
+    lds_i32_t* cand_i;      // [V]
+    lds_u32_t* s_max;       // [256], 16-byte aligned
+    lds_f32_t* s_bv;        // [4]
+    lds_i32_t* s_bi;        // [4]
+    lds_i32_t* s_n;         // [1]
+    lds_i32_t* s_tok;       // [1]
+    lds_i32_t* s_wtot;      // [4]
+};
+
+// 4 waves (tid 0..255) sample ONE sequence.  Thread t owns logits [8t, 8t+8) (+ [2048+8t, ..) for V > 2048), handed
+// in as w[i][0..3] (packed bf16 pairs; zero beyond the row).  `sync` is the 4-wave barrier (k_sample: __syncthreads;
+// the persistent decoder: an LDS counter barrier).
 //  1. per-thread max of the RAW bf16 keys -> LDS; the kth largest of those 256 maxima is a lower
 //     bound L of the kth-largest logit (k distinct elements are >= it);
 //  2. every element with raw key >= L - margin is a candidate: only candidates are divided by the
@@ -128,40 +147,25 @@ __device__ __forceinline__ uint32_t raw_key(uint32_t bits) {
 //     can round to one output, hence the margin) and appended to an LDS list (~k..3k entries);
 //  3. wave 0 finds the exact kth-largest t among the candidates by 16-bit bisection (ties kept),
 //     then log-softmax / softmax / Exp(1) race exactly as torch-CPU rounds them, one element per lane;
-//  4. all 256 threads copy the embedding row of the fed-back code.
-template <int ITERS>
-__global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
-    __shared__ float cand_t[SAMPLE_MAX_ITERS * 512];
-    __shared__ int cand_i[SAMPLE_MAX_ITERS * 512];
-    __shared__ __attribute__((aligned(16))) uint32_t s_max[256];
-    __shared__ float s_bv[4];
-    __shared__ int s_bi[4];
-    __shared__ int s_n, s_tok, s_wtot[4];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bf16_t* lg = a.logits + (long)b * a.ldl;
-    // issued now, consumed by wave 0 three barriers later (a dependent load there would sit on the critical path)
-    const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
-    uint32_t w[ITERS][4];
-#pragma unroll
-    for (int i = 0; i < ITERS; ++i) {
-        const bool in = (i * 2048 + tid * 8) < a.ldl;
-        const uint4 v = in ? reinterpret_cast<const uint4*>(lg + i * 2048)[tid] : make_uint4(0, 0, 0, 0);
-        w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
-    }
+//  4. returns the sampled index (valid in every thread after the final sync).
+template <int ITERS, class Sync>
+__device__ __forceinline__ int sample_body(const uint32_t (&w)[ITERS][4], int V, float temperature, int topk, const bf16_t* noise_row,
+                                           uint64_t seed, uint64_t step, int b, int codebook, const SampleScratch& sc, int tid, Sync sync) {
+    const int lane = tid & 63, wave = tid >> 6;
     int best_idx = 0x7fffffff;
     float best = -INFINITY;
-    if (a.topk <= 1) {
+    if (topk <= 1) {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int idx = i * 2048 + tid * 8 + j;
                 const uint32_t bits = (j & 1) ? (w[i][j >> 1] >> 16) : (w[i][j >> 1] & 0xffffu);
-                const float t = round_bf(__uint_as_float(bits << 16) / a.temperature);
-                if (idx < a.V && t > best) { best = t; best_idx = idx; }
+                const float t = round_bf(__uint_as_float(bits << 16) / temperature);
+                if (idx < V && t > best) { best = t; best_idx = idx; }
             }
     } else {
-        const int k = min(a.topk, a.V);
+        const int k = min(topk, V);
         uint32_t lmax = 0;
 #pragma unroll
         for (int i = 0; i < ITERS; ++i)
@@ -170,20 +174,17 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
                 const int idx = i * 2048 + tid * 8 + j;
                 const uint32_t bits = (j & 1) ? (w[i][j >> 1] >> 16) : (w[i][j >> 1] & 0xffffu);
                 const bool nan = (bits & 0x7fffu) > 0x7f80u;
-                if (idx < a.V && !nan) lmax = max(lmax, raw_key(bits));
+                if (idx < V && !nan) lmax = max(lmax, raw_key(bits));
             }
-        s_max[tid] = lmax;
-        __syncthreads();
-#if defined(SB_STOP) && SB_STOP == 1
-        if (tid == 0) a.frame[b] = (int)lmax; return;
-#endif
+        sc.s_max[tid] = lmax;
+        sync();
         uint32_t L = 0;
         if (k <= 256) {
-            const uint4 mv = reinterpret_cast<const uint4*>(s_max)[lane];
+            const u32x4_t mv = reinterpret_cast<lds_u32x4_t*>(sc.s_max)[lane];
             const uint32_t mk[4] = {mv.x, mv.y, mv.z, mv.w};
             L = kth_largest_key<4>(mk, k);
         }
-        const uint32_t margin = 2u * (uint32_t)ceilf(fmaxf(a.temperature, 1.0f)) + 2u;
+        const uint32_t margin = 2u * (uint32_t)ceilf(fmaxf(temperature, 1.0f)) + 2u;
         const uint32_t Lm = L > margin ? L - margin : 0u;
         // deterministic compaction in index order: per-thread count -> wave scan -> wave bases
         int cnt = 0;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
                 const int idx = i * 2048 + tid * 8 + j;
                 const uint32_t bits = (j & 1) ? (w[i][j >> 1] >> 16) : (w[i][j >> 1] & 0xffffu);
                 const bool nan = (bits & 0x7fffu) > 0x7f80u;
-                cnt += (idx < a.V && !nan && raw_key(bits) >= Lm) ? 1 : 0;
+                cnt += (idx < V && !nan && raw_key(bits) >= Lm) ? 1 : 0;
             }
         int incl = cnt;
 #pragma unroll
@@ -202,11 +203,11 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
             const int o = __shfl_up(incl, off, WAVE);
             if (lane >= off) incl += o;
         }
-        if (lane == 63) s_wtot[wave] = incl;
-        __syncthreads();
+        if (lane == 63) sc.s_wtot[wave] = incl;
+        sync();
         int o = incl - cnt;
-        for (int x = 0; x < wave; ++x) o += s_wtot[x];
-        if (tid == 255) s_n = o + cnt;
+        for (int x = 0; x < wave; ++x) o += sc.s_wtot[x];
+        if (tid == 255) *sc.s_n = o + cnt;
 #pragma unroll
         for (int i = 0; i < ITERS; ++i)
 #pragma unroll
@@ -214,17 +215,14 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
                 const int idx = i * 2048 + tid * 8 + j;
                 const uint32_t bits = (j & 1) ? (w[i][j >> 1] >> 16) : (w[i][j >> 1] & 0xffffu);
                 const bool nan = (bits & 0x7fffu) > 0x7f80u;
-                if (idx < a.V && !nan && raw_key(bits) >= Lm) {
-                    cand_t[o] = round_bf(__uint_as_float(bits << 16) / a.temperature);
-                    cand_i[o] = idx;
+                if (idx < V && !nan && raw_key(bits) >= Lm) {
+                    sc.cand_t[o] = round_bf(__uint_as_float(bits << 16) / temperature);
+                    sc.cand_i[o] = idx;
                     ++o;
                 }
             }
-        __syncthreads();
-        const int n = s_n;
-#if defined(SB_STOP) && SB_STOP == 2
-        if (tid == 0) a.frame[b] = n; return;
-#endif
+        sync();
+        const int n = *sc.s_n;
         if (wave == 0) {
             // ---- exact kth-largest t among the candidates -> keep t >= kth (ties kept) ---------
             uint32_t kth = 0;
@@ -232,16 +230,16 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
                 if (n <= 256) {
                     uint32_t ck[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) ck[c] = (c * 64 + lane < n) ? order_key(cand_t[c * 64 + lane]) : 0u;
+                    for (int c = 0; c < 4; ++c) ck[c] = (c * 64 + lane < n) ? order_key(sc.cand_t[c * 64 + lane]) : 0u;
                     kth = kth_largest_key<4>(ck, k);
                 } else {                               // rare (k > 256 or massive ties): generic loop
                     uint32_t prefix = 0;
                     for (int bit = 15; bit >= 0; --bit) {
                         const uint32_t cnd = prefix | (1u << bit);
-                        int cnt = 0;
+                        int cnt2 = 0;
                         for (int c = lane; c < ((n + 63) & ~63); c += 64)
-                            cnt += __popcll(__ballot(c < n && order_key(cand_t[c]) >= cnd));
-                        if (cnt >= k) prefix = cnd;
+                            cnt2 += __popcll(__ballot(c < n && order_key(sc.cand_t[c]) >= cnd));
+                        if (cnt2 >= k) prefix = cnd;
                     }
                     kth = prefix;
                 }
@@ -249,13 +247,13 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
             // ---- log_softmax (torch-CPU bf16 rounding points) over the kept candidates ---------
             float mx = -INFINITY;
             for (int c = lane; c < n; c += 64) {
-                const float v = cand_t[c];
+                const float v = sc.cand_t[c];
                 if (order_key(v) >= kth) mx = fmaxf(mx, v);
             }
             mx = wave_max(mx);
             float sum = 0.f;
             for (int c = lane; c < n; c += 64) {
-                const float v = cand_t[c];
+                const float v = sc.cand_t[c];
                 if (order_key(v) >= kth) sum += expf(v - mx);
             }
             sum = wave_sum(sum);
@@ -263,21 +261,21 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
             const float mx2 = round_bf(0.f - logsum);      // log-prob of the max element
             float s2 = 0.f;
             for (int c = lane; c < n; c += 64) {
-                const float v = cand_t[c];
+                const float v = sc.cand_t[c];
                 if (order_key(v) >= kth) s2 += expf(round_bf(round_bf(v - mx) - logsum) - mx2);
             }
             s2 = wave_sum(s2);
             // ---- argmax(p / q), q ~ Exp(1); first index wins ties ----------------------------------
             for (int c = lane; c < n; c += 64) {
-                const float v = cand_t[c];
+                const float v = sc.cand_t[c];
                 if (order_key(v) < kth) continue;
-                const int idx = cand_i[c];
+                const int idx = sc.cand_i[c];
                 const float p = round_bf(expf(round_bf(round_bf(v - mx) - logsum) - mx2) / s2);
                 if (!(p > 0.f)) continue;
                 float q;
-                if (a.noise) q = bf2f(a.noise[(long)b * a.V + idx]);
+                if (noise_row) q = bf2f(noise_row[idx]);
                 else {
-                    const uint4 rnd = philox4x32(make_uint4((uint32_t)idx, (uint32_t)b, (uint32_t)a.codebook, (uint32_t)step),
+                    const uint4 rnd = philox4x32(make_uint4((uint32_t)idx, (uint32_t)b, (uint32_t)codebook, (uint32_t)step),
                                                  make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32)));
                     const float u = ((float)rnd.x + 0.5f) * 2.3283064365386963e-10f;   // (0,1]
                     q = round_bf(-logf(u));
@@ -288,9 +286,6 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
             }
         }
     }
-#if defined(SB_STOP) && SB_STOP == 3
-    if (tid == 0) a.frame[b] = best_idx; return;
-#endif
     // argmax over the wave (lowest index on ties), then over the 4 waves
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -298,19 +293,49 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
         const int oi = __shfl_xor(best_idx, off, WAVE);
         if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
     }
-    if (lane == 0) { s_bv[wave] = best; s_bi[wave] = best_idx; }
-    __syncthreads();
+    if (lane == 0) { sc.s_bv[wave] = best; sc.s_bi[wave] = best_idx; }
+    sync();
     if (tid == 0) {
-        float bv = s_bv[0]; int bi = s_bi[0];
+        float bv = sc.s_bv[0]; int bi = sc.s_bi[0];
         for (int x = 1; x < 4; ++x)
-            if (s_bv[x] > bv || (s_bv[x] == bv && s_bi[x] < bi)) { bv = s_bv[x]; bi = s_bi[x]; }
+            if (sc.s_bv[x] > bv || (sc.s_bv[x] == bv && sc.s_bi[x] < bi)) { bv = sc.s_bv[x]; bi = sc.s_bi[x]; }
         if (bi == 0x7fffffff) bi = 0;
-        s_tok = bi;
-        a.frame[(long)b * a.ncb + a.codebook] = bi;
+        *sc.s_tok = bi;
     }
-    __syncthreads();
+    sync();
+    return *sc.s_tok;
+}
+
+struct SyncThreads { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
+
+// One block of 4 waves per sequence (the standalone launch of the chain path).
+template <int ITERS>
+__global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
+    __shared__ float cand_t[SAMPLE_MAX_ITERS * 512];
+    __shared__ int cand_i[SAMPLE_MAX_ITERS * 512];
+    __shared__ __attribute__((aligned(16))) uint32_t s_max[256];
+    __shared__ float s_bv[4];
+    __shared__ int s_bi[4];
+    __shared__ int s_n, s_tok, s_wtot[4];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bf16_t* lg = a.logits + (long)b * a.ldl;
+    // issued now, consumed by wave 0 three barriers later (a dependent load there would sit on the critical path)
+    const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
+    uint32_t w[ITERS][4];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const bool in = (i * 2048 + tid * 8) < a.ldl;
+        const uint4 v = in ? reinterpret_cast<const uint4*>(lg + i * 2048)[tid] : make_uint4(0, 0, 0, 0);
+        w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
+    }
+    SampleScratch sc;
+    sc.cand_t = (lds_f32_t*)cand_t; sc.cand_i = (lds_i32_t*)cand_i; sc.s_max = (lds_u32_t*)s_max; sc.s_bv = (lds_f32_t*)s_bv;
+    sc.s_bi = (lds_i32_t*)s_bi; sc.s_n = (lds_i32_t*)&s_n; sc.s_tok = (lds_i32_t*)&s_tok; sc.s_wtot = (lds_i32_t*)s_wtot;
+    const int tok = sample_body<ITERS>(w, a.V, a.temperature, a.topk, a.noise ? a.noise + (long)b * a.V : nullptr, seed, step, b,
+                                       a.codebook, sc, tid, SyncThreads());
+    if (tid == 0) a.frame[(long)b * a.ncb + a.codebook] = tok;
     if (a.emb_out) {
-        int fed = a.forced ? a.forced[(long)b * a.ncb + a.codebook] : s_tok;
+        int fed = a.forced ? a.forced[(long)b * a.ncb + a.codebook] : tok;
         fed = min(max(fed, 0), a.audio_vocab - 1);
         const uint4* src = reinterpret_cast<const uint4*>(a.audio_emb + ((long)a.codebook * a.audio_vocab + fed) * a.d);
         uint4* dst = reinterpret_cast<uint4*>(a.emb_out + (long)b * a.emb_stride);

@@ -138,21 +138,44 @@ def test_tiny_graph_replay_equals_eager_and_oracle_free_run(tiny):
     assert torch.equal(traces[0], traces[1]), "graph replay differs from eager launches"
     frames = gen.generate_codes(gold["prompt_tokens"], gold["prompt_mask"], 10, 1.0, 1)
     assert torch.equal(frames[:, 0], traces[0])
+    # The free-running trace must equal the LIVE oracle's (this host's CPU kernels; a golden trajectory is host-dependent
+    # at near-ties) up to, not including, the first frame in which the oracle's own top-1/top-2 margin drops under the
+    # rounding-noise floor (2 x its bf16-vs-fp32 gap) -- before that frame nothing is free.
     om = C.OracleModel(shape, w); om.setup_caches(1)
-    ref = torch.cat(C.generate_codes(om, gold["prompt_tokens"], gold["prompt_mask"], 800, 1.0, 1, greedy=True,
-                                     max_seq_len=256), 0)
+    noise = float(gold["bf16_vs_fp32_gap"].max())
+    cur_t, cur_m = gold["prompt_tokens"].unsqueeze(0), gold["prompt_mask"].unsqueeze(0)
+    pos = torch.arange(cur_t.shape[1]).unsqueeze(0)
+    ref, first_tie = [], None
+    for f in range(10):
+        tr = C.FrameTrace()
+        sframe = om.generate_frame(cur_t, cur_m, pos, 1.0, 1, greedy=True, trace=tr)
+        top2 = torch.topk(torch.stack(tr.logits, 0)[:, 0].float(), 2, dim=-1)[0]
+        if first_tie is None and bool(((top2[:, 0] - top2[:, 1]) <= 2 * noise).any()):
+            first_tie = f
+        ref.append(sframe[0])
+        cur_t = torch.cat([sframe.long(), torch.zeros(1, 1).long()], dim=1).unsqueeze(1)
+        cur_m = torch.cat([torch.ones_like(sframe).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
+        pos = pos[:, -1:] + 1
+    ref = torch.stack(ref)
+    first_tie = 10 if first_tie is None else first_tie
     same = (ref == traces[0]).all(dim=1)
     n_same = int(same.float().cumprod(0).sum())
-    # The free-running trace must equal the oracle's up to (not including) the first frame in which the ORACLE's own
-    # top-1/top-2 margin drops under the rounding-noise floor (2 x its bf16-vs-fp32 gap) -- before that frame nothing
-    # is free.  The golden file holds the margins of the oracle's trajectory (= ref while they agree).
-    noise = float(gold["bf16_vs_fp32_gap"].max())
-    assert torch.equal(ref[:gold["codes"].shape[0]], gold["codes"]), "oracle free run is not the golden trajectory"
-    tie_frames = (gold["margin"] <= 2 * noise).any(dim=1).nonzero().flatten()
-    first_tie = int(tie_frames[0]) if tie_frames.numel() else gold["codes"].shape[0]
     print(f"free-running greedy: first {n_same}/10 frames identical to the oracle; the oracle's first near-tie is in frame {first_tie}")
-    assert n_same >= min(first_tie, gold["codes"].shape[0]), (n_same, first_tie)
-    assert n_same >= 1
+    assert n_same >= first_tie, (n_same, first_tie)
+    # a frame that differs must part at a codebook where the oracle's margin is inside the noise floor
+    if n_same < 10:
+        f = n_same
+        om2 = C.OracleModel(shape, w); om2.setup_caches(1)
+        cur_t, cur_m = gold["prompt_tokens"].unsqueeze(0), gold["prompt_mask"].unsqueeze(0)
+        pos = torch.arange(cur_t.shape[1]).unsqueeze(0)
+        for g in range(f + 1):
+            tr = C.FrameTrace()
+            sframe = om2.generate_frame(cur_t, cur_m, pos, 1.0, 1, greedy=True, trace=tr)
+            cur_t = torch.cat([sframe.long(), torch.zeros(1, 1).long()], dim=1).unsqueeze(1)
+            cur_m = torch.cat([torch.ones_like(sframe).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
+            pos = pos[:, -1:] + 1
+        top2 = torch.topk(torch.stack(tr.logits, 0)[:, 0].float(), 2, dim=-1)[0]
+        _same_until_a_near_tie(traces[0][f], ref[f], top2[:, 0] - top2[:, 1], noise, f"free run, frame {f}")
 
 
 def test_generate_frame_surface_matches_reference_loop(tiny):
