@@ -20,6 +20,7 @@
 #include "gemm128.cuh"
 #include "attn_flash.cuh"
 #include "sampler.cuh"
+#include "dec_persist.cuh"
 
 #define BB_NSPLIT_MAX 8
 #define PART_ROWS 32
@@ -72,6 +73,12 @@ struct CsmModel {
     int xpack;                          // batched decode steps keep activations in operand order (env CSM_XPACK=0 disables)
     int fp8_wide;                       // fp8 mode: batched decode steps stream e4m3 on the matrix-core path too (env CSM_FP8_WIDE=0 disables)
     int fuse_dec_attn;                  // depth-decoder attention fused into the O-projection (env CSM_FUSE_DEC_ATTN=0 disables)
+    // persistent depth decoder (dec_persist.cuh): steps 2..ncb-1 of a batch-1 frame as one launch (env CSM_PERSIST=0 disables)
+    bool persist;
+    dp_u64 *pg_q, *pg_h1, *pg_h2, *pg_l, *pg_p;
+    uint32_t* p_state;                  // [0] tag epoch, [1] give-up code of the last launch (0 = ok)
+    uint4* p_w2s[DP_NL];
+    int p_trickle, p_poll;
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
     int last_S;                         // rows per sequence of the h buffer feeding csm_depth
     // graph
@@ -566,6 +573,22 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
     hipError_t e;
     for (int cb = 0; cb < ncb; ++cb) {
         GemvArgs a;
+        if (cb == 2 && B == 1 && m->persist) {
+            // codebooks 2..ncb-1: one persistent launch (the cb = 1 sampler above left the step's input row, its layer-0
+            // q / k / v and the decoder caches of positions 0, 1 where the kernel picks them up)
+            DecPersistArgs p;
+            memset(&p, 0, sizeof p);
+            for (int l = 0; l < DP_NL; ++l) { p.lw[l] = m->dec.lw[l]; p.w2s[l] = m->p_w2s[l]; }
+            p.dec_norm = (const bf16_t*)m->w.dec_norm; p.head_t = (const bf16_t*)m->w.audio_head_t; p.rope = m->dec.rope;
+            p.proj_emb = m->proj_emb; p.qkv0_tab = m->qkv0_tab; p.hdec = m->hdec; p.qd = m->qd;
+            p.kc = m->dec.kc; p.vc = m->dec.vc; p.kv_layer_stride = m->dec.layer_stride;
+            p.temperature = temperature; p.topk = topk; p.noise = (const bf16_t*)noise; p.rng = m->rng; p.forced = forced;
+            p.V = V; p.ncb = ncb; p.frame = m->frame; p.logits_out = (bf16_t*)logits_out; p.cb_first = 2; p.cb_last = ncb - 1;
+            p.gQ = m->pg_q; p.gH1 = m->pg_h1; p.gH2 = m->pg_h2; p.gL = m->pg_l; p.gP = m->pg_p;
+            p.err = m->p_state + 1; p.epoch = m->p_state; p.eps = c.decoder.norm_eps; p.trickle_sleep = m->p_trickle; p.poll_sleep = m->p_poll;
+            hipLaunchKernelGGL(k_dec_persist, dim3(DP_NB), dim3(512), DP_LDS_BYTES, st, p);
+            return hipGetLastError();
+        }
         if (cb >= 1) {
             const int rows = cb == 1 ? 2 * B : B;
             if (cb == 1) {
@@ -921,6 +944,42 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
         const char* ev = getenv("CSM_QKV0_TABLE");
         if (!(ev && ev[0] == '0') && ncb > 2) HIPCHK((CsmModel*)nullptr, build_qkv0_table(m));
     }
+    // ---- persistent depth decoder: the production decoder shape on a 256-CU device, bf16 weight stream ----
+    m->persist = false;
+    {
+        const char* ev = getenv("CSM_PERSIST");
+        const CsmLlamaDims& dc = cfg->decoder;
+        int ncu = 0, dev_ = 0;
+        (void)hipGetDevice(&dev_);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev_);
+        const bool shape_ok = dc.n_layers == DP_NL && dc.dim == DP_D && dc.ffn == DP_FFN && dc.n_heads == 8 && dc.n_kv_heads == 2 &&
+                              cfg->n_codebooks >= 3 && cfg->n_codebooks <= 32 && cfg->audio_vocab <= 2 * DP_LSLOTS && cfg->audio_vocab <= 2560;
+        if (!(ev && ev[0] == '0') && shape_ok && ncu >= DP_NB && m->qkv0_tab != nullptr && !w->fp8) {
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pg_q, (size_t)DP_NREP * 768 * 8));
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pg_h1, (size_t)DP_NREP * 512 * 8));
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pg_h2, (size_t)DP_NREP * 512 * 8));
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pg_l, (size_t)DP_NREP * DP_LSLOTS * 8));
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pg_p, (size_t)256 * 1024 * 8));
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_state, 16));
+            HIPCHK((CsmModel*)nullptr, hipMemset(m->pg_q, 0, (size_t)DP_NREP * 768 * 8));
+            HIPCHK((CsmModel*)nullptr, hipMemset(m->pg_h1, 0, (size_t)DP_NREP * 512 * 8));
+            HIPCHK((CsmModel*)nullptr, hipMemset(m->pg_h2, 0, (size_t)DP_NREP * 512 * 8));
+            HIPCHK((CsmModel*)nullptr, hipMemset(m->pg_l, 0, (size_t)DP_NREP * DP_LSLOTS * 8));
+            HIPCHK((CsmModel*)nullptr, hipMemset(m->pg_p, 0, (size_t)256 * 1024 * 8));
+            HIPCHK((CsmModel*)nullptr, hipMemset(m->p_state, 0, 16));
+            for (int l = 0; l < DP_NL; ++l) {
+                HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_w2s[l], (size_t)DP_D * DP_FFN * 2));
+                hipLaunchKernelGGL(k_dp_retile_w2, dim3(4096), dim3(256), 0, nullptr, (const bf16_t*)m->w.dec[l].w2, m->p_w2s[l]);
+            }
+            HIPCHK((CsmModel*)nullptr, hipGetLastError());
+            HIPCHK((CsmModel*)nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_persist),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_BYTES));
+            HIPCHK((CsmModel*)nullptr, hipDeviceSynchronize());
+            { const char* e2 = getenv("CSM_PERSIST_TRICKLE"); m->p_trickle = e2 ? atoi(e2) : 6; }
+            { const char* e2 = getenv("CSM_PERSIST_POLL"); m->p_poll = e2 ? atoi(e2) : 2; }
+            m->persist = true;
+        }
+    }
     *out = m;
     return CSM_OK;
 }
@@ -935,6 +994,10 @@ extern "C" void csm_destroy(csm_handle m) {
                     m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos, m->qkv0_tab};
     for (void* p : ptrs) (void)hipFree(p);
     for (void* p : m->pk_allocs) (void)hipFree(p);
+    if (m->persist) {
+        void* pp[] = {m->pg_q, m->pg_h1, m->pg_h2, m->pg_l, m->pg_p, m->p_state, m->p_w2s[0], m->p_w2s[1], m->p_w2s[2], m->p_w2s[3]};
+        for (void* p : pp) (void)hipFree(p);
+    }
     delete m;
 }
 
@@ -1049,8 +1112,15 @@ extern "C" int csm_read_frames(csm_handle m, int B, int first, int n, int32_t* h
                                    (size_t)m->max_batch * ncb * 4, (size_t)B * ncb * 4, n, hipMemcpyDeviceToHost, st));
     if (host_eos_at) HIPCHK(m, hipMemcpyAsync(host_eos_at, m->eos_at, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     int overflow = 0;
+    uint32_t pcode = 0;
     HIPCHK(m, hipMemcpyAsync(&overflow, m->n_frames + 1, 4, hipMemcpyDeviceToHost, st));
+    if (m->persist) HIPCHK(m, hipMemcpyAsync(&pcode, m->p_state + 1, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(m, hipStreamSynchronize(st));
+    if (pcode) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "persistent depth-decoder launch gave up waiting (code 0x%x): frames are invalid; set CSM_PERSIST=0", pcode);
+        return fail(m, CSM_E_HIP, buf);
+    }
     if (overflow) return fail(m, CSM_E_TOO_LONG, "a position outside [0, max_seq) was fed to the backbone (prompt + generated frames exceed max_seq_len)");
     return CSM_OK;
 }

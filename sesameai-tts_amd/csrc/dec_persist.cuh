@@ -1,0 +1,646 @@
+// Depth-decoder steps 2..31 of ONE frame as ONE persistent launch (batch 1, the CSM-1B decoder shape: 4 layers,
+// d 1024, 8 heads / 2 KV heads of 128, ffn 8192, 32 positions).   reference: sesameai/models.py:165-182.
+//
+// Why (measured, tools/microbench/persist*_bench.hip, profiles/r02/): as a chain of launches a decoder layer costs
+// 4 seams x ~4.6 us because the HBM/Infinity-Cache stream of a kernel cannot start before the previous kernel has
+// ended; the weights do not depend on the activations, so here every workgroup (one per CU, 256 of them) keeps the
+// NEXT use of its weight rows in flight in VGPRs while the dependency chain runs, and the seams become 8-byte
+// {tag, payload} granule all-gathers polled by one wave per CU that has no weight loads outstanding.
+//
+//   wave 7      "gather": sweeps the granules of the previous op (relaxed agent-scope loads, 8 copies so that only 32
+//               CUs poll a line), applies the RMSNorm the consumer needs, writes LDS, raises an LDS flag; it also owns
+//               rows 4cu..4cu+3 of the residual stream: sums the 256 down-projection partials of those rows in a fixed
+//               order, adds the residual and publishes them; after sampling it fetches the next step's table rows.
+//   waves 0..6  "compute": fixed weight rows per wave; the loads of a wave's next use are issued ONE 1 KB wave load at
+//               a time between polls of the LDS flag the wave waits on anyway (static order -> exact vmcnt(N) waits).
+//               waves 0,1: 6 (gate, up) pairs + 3 row blocks of the split down projection
+//               waves 2-4: one q|k|v unit (2 rows, RoPE) + 4 pairs + 2 row blocks + one head unit
+//               waves 5,6: one o-proj unit (2 rows, + residual) + 4 pairs + 2 row blocks + head unit (5) / tail rows (6)
+//               waves 2-5 ("quad"): attention over the LDS-resident K/V (2 heads each) and the sampler.
+//
+// Arithmetic: every dot product, RoPE, attention, RMSNorm, residual and the sampler use the chain path's code or its
+// exact lane/k mapping (k_gemv, stage_attn, stage_x, sample_body), so those values are bit-identical to the launch
+// chain.  ONE thing differs: the down projection is split over the 256 workgroups' 32-column slices (its input never
+// leaves the CU that produced it) and summed by the row owner in a fixed order -- deterministic, but a different fp32
+// summation order than one wave per row.  Every spin is bounded (s_memrealtime); on a timeout the kernel sets *err and
+// leaves, and csm_read_frames reports it.
+#pragma once
+#include "gemv.cuh"
+#include "sampler.cuh"
+
+typedef unsigned long long dp_u64;
+#define DP_NB 256                     // workgroups = CUs of an MI355X
+#define DP_NREP 8                     // granule copies
+#define DP_TIMEOUT 5000000ull         // 50 ms of s_memrealtime (100 MHz)
+#define DP_NL 4
+#define DP_D 1024
+#define DP_FFN 8192
+#define DP_HD 128
+#define DP_NQKV 1536
+#define DP_LSLOTS 1088                // logit granules per copy (1026 used)
+
+typedef __attribute__((address_space(3))) uint32_t dp_lu32;
+typedef __attribute__((address_space(3))) volatile uint32_t dp_lvu32;
+typedef __attribute__((address_space(3))) u32x4_t dp_lu4;
+typedef __attribute__((address_space(3))) unsigned short dp_lu16;
+typedef __attribute__((address_space(3))) float dp_lf32;
+__device__ __forceinline__ uint4 dp_ldq(const dp_lu4* p) { const u32x4_t v = *p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void dp_stq(dp_lu4* p, const uint4& v) { u32x4_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *p = t; }
+
+struct DecPersistArgs {
+    CsmLayerWeights lw[DP_NL];
+    const uint4* w2s[DP_NL];          // W2 re-tiled [256 cu][4 k chunks][1024 rows] 16-byte pieces (k_dp_retile_w2)
+    const bf16_t* dec_norm;
+    const bf16_t* head_t;             // [ncb-1][V][1024]
+    const bf16_t* rope;               // [max_seq][64][2]
+    const bf16_t* proj_emb;           // [ncb*V][1024]
+    const bf16_t* qkv0_tab;           // [(ncb-2)*V][1536]
+    const bf16_t *hdec, *qd;          // decoder input row / layer-0 q of step cb_first (written by the chain's cb = 1 step)
+    const bf16_t *kc, *vc;            // decoder caches [L][1][2][32][128] (positions < cb_first of every layer, cb_first of layer 0)
+    long kv_layer_stride;
+    float temperature; int topk;
+    const bf16_t* noise;              // optional [ncb][1][V]
+    const uint64_t* rng;
+    const int* forced;                // optional [ncb]
+    int V, ncb;
+    int* frame;                       // [ncb]
+    bf16_t* logits_out;               // optional [ncb][1][V]
+    int cb_first, cb_last;
+    dp_u64 *gQ, *gH1, *gH2, *gL, *gP; // granule slots: 8x768, 8x512, 8x512, 8x1088, 256x1024
+    uint32_t* err;
+    uint32_t* epoch;
+    float eps;
+    int trickle_sleep, poll_sleep;
+};
+
+// LDS image (dynamic shared memory; byte offsets)
+#define DP_OFF_K 0                                   // [4][2][32][128] bf16
+#define DP_OFF_V 65536
+#define DP_OFF_U 131072                              // layers: xA | xC | q | att (2 KB each); sampling: cand_t | cand_i (8448 B each)
+#define DP_OFF_XA (DP_OFF_U)
+#define DP_OFF_XC (DP_OFF_U + 2048)
+#define DP_OFF_QB (DP_OFF_U + 4096)
+#define DP_OFF_ATT (DP_OFF_U + 6144)
+#define DP_OFF_CANDT (DP_OFF_U)
+#define DP_OFF_CANDI (DP_OFF_U + 8448)
+#define DP_OFF_LOGITS (DP_OFF_U + 16896)             // 2560 bf16
+#define DP_OFF_SMAX (DP_OFF_LOGITS + 5120)           // 256 u32
+#define DP_OFF_PS (DP_OFF_SMAX + 1024)               // attention P rows: 4 waves x 64 floats
+#define DP_OFF_MISC (DP_OFF_PS + 1024)
+#define DP_LDS_BYTES (DP_OFF_MISC + 256)
+// misc words
+#define DP_M_HL 0        // 16 words: this CU's 32 h values
+#define DP_M_H0 16       // 2 words: residual rows 4cu..4cu+3 entering the layer
+#define DP_M_H1 18       // 2 words: after the o-projection
+#define DP_M_FXA 20      // flags
+#define DP_M_FQ 21
+#define DP_M_FXC 22
+#define DP_M_FLG 23
+#define DP_M_FTOK 24
+#define DP_M_ATTN 25     // counters
+#define DP_M_CD 26
+#define DP_M_BAR 27
+#define DP_M_ABORT 28
+#define DP_M_TOK 29
+#define DP_M_SBV 32      // sampler: 4 floats, 4 ints, n, tok, 4 wave totals
+#define DP_M_SBI 36
+#define DP_M_SN 40
+#define DP_M_STOK 41
+#define DP_M_SWTOT 42
+
+enum { DP_E_Q = 0, DP_E_H1 = 1, DP_E_P = 2, DP_E_H2 = 3, DP_E_L = 4 };
+__device__ __forceinline__ uint32_t dp_tag(uint32_t base, int s, int l, int e) { return base + 1u + (uint32_t)((s * DP_NL + l) * 5 + e); }
+
+__device__ __forceinline__ void dp_gran_store(dp_u64* p, uint32_t tag, uint32_t val) {
+    __hip_atomic_store(p, ((dp_u64)tag << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ dp_u64 dp_gran_load(const dp_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool dp_give_up(dp_u64 t0, dp_lvu32* ab, uint32_t* err, uint32_t code, int lane) {
+    if (*ab) return true;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > DP_TIMEOUT) {
+        *ab = 1;
+        if (lane == 0) atomicCAS(err, 0u, code);
+        return true;
+    }
+    return false;
+}
+
+// wait until *f == tag (or, with `at_least`, *f >= tag) while issuing N loads one at a time in a static order
+template <int N, bool AT_LEAST, class Issue>
+__device__ __forceinline__ bool dp_wait(dp_lvu32* f, uint32_t tag, dp_lvu32* ab, uint32_t* err, uint32_t code, int lane, int sleep_units, Issue issue) {
+    auto hit = [&]() { const uint32_t v = *f; return AT_LEAST ? (int32_t)(v - tag) >= 0 : v == tag; };
+    // No branch on `seen` between the loads (a branch there gets jump-threaded into one clone of the remaining load
+    // sequence per step): the sleep length is data (0 once the flag has been seen) and the LDS poll always runs.
+    int seen = (int)hit();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        issue(k);
+        const int nap = seen ? 0 : sleep_units;
+        for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(1);
+        seen |= (int)hit();
+    }
+    seen = __builtin_amdgcn_readfirstlane(seen);
+    if (!seen) {
+        const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
+        while (!hit()) {
+            if (dp_give_up(t0, ab, err, code, lane)) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+
+// gather wave: sweep NL granules per lane (slots j*64 + lane < n_valid) until every tag matches
+template <int NL>
+__device__ __forceinline__ bool dp_sweep(const dp_u64* g, int n_valid, uint32_t tag, uint32_t (&v)[NL], int lane, dp_lvu32* ab, uint32_t* err,
+                                         uint32_t code, int poll_sleep) {
+    const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            if (j * 64 + lane < n_valid) {
+                const dp_u64 x = dp_gran_load(g + j * 64 + lane);
+                v[j] = (uint32_t)x;
+                ok &= (uint32_t)(x >> 32) == tag;
+            } else v[j] = 0;
+        }
+        if (__all(ok)) return true;
+        if (dp_give_up(t0, ab, err, code, lane)) return false;
+        for (int z = 0; z < poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+__device__ __forceinline__ void dp_flag(dp_lvu32* flag, uint32_t tag) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    *flag = tag;
+}
+
+// stage_x<1, 2, true>'s RMSNorm arithmetic by one wave on a 1024-vector in LDS, in place (thread t < 128 of that
+// kernel owns 16-byte chunk t: lane l here owns chunks l (its wave 0) and 64 + l (its wave 1))
+__device__ __forceinline__ float dp_chunk_ss(const uint4& v) {
+    float ss = 0.f, f;
+    f = lo2f(v.x); ss += f * f; f = hi2f(v.x); ss += f * f;
+    f = lo2f(v.y); ss += f * f; f = hi2f(v.y); ss += f * f;
+    f = lo2f(v.z); ss += f * f; f = hi2f(v.z); ss += f * f;
+    f = lo2f(v.w); ss += f * f; f = hi2f(v.w); ss += f * f;
+    return ss;
+}
+__device__ __forceinline__ uint4 dp_chunk_norm(const uint4& v, const uint4& g, float r) {
+    uint4 o;
+    o.x = pack_bf(round_bf(lo2f(v.x) * r) * lo2f(g.x), round_bf(hi2f(v.x) * r) * hi2f(g.x));
+    o.y = pack_bf(round_bf(lo2f(v.y) * r) * lo2f(g.y), round_bf(hi2f(v.y) * r) * hi2f(g.y));
+    o.z = pack_bf(round_bf(lo2f(v.z) * r) * lo2f(g.z), round_bf(hi2f(v.z) * r) * hi2f(g.z));
+    o.w = pack_bf(round_bf(lo2f(v.w) * r) * lo2f(g.w), round_bf(hi2f(v.w) * r) * hi2f(g.w));
+    return o;
+}
+__device__ __forceinline__ void dp_norm_in_lds(dp_lu4* xs, const bf16_t* scale, float eps, int lane) {
+    const uint4 g0 = reinterpret_cast<const uint4*>(scale)[lane], g1 = reinterpret_cast<const uint4*>(scale)[64 + lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint4 v0 = dp_ldq(xs + lane), v1 = dp_ldq(xs + 64 + lane);
+    const float s0 = wave_sum(dp_chunk_ss(v0)), s1 = wave_sum(dp_chunk_ss(v1));
+    const float tot = s0 + s1 + 0.f + 0.f;
+    const float r = 1.0f / sqrtf(tot / 1024.0f + eps);
+    dp_stq(xs + lane, dp_chunk_norm(v0, g0, r));
+    dp_stq(xs + 64 + lane, dp_chunk_norm(v1, g1, r));
+}
+
+__device__ __forceinline__ uint32_t dp_resid_pair(float a0, float a1, uint32_t hw) {
+#pragma clang fp contract(off)
+    const float y0 = round_bf(a0) + lo2f(hw), y1 = round_bf(a1) + hi2f(hw);
+    return pack_bf(y0, y1);
+}
+__device__ __forceinline__ uint32_t dp_swiglu(float ag, float au) {
+#pragma clang fp contract(off)
+    const float g = round_bf(ag), u = round_bf(au);
+    const float s = round_bf(g / (1.0f + __expf(-g)));
+    return (uint32_t)f2bf(s * u);
+}
+__device__ __forceinline__ uint32_t dp_rope_pair(float a0, float a1, uint32_t cs, bool rotate) {
+#pragma clang fp contract(off)
+    float v0 = round_bf(a0), v1 = round_bf(a1);
+    if (rotate) {
+        const float c = lo2f(cs), s = hi2f(cs);
+        const float o0 = v0 * c - v1 * s;
+        const float o1 = v1 * c + v0 * s;
+        v0 = o0; v1 = o1;
+    }
+    return pack_bf(v0, v1);
+}
+__device__ __forceinline__ float dp_down_partial(const uint4 (&w)[4], const uint4 (&h)[4]) {
+    float acc = dot8(w[0], h[0], 0.f);
+    acc = dot8(w[1], h[1], acc);
+    acc = dot8(w[2], h[2], acc);
+    return dot8(w[3], h[3], acc);
+}
+// owner-side sum of the 256 partials of 4 rows: lane l holds row l & 3 of producers j*16 + (l >> 2), j = 0..15
+__device__ __forceinline__ float dp_reduce_partials(const uint32_t (&v)[16]) {
+    float s = __uint_as_float(v[0]);
+#pragma unroll
+    for (int j = 1; j < 16; ++j) s += __uint_as_float(v[j]);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    return s;
+}
+
+// stage_attn (gemv.cuh) for one row, heads h and h + 1 of one KV group, with q / K / V in LDS.  Same lane layout and
+// operation order: lane l holds 16-byte pieces of keys 4i + l/16 (i = 0..7) at element offset 8 (l % 16).
+__device__ __forceinline__ void dp_attention_pair(const dp_lu4* qb, const dp_lu4* kt, const dp_lu32* vt, dp_lf32* myps, dp_lu32* att,
+                                                  int h, int nk, float ascale, int lane) {
+    const int grp = lane >> 4, sub = lane & 15;
+    const uint4 qa = dp_ldq(qb + h * 16 + sub), qbv = dp_ldq(qb + (h + 1) * 16 + sub);
+    float s0[8], s1[8], mx0 = -INFINITY, mx1 = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s0[i] = -INFINITY; s1[i] = -INFINITY;
+        if (4 * i < nk) {
+            const uint4 kv = dp_ldq(kt + i * 64 + lane);
+            const bool live = (4 * i + grp) < nk;
+            const float d0 = row16_sum(dot8(qa, kv, 0.f)) * ascale, d1 = row16_sum(dot8(qbv, kv, 0.f)) * ascale;
+            s0[i] = live ? d0 : -INFINITY;
+            s1[i] = live ? d1 : -INFINITY;
+            mx0 = fmaxf(mx0, s0[i]); mx1 = fmaxf(mx1, s1[i]);
+        }
+    }
+    mx0 = wave_max(mx0); mx1 = wave_max(mx1);
+    float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (4 * i < nk) {
+            s0[i] = (s0[i] == -INFINITY) ? 0.f : __expf(s0[i] - mx0);
+            s1[i] = (s1[i] == -INFINITY) ? 0.f : __expf(s1[i] - mx1);
+            l0 += s0[i]; l1 += s1[i];
+            if (sub == 0) { myps[4 * i + grp] = s0[i]; myps[32 + 4 * i + grp] = s1[i]; }
+        }
+    }
+    l0 = wave_sum(l0) * (1.0f / 16.0f);
+    l1 = wave_sum(l1) * (1.0f / 16.0f);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+#pragma unroll
+    for (int t4 = 0; t4 < 8; ++t4) {
+        if (4 * t4 < nk) {
+            const float pav[4] = {myps[4 * t4], myps[4 * t4 + 1], myps[4 * t4 + 2], myps[4 * t4 + 3]};
+            const float pbv[4] = {myps[32 + 4 * t4], myps[32 + 4 * t4 + 1], myps[32 + 4 * t4 + 2], myps[32 + 4 * t4 + 3]};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t raw = (4 * t4 + u) < nk ? vt[(4 * t4 + u) * 64 + lane] : 0u;
+                const float v0 = lo2f(raw), v1 = hi2f(raw);
+                o00 += pav[u] * v0; o01 += pav[u] * v1;
+                o10 += pbv[u] * v0; o11 += pbv[u] * v1;
+            }
+        }
+    }
+    const float i0 = 1.0f / l0, i1 = 1.0f / l1;
+    att[h * 64 + lane] = pack_bf(o00 * i0, o01 * i0);
+    att[(h + 1) * 64 + lane] = pack_bf(o10 * i1, o11 * i1);
+}
+
+// 4-wave barrier of the quad (waves 2..5) on an LDS counter: phase-numbered, bounded
+struct DpQuadSync {
+    dp_lvu32* ctr; dp_lvu32* ab; uint32_t* err; int lane; uint32_t* phase;
+    __device__ __forceinline__ void operator()() const {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t want = 4u * (++*phase);
+        if (lane == 0) __hip_atomic_fetch_add((dp_lu32*)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int32_t)(*ctr - want) < 0)
+            if (dp_give_up(t0, ab, err, 0xB00u, lane)) break;
+        asm volatile("" ::: "memory");
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// compute wave.  Roles: X = waves 0,1;  A = waves 2,3,4 (q|k|v unit; 2,3,4 are in the quad);  B = waves 5,6 (o-proj
+// unit; 5 is in the quad).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool IS_X, bool IS_A, bool IN_QUAD>
+__device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* lds, const int wave, const unsigned lane, const int cu, const uint32_t base) {
+    constexpr bool IS_B = !IS_X && !IS_A;
+    constexpr int NP = IS_X ? 6 : 4, NBK = IS_X ? 3 : 2, NCD = NP * 4 + NBK * 4;
+    dp_lu32* misc = (dp_lu32*)(lds + DP_OFF_MISC);
+    dp_lvu32* ab = (dp_lvu32*)(misc + DP_M_ABORT);
+    const int ts = a.trickle_sleep;
+    const int unit = IS_A ? cu * 3 + (wave - 2) : cu * 2 + (wave - 5);            // q|k|v unit (768) or o-proj unit (512)
+    const int hoff = IS_X ? wave * 6 : 12 + (wave - 2) * 4;
+    const int hbase = cu * 32 + hoff;
+    // head rows of this wave: waves 2..5 own unit cu*4 + (wave - 2); wave 6 of CU 0 / 1 owns the tail units 1024 / 1025
+    const int hunit = IS_X ? -1 : (wave < 6 ? cu * 4 + (wave - 2) : (cu < 2 ? 1024 + cu : -1));
+    const int hrow0 = hunit < 0 ? 0 : 2 * hunit, hrow1 = hunit < 0 ? 0 : min(2 * hunit + 1, a.V - 1);
+    uint4 ws[2][2];
+    uint4 wc[NP][2][2];
+    uint4 wd[NBK][4];
+
+    // rows of the small op slot `slot`: 0..3 = this wave's layer op, 4 = the head of codebook step cb
+    auto load_ws = [&](int slot, int cb, int k) {
+        const bf16_t* r;
+        if (slot < DP_NL) {
+            if (IS_A) {
+                const int row = 2 * unit + (k >> 1);
+                r = row < 1024 ? (const bf16_t*)a.lw[slot].wq + (long)row * DP_D
+                  : row < 1280 ? (const bf16_t*)a.lw[slot].wk + (long)(row - 1024) * DP_D
+                               : (const bf16_t*)a.lw[slot].wv + (long)(row - 1280) * DP_D;
+            } else r = (const bf16_t*)a.lw[slot].wo + (long)(2 * unit + (k >> 1)) * DP_D;
+        } else r = a.head_t + ((long)(cb - 1) * a.V + ((k >> 1) ? hrow1 : hrow0)) * DP_D;
+        ws[k >> 1][k & 1] = reinterpret_cast<const uint4*>(r)[(k & 1) * 64 + lane];
+    };
+    auto load_cd = [&](int l, int k) {
+        if (k < NP * 4) {
+            const bf16_t* r = (const bf16_t*)((k >> 1) & 1 ? a.lw[l].w3 : a.lw[l].w1) + (long)(hbase + (k >> 2)) * DP_D;
+            wc[k >> 2][(k >> 1) & 1][k & 1] = reinterpret_cast<const uint4*>(r)[(k & 1) * 64 + lane];
+        } else {
+            const int kk = k - NP * 4;
+            wd[kk >> 2][kk & 3] = a.w2s[l][((long)cu * 4 + (kk & 3)) * 1024 + (wave + 7 * (kk >> 2)) * 64 + lane];
+        }
+    };
+    if (!IS_X) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load_ws(IS_A ? 1 : 0, a.cb_first, k);
+    }
+#pragma unroll
+    for (int k = 0; k < NCD; ++k) load_cd(0, k);
+
+    uint32_t quad_phase = 0;
+    const int n_steps = a.cb_last - a.cb_first + 1;
+    for (int s = 0; s < n_steps; ++s) {
+        const int cb = a.cb_first + s;                 // this step's token sits at position cb; keys 0..cb
+        for (int l = 0; l < DP_NL; ++l) {
+            const int it = s * DP_NL + l;
+            dp_lu32* att = (dp_lu32*)(lds + DP_OFF_ATT);
+            if (IS_A) {
+                // -- q|k|v unit of layers 1..3 (layer 0's row comes from the table); first third of this layer's MLP weights meanwhile
+                const uint32_t tg = dp_tag(base, s, l - 1, DP_E_H2);
+                if (!dp_wait<NCD / 3, false>((dp_lvu32*)(misc + DP_M_FXA), l > 0 ? tg : *(dp_lvu32*)(misc + DP_M_FXA), ab, a.err, 0x910u, lane, ts,
+                                             [&](int k) { load_cd(l, k); })) return;
+                if (l > 0) {
+                    const dp_lu4* xs = (const dp_lu4*)(lds + DP_OFF_XA);
+                    const uint4 x0 = dp_ldq(xs + lane), x1 = dp_ldq(xs + 64 + lane);
+                    float a0 = dot8(ws[0][0], x0, 0.f); a0 = dot8(ws[0][1], x1, a0);
+                    float a1 = dot8(ws[1][0], x0, 0.f); a1 = dot8(ws[1][1], x1, a1);
+                    a0 = wave_sum(a0); a1 = wave_sum(a1);
+                    const int row = 2 * unit;                              // q rows 0..1023, k 1024..1279, v 1280..1535
+                    const int e = (row < 1024 ? row : row - 1024) % DP_HD;
+                    const uint32_t cs = reinterpret_cast<const uint32_t*>(a.rope)[cb * (DP_HD / 2) + e / 2];
+                    const uint32_t outw = dp_rope_pair(a0, a1, cs, row < 1280);
+                    if (lane < DP_NREP) dp_gran_store(a.gQ + lane * 768 + unit, dp_tag(base, s, l, DP_E_Q), outw);
+                }
+            }
+            if (IN_QUAD) {
+                // -- attention: 2 heads per quad wave over keys 0..cb; the A waves' next q|k|v rows and a third of the MLP weights meanwhile
+                constexpr int N2 = IS_A ? 4 + NCD / 3 : NCD / 2;
+                if (!dp_wait<N2, false>((dp_lvu32*)(misc + DP_M_FQ), dp_tag(base, s, l, DP_E_Q), ab, a.err, 0x920u, lane, ts, [&](int k) {
+                        if (IS_A) { if (k < 4) load_ws(l + 1 < DP_NL ? l + 1 : DP_NL, cb, k); else load_cd(l, NCD / 3 + k - 4); }
+                        else load_cd(l, k);
+                    })) return;
+                const int h = (wave - 2) * 2, kvh = h >> 2;
+                dp_attention_pair((const dp_lu4*)(lds + DP_OFF_QB), (const dp_lu4*)(lds + DP_OFF_K + ((l * 2 + kvh) * 32) * 256),
+                                  (const dp_lu32*)(lds + DP_OFF_V + ((l * 2 + kvh) * 32) * 256), (dp_lf32*)(lds + DP_OFF_PS) + (wave - 2) * 64, att,
+                                  h, cb + 1, 0.08838834764831845f, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(misc + DP_M_ATTN, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (IS_B) {
+                // -- o-projection unit + residual, once the four attention waves are done
+                constexpr int N3 = IN_QUAD ? 0 : NCD / 2;
+                if (!dp_wait<N3 ? N3 : 1, true>((dp_lvu32*)(misc + DP_M_ATTN), 4u * (uint32_t)(it + 1), ab, a.err, 0x930u, lane, ts,
+                                                [&](int k) { if (N3) load_cd(l, k); })) return;
+                const dp_lu4* xs = (const dp_lu4*)att;
+                const uint4 x0 = dp_ldq(xs + lane), x1 = dp_ldq(xs + 64 + lane);
+                float a0 = dot8(ws[0][0], x0, 0.f); a0 = dot8(ws[0][1], x1, a0);
+                float a1 = dot8(ws[1][0], x0, 0.f); a1 = dot8(ws[1][1], x1, a1);
+                a0 = wave_sum(a0); a1 = wave_sum(a1);
+                const uint32_t h0w = *(dp_lvu32*)(misc + DP_M_H0 + (wave - 5));
+                const uint32_t outw = dp_resid_pair(a0, a1, h0w);
+                if (lane == 0) misc[DP_M_H1 + (wave - 5)] = outw;
+                if (lane < DP_NREP) dp_gran_store(a.gH1 + lane * 512 + unit, dp_tag(base, s, l, DP_E_H1), outw);
+            }
+            {
+                // -- the MLP: my (gate, up) pairs -> h values -> LDS -> my row blocks of the split down projection
+                constexpr int N4 = IS_X ? NCD : IS_A ? NCD - 2 * (NCD / 3) : 4 + NCD / 2;
+                if (!dp_wait<N4, false>((dp_lvu32*)(misc + DP_M_FXC), dp_tag(base, s, l, DP_E_H1), ab, a.err, 0x940u, lane, ts, [&](int k) {
+                        if (IS_X) load_cd(l, k);
+                        else if (IS_A) load_cd(l, 2 * (NCD / 3) + k);
+                        else { if (k < 4) load_ws(l + 1 < DP_NL ? l + 1 : DP_NL, cb, k); else load_cd(l, NCD / 2 + k - 4); }
+                    })) return;
+                const dp_lu4* xs = (const dp_lu4*)(lds + DP_OFF_XC);
+                const uint4 x0 = dp_ldq(xs + lane), x1 = dp_ldq(xs + 64 + lane);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    float ag = dot8(wc[j][0][0], x0, 0.f); ag = dot8(wc[j][0][1], x1, ag);
+                    float au = dot8(wc[j][1][0], x0, 0.f); au = dot8(wc[j][1][1], x1, au);
+                    const uint32_t hv = dp_swiglu(wave_sum(ag), wave_sum(au));
+                    if (lane == 0) ((dp_lu16*)(misc + DP_M_HL))[hoff + j] = (unsigned short)hv;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(misc + DP_M_CD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                {
+                    const uint32_t want = 7u * (uint32_t)(it + 1);
+                    const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
+                    while ((int32_t)(*(dp_lvu32*)(misc + DP_M_CD) - want) < 0)
+                        if (dp_give_up(t0, ab, a.err, 0x950u, lane)) return;
+                    asm volatile("" ::: "memory");
+                }
+                uint4 h[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h[q] = dp_ldq((const dp_lu4*)(misc + DP_M_HL) + q);
+#pragma unroll
+                for (int b = 0; b < NBK; ++b) {
+                    const int n = (wave + 7 * b) * 64 + lane;
+                    const float p = dp_down_partial(wd[b], h);
+                    dp_gran_store(a.gP + ((long)(n >> 2) * 256 + cu) * 4 + (n & 3), dp_tag(base, s, l, DP_E_P), __float_as_uint(p));
+                }
+            }
+        }
+        // ---- the head of codebook cb: waves 2..6 hold 2 logit rows each (ws slot 4), x = dec_norm(h)
+        if (!IS_X) {
+            if (!dp_wait<1, false>((dp_lvu32*)(misc + DP_M_FXA), dp_tag(base, s, DP_NL - 1, DP_E_H2), ab, a.err, 0x960u, lane, ts, [&](int) {})) return;
+            if (hunit >= 0) {
+                const dp_lu4* xs = (const dp_lu4*)(lds + DP_OFF_XA);
+                const uint4 x0 = dp_ldq(xs + lane), x1 = dp_ldq(xs + 64 + lane);
+                float a0 = dot8(ws[0][0], x0, 0.f); a0 = dot8(ws[0][1], x1, a0);
+                float a1 = dot8(ws[1][0], x0, 0.f); a1 = dot8(ws[1][1], x1, a1);
+                a0 = wave_sum(a0); a1 = wave_sum(a1);
+                if (lane < DP_NREP) dp_gran_store(a.gL + lane * DP_LSLOTS + hunit, dp_tag(base, s, DP_NL - 1, DP_E_L), pack_bf(a0, a1));
+            }
+            // next use of the small-op rows: the B waves' layer-0 o-proj of the next step (the A waves reload theirs in layer 0)
+            if (IS_B) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) load_ws(0, cb, k);
+            }
+        }
+        // ---- the sampler (quad), on every CU alike: each CU needs the code to fetch its table rows
+        if (IN_QUAD) {
+            if (!dp_wait<1, false>((dp_lvu32*)(misc + DP_M_FLG), dp_tag(base, s, DP_NL - 1, DP_E_L), ab, a.err, 0x970u, lane, ts, [&](int) {})) return;
+            const int tid = (wave - 2) * 64 + (int)lane;
+            const dp_lu4* lg = (const dp_lu4*)(lds + DP_OFF_LOGITS);
+            uint32_t w[2][4];
+            {
+                const uint4 v0 = dp_ldq(lg + tid);
+                w[0][0] = v0.x; w[0][1] = v0.y; w[0][2] = v0.z; w[0][3] = v0.w;
+                const uint4 v1 = tid < 64 ? dp_ldq(lg + 256 + tid) : make_uint4(0, 0, 0, 0);
+                w[1][0] = v1.x; w[1][1] = v1.y; w[1][2] = v1.z; w[1][3] = v1.w;
+            }
+            if (a.logits_out != nullptr && cu == 0) {
+                for (int i = tid; i < a.V; i += 256) a.logits_out[(long)cb * a.V + i] = ((const dp_lu16*)lg)[i];
+            }
+            SampleScratch sc;
+            sc.cand_t = (lds_f32_t*)(lds + DP_OFF_CANDT); sc.cand_i = (lds_i32_t*)(lds + DP_OFF_CANDI); sc.s_max = (lds_u32_t*)(lds + DP_OFF_SMAX);
+            sc.s_bv = (lds_f32_t*)(misc + DP_M_SBV); sc.s_bi = (lds_i32_t*)(misc + DP_M_SBI); sc.s_n = (lds_i32_t*)(misc + DP_M_SN);
+            sc.s_tok = (lds_i32_t*)(misc + DP_M_STOK); sc.s_wtot = (lds_i32_t*)(misc + DP_M_SWTOT);
+            DpQuadSync sync{(dp_lvu32*)(misc + DP_M_BAR), ab, a.err, (int)lane, &quad_phase};
+            const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
+            const int tok = sample_body<2>(w, a.V, a.temperature, a.topk, a.noise ? a.noise + (long)cb * a.V : nullptr, seed, step, 0, cb, sc, tid, sync);
+            if (*ab) return;
+            if (tid == 0) {
+                if (cu == 0) a.frame[cb] = tok;
+                misc[DP_M_TOK] = (uint32_t)tok;
+                dp_flag((dp_lvu32*)(misc + DP_M_FTOK), dp_tag(base, s, DP_NL - 1, DP_E_L));
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cu = blockIdx.x;
+    const unsigned lane = threadIdx.x & 63;
+    dp_lu32* misc = (dp_lu32*)(lds + DP_OFF_MISC);
+    dp_lvu32* ab = (dp_lvu32*)(misc + DP_M_ABORT);
+    // ---- LDS image of the step's starting state (all 512 threads) ----
+    for (int i = threadIdx.x; i < 64; i += 512) misc[i] = 0;
+    for (int i = threadIdx.x; i < 2560 / 2; i += 512) ((dp_lu32*)(lds + DP_OFF_LOGITS))[i] = 0;
+    {   // K/V rows of positions 0..cb_first (rows the chain has not written hold stale bits; they are overwritten before use)
+        const int npos = a.cb_first + 1;
+        for (int i = threadIdx.x; i < DP_NL * 2 * npos * 16; i += 512) {
+            const int c = i & 15, pos = (i >> 4) % npos, lk = (i >> 4) / npos;           // lk = layer * 2 + kv head
+            const long src = (long)(lk >> 1) * a.kv_layer_stride + ((long)(lk & 1) * 32 + pos) * DP_HD;
+            dp_stq((dp_lu4*)(lds + DP_OFF_K + (lk * 32 + pos) * 256) + c, reinterpret_cast<const uint4*>(a.kc + src)[c]);
+            dp_stq((dp_lu4*)(lds + DP_OFF_V + (lk * 32 + pos) * 256) + c, reinterpret_cast<const uint4*>(a.vc + src)[c]);
+        }
+        for (int i = threadIdx.x; i < 128; i += 512) dp_stq((dp_lu4*)(lds + DP_OFF_QB) + i, reinterpret_cast<const uint4*>(a.qd)[i]);
+        if (threadIdx.x < 2) misc[DP_M_H0 + threadIdx.x] = reinterpret_cast<const uint32_t*>(a.hdec)[2 * cu + threadIdx.x];
+    }
+    __syncthreads();
+    const uint32_t base = *a.epoch;
+    if (wave == 7) {
+        // ------------------------------------------------------------------------------------------------ gather wave
+        const int rep = cu % DP_NREP, ln = (int)lane;
+        const dp_u64 *rgQ = a.gQ + rep * 768, *rgH1 = a.gH1 + rep * 512, *rgH2 = a.gH2 + rep * 512, *rgL = a.gL + rep * DP_LSLOTS;
+        const dp_u64* rgP = a.gP + (long)cu * 1024;
+        const int n_steps = a.cb_last - a.cb_first + 1;
+        dp_flag((dp_lvu32*)(misc + DP_M_FQ), dp_tag(base, 0, 0, DP_E_Q));          // layer 0's q / k / v of the first step are in place
+        for (int s = 0; s < n_steps; ++s) {
+            const int cb = a.cb_first + s;
+            for (int l = 0; l < DP_NL; ++l) {
+                if (l > 0) {
+                    {   // rows of the previous layer -> sa_norm -> xA
+                        uint32_t v[8];
+                        if (!dp_sweep<8>(rgH2, 512, dp_tag(base, s, l - 1, DP_E_H2), v, ln, ab, a.err, 0x100u + l, a.poll_sleep)) return;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ((dp_lu32*)(lds + DP_OFF_XA))[j * 64 + ln] = v[j];
+                        dp_norm_in_lds((dp_lu4*)(lds + DP_OFF_XA), (const bf16_t*)a.lw[l].sa_norm, a.eps, ln);
+                        dp_flag((dp_lvu32*)(misc + DP_M_FXA), dp_tag(base, s, l - 1, DP_E_H2));
+                    }
+                    {   // q | k | v -> q buffer and this position's K / V rows
+                        uint32_t v[12];
+                        if (!dp_sweep<12>(rgQ, 768, dp_tag(base, s, l, DP_E_Q), v, ln, ab, a.err, 0x200u + l, a.poll_sleep)) return;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ((dp_lu32*)(lds + DP_OFF_QB))[j * 64 + ln] = v[j];
+#pragma unroll
+                        for (int j = 8; j < 12; ++j) {        // j = 8, 9: k heads 0, 1;  10, 11: v heads 0, 1
+                            const int kvh = j & 1;
+                            ((dp_lu32*)(lds + (j < 10 ? DP_OFF_K : DP_OFF_V) + ((l * 2 + kvh) * 32 + cb) * 256))[ln] = v[j];
+                        }
+                        dp_flag((dp_lvu32*)(misc + DP_M_FQ), dp_tag(base, s, l, DP_E_Q));
+                    }
+                }
+                {   // rows after the o-projection -> mlp_norm -> xC
+                    uint32_t v[8];
+                    if (!dp_sweep<8>(rgH1, 512, dp_tag(base, s, l, DP_E_H1), v, ln, ab, a.err, 0x300u + l, a.poll_sleep)) return;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ((dp_lu32*)(lds + DP_OFF_XC))[j * 64 + ln] = v[j];
+                    dp_norm_in_lds((dp_lu4*)(lds + DP_OFF_XC), (const bf16_t*)a.lw[l].mlp_norm, a.eps, ln);
+                    dp_flag((dp_lvu32*)(misc + DP_M_FXC), dp_tag(base, s, l, DP_E_H1));
+                }
+                {   // the 256 down-projection partials of my 4 rows -> sum + residual -> the layer's output rows
+                    uint32_t v[16];
+                    if (!dp_sweep<16>(rgP, 1024, dp_tag(base, s, l, DP_E_P), v, ln, ab, a.err, 0x400u + l, a.poll_sleep)) return;
+                    const float tot = dp_reduce_partials(v);
+                    const uint32_t h1w = *(dp_lvu32*)(misc + DP_M_H1 + ((ln & 3) >> 1));
+                    const float res = (ln & 1) ? hi2f(h1w) : lo2f(h1w);
+                    float y;
+                    {
+#pragma clang fp contract(off)
+                        y = round_bf(tot) + res;
+                    }
+                    const uint32_t hb = (uint32_t)f2bf(y);
+                    const uint32_t hb_next = (uint32_t)__shfl_down((int)hb, 1, 64);
+                    const uint32_t pair = hb | (hb_next << 16);                    // valid in lanes 0 and 2
+                    if (ln == 0 || ln == 2) misc[DP_M_H0 + (ln >> 1)] = pair;
+                    const uint32_t p0 = (uint32_t)__shfl((int)pair, 0, 64), p1 = (uint32_t)__shfl((int)pair, 2, 64);
+                    if (ln < 2 * DP_NREP) dp_gran_store(a.gH2 + (ln >> 1) * 512 + 2 * cu + (ln & 1), dp_tag(base, s, l, DP_E_H2), (ln & 1) ? p1 : p0);
+                }
+            }
+            {   // the stack's output rows -> final norm -> x of the head
+                uint32_t v[8];
+                if (!dp_sweep<8>(rgH2, 512, dp_tag(base, s, DP_NL - 1, DP_E_H2), v, ln, ab, a.err, 0x500u, a.poll_sleep)) return;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ((dp_lu32*)(lds + DP_OFF_XA))[j * 64 + ln] = v[j];
+                dp_norm_in_lds((dp_lu4*)(lds + DP_OFF_XA), a.dec_norm, a.eps, ln);
+                dp_flag((dp_lvu32*)(misc + DP_M_FXA), dp_tag(base, s, DP_NL - 1, DP_E_H2));
+            }
+            {   // logits -> LDS
+                uint32_t v[17];
+                if (!dp_sweep<17>(rgL, (a.V + 1) / 2, dp_tag(base, s, DP_NL - 1, DP_E_L), v, ln, ab, a.err, 0x600u, a.poll_sleep)) return;
+#pragma unroll
+                for (int j = 0; j < 17; ++j)
+                    if (j * 64 + ln < (a.V + 1) / 2) ((dp_lu32*)(lds + DP_OFF_LOGITS))[j * 64 + ln] = v[j];
+                if ((a.V & 1) && ln == 0) ((dp_lu16*)(lds + DP_OFF_LOGITS))[a.V] = 0;       // the tail unit's second half is not a logit
+                dp_flag((dp_lvu32*)(misc + DP_M_FLG), dp_tag(base, s, DP_NL - 1, DP_E_L));
+            }
+            {   // the sampled code -> the next step's input row and layer-0 q / k / v (table rows), like k_sample's tail
+                const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
+                while (*(dp_lvu32*)(misc + DP_M_FTOK) != dp_tag(base, s, DP_NL - 1, DP_E_L)) {
+                    if (dp_give_up(t0, ab, a.err, 0x700u, ln)) return;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+                if (cb + 1 < a.ncb) {
+                    int fed = a.forced ? a.forced[cb] : (int)*(dp_lvu32*)(misc + DP_M_TOK);
+                    fed = min(max(fed, 0), a.V - 1);
+                    const uint32_t* hrow = reinterpret_cast<const uint32_t*>(a.proj_emb + ((long)cb * a.V + fed) * DP_D);
+                    const uint32_t* qrow = reinterpret_cast<const uint32_t*>(a.qkv0_tab + ((long)(cb - 1) * a.V + fed) * DP_NQKV);
+                    uint32_t qv[12];
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) qv[j] = qrow[j * 64 + ln];
+                    const uint32_t hv = ln < 2 ? hrow[2 * cu + ln] : 0u;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ((dp_lu32*)(lds + DP_OFF_QB))[j * 64 + ln] = qv[j];
+#pragma unroll
+                    for (int j = 8; j < 12; ++j)
+                        ((dp_lu32*)(lds + (j < 10 ? DP_OFF_K : DP_OFF_V) + ((j & 1) * 32 + cb + 1) * 256))[ln] = qv[j];
+                    if (ln < 2) misc[DP_M_H0 + ln] = hv;
+                    dp_flag((dp_lvu32*)(misc + DP_M_FQ), dp_tag(base, s + 1, 0, DP_E_Q));
+                }
+            }
+        }
+        if (cu == 0 && lane == 0) __hip_atomic_store(a.epoch, base + (uint32_t)(n_steps * DP_NL * 5 + 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (wave < 2) dp_compute_wave<true, false, false>(a, lds, wave, lane, cu, base);
+    else if (wave < 5) dp_compute_wave<false, true, true>(a, lds, wave, lane, cu, base);
+    else if (wave == 5) dp_compute_wave<false, false, true>(a, lds, wave, lane, cu, base);
+    else dp_compute_wave<false, false, false>(a, lds, wave, lane, cu, base);
+}
+
+// W2 [1024][8192] -> [256 cu][4 k chunks][1024 rows] 16-byte pieces (workgroup cu's 32 columns, 8 at a time)
+__global__ void k_dp_retile_w2(const bf16_t* w2, uint4* w2s) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 256L * 4 * 1024) return;
+    const int n = (int)(i % 1024), q = (int)((i / 1024) % 4), c = (int)(i / 4096);
+    w2s[i] = *reinterpret_cast<const uint4*>(w2 + (long)n * DP_FFN + c * 32 + q * 8);
+}
