@@ -46,6 +46,13 @@ int csm_op_embed_sum(int M, int ncb, int d, int audio_vocab, int text_vocab, con
 int csm_op_sample(int B, int V, int ldl, const void* logits, float temperature, int topk, const void* noise,
                   const uint64_t* rng, int codebook, int ncb, int32_t* frame, void* stream);
 
+/* Debug timeline of the persistent depth-decoder launch (csrc/dec_persist.cuh): the first call (host == NULL) turns it
+ * on, later calls copy [32 steps][32] s_memrealtime ticks (100 MHz) of workgroup 100's gather wave to `host`.
+ * Per step s: words l*4 + {0: x of q|k|v ready, 1: q/k/v in LDS, 2: x of the MLP ready, 3: layer-l rows published},
+ * 16: x of the head ready, 17: logits in LDS, 18: code sampled, 19: next step's table rows in LDS, 20-23: head / sampler waves, 24-27: poll passes of the logits / head-x / q|k|v / partials sweeps.   CSM_E_STATE when the
+ * handle does not run the persistent launch.                                                                          */
+int csm_debug_persist_stamps(csm_handle h, uint64_t* host, int n_words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,31 @@ __device__ __forceinline__ float wave_max(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// integer min over the wave on the DPP network (same butterfly as wave_max)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ int wave_min_i(int v) {
+    v = min(v, dpp_i<0xB1, 0xF>(v, v));
+    v = min(v, dpp_i<0x4E, 0xF>(v, v));
+    v = min(v, dpp_i<0x141, 0xF>(v, v));
+    v = min(v, dpp_i<0x140, 0xF>(v, v));
+    v = min(v, dpp_i<0x142, 0xA>(v, v));
+    v = min(v, dpp_i<0x143, 0xC>(v, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// exclusive prefix sum over the wave of a small non-negative count (< 2^BITS per lane), bit-sliced: one ballot and one
+// mbcnt per bit, no LDS round trips (a __shfl_up scan is six ds_bpermute)
+template <int BITS>
+__device__ __forceinline__ int wave_excl_scan_small(int cnt) {
+    int excl = 0;
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+        const unsigned long long m = __ballot((cnt >> b) & 1);
+        excl += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) << b;
+    }
+    return excl;
+}
+
 // streamed-once weight load: non-temporal keeps the 1.9 GB backbone stream from evicting
 // the depth decoder's 222 MB out of the 256 MB Infinity Cache.
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));

@@ -79,6 +79,7 @@ struct CsmModel {
     uint32_t* p_state;                  // [0] tag epoch, [1] give-up code of the last launch (0 = ok)
     uint4* p_w2s[DP_NL];
     int p_trickle, p_poll;
+    dp_u64* p_stamps;                   // debug timeline (csm_debug_persist_stamps), else nullptr
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
     int last_S;                         // rows per sequence of the h buffer feeding csm_depth
     // graph
@@ -586,6 +587,7 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             p.V = V; p.ncb = ncb; p.frame = m->frame; p.logits_out = (bf16_t*)logits_out; p.cb_first = 2; p.cb_last = ncb - 1;
             p.gQ = m->pg_q; p.gH1 = m->pg_h1; p.gH2 = m->pg_h2; p.gL = m->pg_l; p.gP = m->pg_p;
             p.err = m->p_state + 1; p.epoch = m->p_state; p.eps = c.decoder.norm_eps; p.trickle_sleep = m->p_trickle; p.poll_sleep = m->p_poll;
+            p.stamps = m->p_stamps;
             hipLaunchKernelGGL(k_dec_persist, dim3(DP_NB), dim3(512), DP_LDS_BYTES, st, p);
             return hipGetLastError();
         }
@@ -980,6 +982,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
             m->persist = true;
         }
     }
+    m->p_stamps = nullptr;
     *out = m;
     return CSM_OK;
 }
@@ -1147,6 +1150,21 @@ extern "C" double csm_bytes_per_frame(csm_handle m, int B, double p_mean) {
 // ---------------------------------------------------------------------------------------
 // op-level test hooks (include/csm_hip_ops.h)
 // ---------------------------------------------------------------------------------------
+// debug: enable (host == nullptr) or read back the persistent decoder's gather-wave timeline, [32 steps][32] 100 MHz ticks
+extern "C" int csm_debug_persist_stamps(csm_handle m, uint64_t* host, int n_words) {
+    if (!m || !m->persist) return CSM_E_STATE;
+    if (!m->p_stamps) {
+        HIPCHK(m, hipMalloc((void**)&m->p_stamps, (32 * 32 + 4096) * 8));
+        HIPCHK(m, hipMemset(m->p_stamps, 0, (32 * 32 + 4096) * 8));
+        if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }      // re-capture with the stamp pointer
+    }
+    if (host) {
+        HIPCHK(m, hipDeviceSynchronize());
+        HIPCHK(m, hipMemcpy(host, m->p_stamps, (size_t)(n_words < 32 * 32 + 4096 ? n_words : 32 * 32 + 4096) * 8, hipMemcpyDeviceToHost));
+    }
+    return CSM_OK;
+}
+
 extern "C" int csm_op_gemv(int kind, int M, int K, int N, const void* x, long x_row_stride, long x_row_offset,
                            const void* norm_scale, float eps, const void* w0, const void* w1, const void* w2,
                            const void* resid, void* out, long ldo, void* normed_out, long normed_stride, int nt,

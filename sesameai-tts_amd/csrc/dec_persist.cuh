@@ -71,6 +71,7 @@ struct DecPersistArgs {
     uint32_t* epoch;
     float eps;
     int trickle_sleep, poll_sleep;
+    dp_u64* stamps;                   // optional (csm_debug_persist_stamps): s_memrealtime of workgroup 100's gather wave, [step][32]
 };
 
 // LDS image (dynamic shared memory; byte offsets)
@@ -85,7 +86,7 @@ struct DecPersistArgs {
 #define DP_OFF_CANDI (DP_OFF_U + 8448)
 #define DP_OFF_LOGITS (DP_OFF_U + 16896)             // 2560 bf16
 #define DP_OFF_SMAX (DP_OFF_LOGITS + 5120)           // 256 u32
-#define DP_OFF_PS (DP_OFF_SMAX + 1024)               // attention P rows: 4 waves x 64 floats
+#define DP_OFF_PS (DP_OFF_SMAX + 1024)               // attention P rows: 8 waves x 32 floats
 #define DP_OFF_MISC (DP_OFF_PS + 1024)
 #define DP_LDS_BYTES (DP_OFF_MISC + 256)
 // misc words
@@ -143,29 +144,38 @@ __device__ __forceinline__ bool dp_wait(dp_lvu32* f, uint32_t tag, dp_lvu32* ab,
     seen = __builtin_amdgcn_readfirstlane(seen);
     if (!seen) {
         const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
-        while (!hit()) {
-            if (dp_give_up(t0, ab, err, code, lane)) return false;
-            __builtin_amdgcn_s_sleep(1);
-        }
+        for (uint32_t spins = 1; !hit(); ++spins)
+            if ((spins & 255u) == 0 && dp_give_up(t0, ab, err, code, lane)) return false;
     }
     asm volatile("" ::: "memory");
     return true;
 }
 
-// gather wave: sweep NL granules per lane (slots j*64 + lane < n_valid) until every tag matches
+// gather wave: sweep the granules of one edge until every tag matches.  16-byte `sc1` loads (two granules per lane
+// per instruction: a poll pass costs ~0.1 us per load instruction, so half the instructions of 8-byte polls), all
+// issued before the one wait; load j of lane l covers granules 2 (j*64 + l) and the next one, clamped to the last
+// valid pair (no per-load predicate: hipcc would serialise predicated loads).  v[2j], v[2j+1] = their payloads.
 template <int NL>
-__device__ __forceinline__ bool dp_sweep(const dp_u64* g, int n_valid, uint32_t tag, uint32_t (&v)[NL], int lane, dp_lvu32* ab, uint32_t* err,
-                                         uint32_t code, int poll_sleep) {
+__device__ __forceinline__ bool dp_sweep(const dp_u64* g, int n_valid, uint32_t tag, uint32_t (&v)[2 * NL], int lane, dp_lvu32* ab, uint32_t* err,
+                                         uint32_t code, int poll_sleep, dp_u64* passes = nullptr) {
     const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
+    const int last_pair = (n_valid - 1) >> 1;
     for (;;) {
+        if (passes && lane == 0) *passes += 1;
+        u32x4_t x[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const dp_u64* p = g + 2 * min(j * 64 + lane, last_pair);
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x[j]) : "v"(p) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            if (j * 64 + lane < n_valid) {
-                const dp_u64 x = dp_gran_load(g + j * 64 + lane);
-                v[j] = (uint32_t)x;
-                ok &= (uint32_t)(x >> 32) == tag;
-            } else v[j] = 0;
+            asm volatile("" : "+v"(x[j]));                 // the values exist only behind the wait above
+            v[2 * j] = x[j].x; v[2 * j + 1] = x[j].z;
+            const bool second = 2 * min(j * 64 + lane, last_pair) + 1 < n_valid;
+            ok &= x[j].y == tag && (x[j].w == tag || !second);
         }
         if (__all(ok)) return true;
         if (dp_give_up(t0, ab, err, code, lane)) return false;
@@ -235,69 +245,73 @@ __device__ __forceinline__ float dp_down_partial(const uint4 (&w)[4], const uint
     acc = dot8(w[2], h[2], acc);
     return dot8(w[3], h[3], acc);
 }
-// owner-side sum of the 256 partials of 4 rows: lane l holds row l & 3 of producers j*16 + (l >> 2), j = 0..15
-__device__ __forceinline__ float dp_reduce_partials(const uint32_t (&v)[16]) {
-    float s = __uint_as_float(v[0]);
+// owner-side sum of the 256 partials of 4 rows (granule index producer*4 + row): lane l holds rows 2 (l & 1) and
+// 2 (l & 1) + 1 of producers j*32 + (l >> 1), j = 0..7 (v[2j], v[2j+1]); sequential over j, then butterflies over the
+// lanes of equal parity.  Returns the two row totals of this lane's parity in every lane.
+__device__ __forceinline__ void dp_reduce_partials(const uint32_t (&v)[16], float& r0, float& r1) {
+    float s0 = __uint_as_float(v[0]), s1 = __uint_as_float(v[1]);
 #pragma unroll
-    for (int j = 1; j < 16; ++j) s += __uint_as_float(v[j]);
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 8, 64);
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    return s;
+    for (int j = 1; j < 8; ++j) { s0 += __uint_as_float(v[2 * j]); s1 += __uint_as_float(v[2 * j + 1]); }
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    r0 = s0; r1 = s1;
 }
 
-// stage_attn (gemv.cuh) for one row, heads h and h + 1 of one KV group, with q / K / V in LDS.  Same lane layout and
-// operation order: lane l holds 16-byte pieces of keys 4i + l/16 (i = 0..7) at element offset 8 (l % 16).
-__device__ __forceinline__ void dp_attention_pair(const dp_lu4* qb, const dp_lu4* kt, const dp_lu32* vt, dp_lf32* myps, dp_lu32* att,
+// stage_attn (gemv.cuh) for one row and ONE head, with q / K / V in LDS (that kernel walks two heads of a KV group
+// per wave; per head the lane layout and the operation order are the same): lane l holds 16-byte pieces of keys
+// 4i + l/16 (i = 0..7) at element offset 8 (l % 16).  Eight waves take one head each.
+__device__ __forceinline__ void dp_attention_head(const dp_lu4* qb, const dp_lu4* kt, const dp_lu32* vt, dp_lf32* myps, dp_lu32* att,
                                                   int h, int nk, float ascale, int lane) {
     const int grp = lane >> 4, sub = lane & 15;
-    const uint4 qa = dp_ldq(qb + h * 16 + sub), qbv = dp_ldq(qb + (h + 1) * 16 + sub);
-    float s0[8], s1[8], mx0 = -INFINITY, mx1 = -INFINITY;
+    const uint4 qa = dp_ldq(qb + h * 16 + sub);
+    float s0[8], mx0 = -INFINITY;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        s0[i] = -INFINITY; s1[i] = -INFINITY;
+        s0[i] = -INFINITY;
         if (4 * i < nk) {
             const uint4 kv = dp_ldq(kt + i * 64 + lane);
             const bool live = (4 * i + grp) < nk;
-            const float d0 = row16_sum(dot8(qa, kv, 0.f)) * ascale, d1 = row16_sum(dot8(qbv, kv, 0.f)) * ascale;
+            const float d0 = row16_sum(dot8(qa, kv, 0.f)) * ascale;
             s0[i] = live ? d0 : -INFINITY;
-            s1[i] = live ? d1 : -INFINITY;
-            mx0 = fmaxf(mx0, s0[i]); mx1 = fmaxf(mx1, s1[i]);
+            mx0 = fmaxf(mx0, s0[i]);
         }
     }
-    mx0 = wave_max(mx0); mx1 = wave_max(mx1);
-    float l0 = 0.f, l1 = 0.f;
+    mx0 = wave_max(mx0);
+    float l0 = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         if (4 * i < nk) {
             s0[i] = (s0[i] == -INFINITY) ? 0.f : __expf(s0[i] - mx0);
-            s1[i] = (s1[i] == -INFINITY) ? 0.f : __expf(s1[i] - mx1);
-            l0 += s0[i]; l1 += s1[i];
-            if (sub == 0) { myps[4 * i + grp] = s0[i]; myps[32 + 4 * i + grp] = s1[i]; }
+            l0 += s0[i];
+            if (sub == 0) myps[4 * i + grp] = s0[i];
         }
     }
     l0 = wave_sum(l0) * (1.0f / 16.0f);
-    l1 = wave_sum(l1) * (1.0f / 16.0f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+    float o00 = 0.f, o01 = 0.f;
 #pragma unroll
     for (int t4 = 0; t4 < 8; ++t4) {
         if (4 * t4 < nk) {
             const float pav[4] = {myps[4 * t4], myps[4 * t4 + 1], myps[4 * t4 + 2], myps[4 * t4 + 3]};
-            const float pbv[4] = {myps[32 + 4 * t4], myps[32 + 4 * t4 + 1], myps[32 + 4 * t4 + 2], myps[32 + 4 * t4 + 3]};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t raw = (4 * t4 + u) < nk ? vt[(4 * t4 + u) * 64 + lane] : 0u;
-                const float v0 = lo2f(raw), v1 = hi2f(raw);
-                o00 += pav[u] * v0; o01 += pav[u] * v1;
-                o10 += pbv[u] * v0; o11 += pbv[u] * v1;
+                o00 += pav[u] * lo2f(raw); o01 += pav[u] * hi2f(raw);
             }
         }
     }
-    const float i0 = 1.0f / l0, i1 = 1.0f / l1;
+    const float i0 = 1.0f / l0;
     att[h * 64 + lane] = pack_bf(o00 * i0, o01 * i0);
-    att[(h + 1) * 64 + lane] = pack_bf(o10 * i1, o11 * i1);
+}
+// head `wave` of layer l, keys 0..cb, then one arrival on the attention counter
+__device__ __forceinline__ void dp_attention_wave(char* lds, int wave, int l, int cb, int lane) {
+    dp_lu32* misc = (dp_lu32*)(lds + DP_OFF_MISC);
+    const int kvh = wave >> 2;
+    dp_attention_head((const dp_lu4*)(lds + DP_OFF_QB), (const dp_lu4*)(lds + DP_OFF_K + ((l * 2 + kvh) * 32) * 256),
+                      (const dp_lu32*)(lds + DP_OFF_V + ((l * 2 + kvh) * 32) * 256), (dp_lf32*)(lds + DP_OFF_PS) + wave * 32,
+                      (dp_lu32*)(lds + DP_OFF_ATT), wave, cb + 1, 0.08838834764831845f, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(misc + DP_M_ATTN, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // 4-wave barrier of the quad (waves 2..5) on an LDS counter: phase-numbered, bounded
@@ -308,8 +322,10 @@ struct DpQuadSync {
         const uint32_t want = 4u * (++*phase);
         if (lane == 0) __hip_atomic_fetch_add((dp_lu32*)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
-        while ((int32_t)(*ctr - want) < 0)
-            if (dp_give_up(t0, ab, err, 0xB00u, lane)) break;
+        for (uint32_t spins = 1; (int32_t)(*ctr - want) < 0; ++spins) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((spins & 255u) == 0 && dp_give_up(t0, ab, err, 0xB00u, lane)) break;
+        }
         asm volatile("" ::: "memory");
     }
 };
@@ -324,7 +340,7 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
     constexpr int NP = IS_X ? 6 : 4, NBK = IS_X ? 3 : 2, NCD = NP * 4 + NBK * 4;
     dp_lu32* misc = (dp_lu32*)(lds + DP_OFF_MISC);
     dp_lvu32* ab = (dp_lvu32*)(misc + DP_M_ABORT);
-    const int ts = a.trickle_sleep;
+    const int ts = a.trickle_sleep & 63;
     const int unit = IS_A ? cu * 3 + (wave - 2) : cu * 2 + (wave - 5);            // q|k|v unit (768) or o-proj unit (512)
     const int hoff = IS_X ? wave * 6 : 12 + (wave - 2) * 4;
     const int hbase = cu * 32 + hoff;
@@ -389,25 +405,19 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                     if (lane < DP_NREP) dp_gran_store(a.gQ + lane * 768 + unit, dp_tag(base, s, l, DP_E_Q), outw);
                 }
             }
-            if (IN_QUAD) {
-                // -- attention: 2 heads per quad wave over keys 0..cb; the A waves' next q|k|v rows and a third of the MLP weights meanwhile
+            {
+                // -- attention: head `wave` over keys 0..cb (the gather wave takes head 7); the A waves' next q|k|v rows and part
+                //    of this layer's MLP weights meanwhile
                 constexpr int N2 = IS_A ? 4 + NCD / 3 : NCD / 2;
                 if (!dp_wait<N2, false>((dp_lvu32*)(misc + DP_M_FQ), dp_tag(base, s, l, DP_E_Q), ab, a.err, 0x920u, lane, ts, [&](int k) {
                         if (IS_A) { if (k < 4) load_ws(l + 1 < DP_NL ? l + 1 : DP_NL, cb, k); else load_cd(l, NCD / 3 + k - 4); }
                         else load_cd(l, k);
                     })) return;
-                const int h = (wave - 2) * 2, kvh = h >> 2;
-                dp_attention_pair((const dp_lu4*)(lds + DP_OFF_QB), (const dp_lu4*)(lds + DP_OFF_K + ((l * 2 + kvh) * 32) * 256),
-                                  (const dp_lu32*)(lds + DP_OFF_V + ((l * 2 + kvh) * 32) * 256), (dp_lf32*)(lds + DP_OFF_PS) + (wave - 2) * 64, att,
-                                  h, cb + 1, 0.08838834764831845f, lane);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(misc + DP_M_ATTN, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                dp_attention_wave(lds, wave, l, cb, lane);
             }
             if (IS_B) {
                 // -- o-projection unit + residual, once the four attention waves are done
-                constexpr int N3 = IN_QUAD ? 0 : NCD / 2;
-                if (!dp_wait<N3 ? N3 : 1, true>((dp_lvu32*)(misc + DP_M_ATTN), 4u * (uint32_t)(it + 1), ab, a.err, 0x930u, lane, ts,
-                                                [&](int k) { if (N3) load_cd(l, k); })) return;
+                if (!dp_wait<1, true>((dp_lvu32*)(misc + DP_M_ATTN), 8u * (uint32_t)(it + 1), ab, a.err, 0x930u, lane, ts, [&](int) {})) return;
                 const dp_lu4* xs = (const dp_lu4*)att;
                 const uint4 x0 = dp_ldq(xs + lane), x1 = dp_ldq(xs + 64 + lane);
                 float a0 = dot8(ws[0][0], x0, 0.f); a0 = dot8(ws[0][1], x1, a0);
@@ -420,9 +430,9 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
             }
             {
                 // -- the MLP: my (gate, up) pairs -> h values -> LDS -> my row blocks of the split down projection
-                constexpr int N4 = IS_X ? NCD : IS_A ? NCD - 2 * (NCD / 3) : 4 + NCD / 2;
+                constexpr int N4 = IS_X ? NCD - NCD / 2 : IS_A ? NCD - 2 * (NCD / 3) : 4 + NCD - NCD / 2;
                 if (!dp_wait<N4, false>((dp_lvu32*)(misc + DP_M_FXC), dp_tag(base, s, l, DP_E_H1), ab, a.err, 0x940u, lane, ts, [&](int k) {
-                        if (IS_X) load_cd(l, k);
+                        if (IS_X) load_cd(l, NCD / 2 + k);
                         else if (IS_A) load_cd(l, 2 * (NCD / 3) + k);
                         else { if (k < 4) load_ws(l + 1 < DP_NL ? l + 1 : DP_NL, cb, k); else load_cd(l, NCD / 2 + k - 4); }
                     })) return;
@@ -440,8 +450,8 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                 {
                     const uint32_t want = 7u * (uint32_t)(it + 1);
                     const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
-                    while ((int32_t)(*(dp_lvu32*)(misc + DP_M_CD) - want) < 0)
-                        if (dp_give_up(t0, ab, a.err, 0x950u, lane)) return;
+                    for (uint32_t spins = 1; (int32_t)(*(dp_lvu32*)(misc + DP_M_CD) - want) < 0; ++spins)
+                        if ((spins & 255u) == 0 && dp_give_up(t0, ab, a.err, 0x950u, lane)) return;
                     asm volatile("" ::: "memory");
                 }
                 uint4 h[4];
@@ -458,6 +468,8 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
         // ---- the head of codebook cb: waves 2..6 hold 2 logit rows each (ws slot 4), x = dec_norm(h)
         if (!IS_X) {
             if (!dp_wait<1, false>((dp_lvu32*)(misc + DP_M_FXA), dp_tag(base, s, DP_NL - 1, DP_E_H2), ab, a.err, 0x960u, lane, ts, [&](int) {})) return;
+            const bool st2 = a.stamps != nullptr && cu == 100 && lane == 0 && wave == 2;
+            if (st2) a.stamps[s * 32 + 20] = __builtin_amdgcn_s_memrealtime();
             if (hunit >= 0) {
                 const dp_lu4* xs = (const dp_lu4*)(lds + DP_OFF_XA);
                 const uint4 x0 = dp_ldq(xs + lane), x1 = dp_ldq(xs + 64 + lane);
@@ -465,7 +477,10 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                 float a1 = dot8(ws[1][0], x0, 0.f); a1 = dot8(ws[1][1], x1, a1);
                 a0 = wave_sum(a0); a1 = wave_sum(a1);
                 if (lane < DP_NREP) dp_gran_store(a.gL + lane * DP_LSLOTS + hunit, dp_tag(base, s, DP_NL - 1, DP_E_L), pack_bf(a0, a1));
+                if (a.trickle_sleep & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // experiment: drain the publishing store
             }
+            if (st2) a.stamps[s * 32 + 21] = __builtin_amdgcn_s_memrealtime();
+            if (a.stamps != nullptr && s == 5 && lane == 0 && hunit >= 0) a.stamps[1024 + cu * 8 + wave] = __builtin_amdgcn_s_memrealtime();
             // next use of the small-op rows: the B waves' layer-0 o-proj of the next step (the A waves reload theirs in layer 0)
             if (IS_B) {
 #pragma unroll
@@ -476,6 +491,7 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
         if (IN_QUAD) {
             if (!dp_wait<1, false>((dp_lvu32*)(misc + DP_M_FLG), dp_tag(base, s, DP_NL - 1, DP_E_L), ab, a.err, 0x970u, lane, ts, [&](int) {})) return;
             const int tid = (wave - 2) * 64 + (int)lane;
+            if (a.stamps != nullptr && cu == 100 && tid == 0) a.stamps[s * 32 + 22] = __builtin_amdgcn_s_memrealtime();
             const dp_lu4* lg = (const dp_lu4*)(lds + DP_OFF_LOGITS);
             uint32_t w[2][4];
             {
@@ -495,6 +511,7 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
             const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
             const int tok = sample_body<2>(w, a.V, a.temperature, a.topk, a.noise ? a.noise + (long)cb * a.V : nullptr, seed, step, 0, cb, sc, tid, sync);
             if (*ab) return;
+            if (a.stamps != nullptr && cu == 100 && tid == 0) a.stamps[s * 32 + 23] = __builtin_amdgcn_s_memrealtime();
             if (tid == 0) {
                 if (cu == 0) a.frame[cb] = tok;
                 misc[DP_M_TOK] = (uint32_t)tok;
@@ -533,82 +550,97 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
         const dp_u64* rgP = a.gP + (long)cu * 1024;
         const int n_steps = a.cb_last - a.cb_first + 1;
         dp_flag((dp_lvu32*)(misc + DP_M_FQ), dp_tag(base, 0, 0, DP_E_Q));          // layer 0's q / k / v of the first step are in place
+        const bool st = a.stamps != nullptr && cu == 100 && lane == 0;
+#define DP_STAMP(s_, i_) do { if (st) a.stamps[(s_) * 32 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
         for (int s = 0; s < n_steps; ++s) {
             const int cb = a.cb_first + s;
             for (int l = 0; l < DP_NL; ++l) {
                 if (l > 0) {
                     {   // rows of the previous layer -> sa_norm -> xA
                         uint32_t v[8];
-                        if (!dp_sweep<8>(rgH2, 512, dp_tag(base, s, l - 1, DP_E_H2), v, ln, ab, a.err, 0x100u + l, a.poll_sleep)) return;
+                        if (!dp_sweep<4>(rgH2, 512, dp_tag(base, s, l - 1, DP_E_H2), v, ln, ab, a.err, 0x100u + l, a.poll_sleep)) return;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) ((dp_lu32*)(lds + DP_OFF_XA))[j * 64 + ln] = v[j];
+                        for (int j = 0; j < 4; ++j) { ((dp_lu32*)(lds + DP_OFF_XA))[2 * (j * 64 + ln)] = v[2 * j]; ((dp_lu32*)(lds + DP_OFF_XA))[2 * (j * 64 + ln) + 1] = v[2 * j + 1]; }
                         dp_norm_in_lds((dp_lu4*)(lds + DP_OFF_XA), (const bf16_t*)a.lw[l].sa_norm, a.eps, ln);
                         dp_flag((dp_lvu32*)(misc + DP_M_FXA), dp_tag(base, s, l - 1, DP_E_H2));
+                        DP_STAMP(s, l * 4 + 0);
                     }
                     {   // q | k | v -> q buffer and this position's K / V rows
                         uint32_t v[12];
-                        if (!dp_sweep<12>(rgQ, 768, dp_tag(base, s, l, DP_E_Q), v, ln, ab, a.err, 0x200u + l, a.poll_sleep)) return;
+                        if (!dp_sweep<6>(rgQ, 768, dp_tag(base, s, l, DP_E_Q), v, ln, ab, a.err, 0x200u + l, a.poll_sleep, st ? a.stamps + s * 32 + 26 : nullptr)) return;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) ((dp_lu32*)(lds + DP_OFF_QB))[j * 64 + ln] = v[j];
-#pragma unroll
-                        for (int j = 8; j < 12; ++j) {        // j = 8, 9: k heads 0, 1;  10, 11: v heads 0, 1
-                            const int kvh = j & 1;
-                            ((dp_lu32*)(lds + (j < 10 ? DP_OFF_K : DP_OFF_V) + ((l * 2 + kvh) * 32 + cb) * 256))[ln] = v[j];
+                        for (int j = 0; j < 4; ++j) { ((dp_lu32*)(lds + DP_OFF_QB))[2 * (j * 64 + ln)] = v[2 * j]; ((dp_lu32*)(lds + DP_OFF_QB))[2 * (j * 64 + ln) + 1] = v[2 * j + 1]; }
+                        {   // load 4: granules 512 + 2 ln (k: head ln >> 5), load 5: 640 + 2 ln (v)
+                            const int kvh = ln >> 5, wd_ = 2 * (ln & 31);
+                            dp_lu32* kr = (dp_lu32*)(lds + DP_OFF_K + ((l * 2 + kvh) * 32 + cb) * 256);
+                            dp_lu32* vr = (dp_lu32*)(lds + DP_OFF_V + ((l * 2 + kvh) * 32 + cb) * 256);
+                            kr[wd_] = v[8]; kr[wd_ + 1] = v[9]; vr[wd_] = v[10]; vr[wd_ + 1] = v[11];
                         }
                         dp_flag((dp_lvu32*)(misc + DP_M_FQ), dp_tag(base, s, l, DP_E_Q));
+                        DP_STAMP(s, l * 4 + 1);
                     }
                 }
+                dp_attention_wave(lds, 7, l, cb, ln);              // (layer 0: q / k / v were placed by the table fetch)
                 {   // rows after the o-projection -> mlp_norm -> xC
                     uint32_t v[8];
-                    if (!dp_sweep<8>(rgH1, 512, dp_tag(base, s, l, DP_E_H1), v, ln, ab, a.err, 0x300u + l, a.poll_sleep)) return;
+                    if (!dp_sweep<4>(rgH1, 512, dp_tag(base, s, l, DP_E_H1), v, ln, ab, a.err, 0x300u + l, a.poll_sleep)) return;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) ((dp_lu32*)(lds + DP_OFF_XC))[j * 64 + ln] = v[j];
+                    for (int j = 0; j < 4; ++j) { ((dp_lu32*)(lds + DP_OFF_XC))[2 * (j * 64 + ln)] = v[2 * j]; ((dp_lu32*)(lds + DP_OFF_XC))[2 * (j * 64 + ln) + 1] = v[2 * j + 1]; }
                     dp_norm_in_lds((dp_lu4*)(lds + DP_OFF_XC), (const bf16_t*)a.lw[l].mlp_norm, a.eps, ln);
                     dp_flag((dp_lvu32*)(misc + DP_M_FXC), dp_tag(base, s, l, DP_E_H1));
+                    DP_STAMP(s, l * 4 + 2);
                 }
                 {   // the 256 down-projection partials of my 4 rows -> sum + residual -> the layer's output rows
                     uint32_t v[16];
-                    if (!dp_sweep<16>(rgP, 1024, dp_tag(base, s, l, DP_E_P), v, ln, ab, a.err, 0x400u + l, a.poll_sleep)) return;
-                    const float tot = dp_reduce_partials(v);
-                    const uint32_t h1w = *(dp_lvu32*)(misc + DP_M_H1 + ((ln & 3) >> 1));
-                    const float res = (ln & 1) ? hi2f(h1w) : lo2f(h1w);
-                    float y;
+                    if (!dp_sweep<8>(rgP, 1024, dp_tag(base, s, l, DP_E_P), v, ln, ab, a.err, 0x400u + l, a.poll_sleep, st ? a.stamps + s * 32 + 27 : nullptr)) return;
+                    float t0_, t1_;
+                    dp_reduce_partials(v, t0_, t1_);                 // rows 2 (ln & 1), 2 (ln & 1) + 1 of this CU's four
+                    const uint32_t h1w = *(dp_lvu32*)(misc + DP_M_H1 + (ln & 1));
+                    float y0, y1;
                     {
 #pragma clang fp contract(off)
-                        y = round_bf(tot) + res;
+                        y0 = round_bf(t0_) + lo2f(h1w); y1 = round_bf(t1_) + hi2f(h1w);
                     }
-                    const uint32_t hb = (uint32_t)f2bf(y);
-                    const uint32_t hb_next = (uint32_t)__shfl_down((int)hb, 1, 64);
-                    const uint32_t pair = hb | (hb_next << 16);                    // valid in lanes 0 and 2
-                    if (ln == 0 || ln == 2) misc[DP_M_H0 + (ln >> 1)] = pair;
-                    const uint32_t p0 = (uint32_t)__shfl((int)pair, 0, 64), p1 = (uint32_t)__shfl((int)pair, 2, 64);
-                    if (ln < 2 * DP_NREP) dp_gran_store(a.gH2 + (ln >> 1) * 512 + 2 * cu + (ln & 1), dp_tag(base, s, l, DP_E_H2), (ln & 1) ? p1 : p0);
+                    const uint32_t pair = pack_bf(y0, y1);          // lane parity 0: rows 0, 1; parity 1: rows 2, 3
+                    if (ln < 2) misc[DP_M_H0 + ln] = pair;
+                    // copies r = ln >> 1 (lanes 0..15), granule 2cu + (ln & 1)
+                    if (ln < 2 * DP_NREP) dp_gran_store(a.gH2 + (ln >> 1) * 512 + 2 * cu + (ln & 1), dp_tag(base, s, l, DP_E_H2), pair);
+                    DP_STAMP(s, l * 4 + 3);
                 }
             }
             {   // the stack's output rows -> final norm -> x of the head
                 uint32_t v[8];
-                if (!dp_sweep<8>(rgH2, 512, dp_tag(base, s, DP_NL - 1, DP_E_H2), v, ln, ab, a.err, 0x500u, a.poll_sleep)) return;
+                if (!dp_sweep<4>(rgH2, 512, dp_tag(base, s, DP_NL - 1, DP_E_H2), v, ln, ab, a.err, 0x500u, a.poll_sleep, st ? a.stamps + s * 32 + 25 : nullptr)) return;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ((dp_lu32*)(lds + DP_OFF_XA))[j * 64 + ln] = v[j];
+                for (int j = 0; j < 4; ++j) { ((dp_lu32*)(lds + DP_OFF_XA))[2 * (j * 64 + ln)] = v[2 * j]; ((dp_lu32*)(lds + DP_OFF_XA))[2 * (j * 64 + ln) + 1] = v[2 * j + 1]; }
                 dp_norm_in_lds((dp_lu4*)(lds + DP_OFF_XA), a.dec_norm, a.eps, ln);
                 dp_flag((dp_lvu32*)(misc + DP_M_FXA), dp_tag(base, s, DP_NL - 1, DP_E_H2));
+                DP_STAMP(s, 16);
+                if (a.stamps != nullptr && s == 5 && lane == 0) a.stamps[1024 + 2048 + 256 + cu] = __builtin_amdgcn_s_memrealtime();
             }
             {   // logits -> LDS
-                uint32_t v[17];
-                if (!dp_sweep<17>(rgL, (a.V + 1) / 2, dp_tag(base, s, DP_NL - 1, DP_E_L), v, ln, ab, a.err, 0x600u, a.poll_sleep)) return;
+                uint32_t v[18];
+                const int ng = (a.V + 1) / 2;
+                if (!dp_sweep<9>(rgL, ng, dp_tag(base, s, DP_NL - 1, DP_E_L), v, ln, ab, a.err, 0x600u, a.poll_sleep, st ? a.stamps + s * 32 + 24 : nullptr)) return;
 #pragma unroll
-                for (int j = 0; j < 17; ++j)
-                    if (j * 64 + ln < (a.V + 1) / 2) ((dp_lu32*)(lds + DP_OFF_LOGITS))[j * 64 + ln] = v[j];
+                for (int j = 0; j < 9; ++j) {
+                    const int g0 = 2 * (j * 64 + ln);
+                    if (g0 < ng) ((dp_lu32*)(lds + DP_OFF_LOGITS))[g0] = v[2 * j];
+                    if (g0 + 1 < ng) ((dp_lu32*)(lds + DP_OFF_LOGITS))[g0 + 1] = v[2 * j + 1];
+                }
                 if ((a.V & 1) && ln == 0) ((dp_lu16*)(lds + DP_OFF_LOGITS))[a.V] = 0;       // the tail unit's second half is not a logit
                 dp_flag((dp_lvu32*)(misc + DP_M_FLG), dp_tag(base, s, DP_NL - 1, DP_E_L));
+                DP_STAMP(s, 17);
+                if (a.stamps != nullptr && s == 5 && lane == 0) a.stamps[1024 + 2048 + cu] = __builtin_amdgcn_s_memrealtime();
             }
             {   // the sampled code -> the next step's input row and layer-0 q / k / v (table rows), like k_sample's tail
                 const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
-                while (*(dp_lvu32*)(misc + DP_M_FTOK) != dp_tag(base, s, DP_NL - 1, DP_E_L)) {
-                    if (dp_give_up(t0, ab, a.err, 0x700u, ln)) return;
+                for (uint32_t spins = 1; *(dp_lvu32*)(misc + DP_M_FTOK) != dp_tag(base, s, DP_NL - 1, DP_E_L); ++spins) {
+                    if ((spins & 255u) == 0 && dp_give_up(t0, ab, a.err, 0x700u, ln)) return;
                     __builtin_amdgcn_s_sleep(1);
                 }
                 asm volatile("" ::: "memory");
+                DP_STAMP(s, 18);
                 if (cb + 1 < a.ncb) {
                     int fed = a.forced ? a.forced[cb] : (int)*(dp_lvu32*)(misc + DP_M_TOK);
                     fed = min(max(fed, 0), a.V - 1);
@@ -625,6 +657,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
                         ((dp_lu32*)(lds + (j < 10 ? DP_OFF_K : DP_OFF_V) + ((j & 1) * 32 + cb + 1) * 256))[ln] = qv[j];
                     if (ln < 2) misc[DP_M_H0 + ln] = hv;
                     dp_flag((dp_lvu32*)(misc + DP_M_FQ), dp_tag(base, s + 1, 0, DP_E_Q));
+                    DP_STAMP(s, 19);
                 }
             }
         }

@@ -197,12 +197,8 @@ __device__ __forceinline__ int sample_body(const uint32_t (&w)[ITERS][4], int V,
                 const bool nan = (bits & 0x7fffu) > 0x7f80u;
                 cnt += (idx < V && !nan && raw_key(bits) >= Lm) ? 1 : 0;
             }
-        int incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(incl, off, WAVE);
-            if (lane >= off) incl += o;
-        }
+        // (cnt <= 8 * ITERS <= 64: 7 bits)
+        const int incl = wave_excl_scan_small<7>(cnt) + cnt;
         if (lane == 63) sc.s_wtot[wave] = incl;
         sync();
         int o = incl - cnt;
@@ -287,11 +283,10 @@ __device__ __forceinline__ int sample_body(const uint32_t (&w)[ITERS][4], int V,
         }
     }
     // argmax over the wave (lowest index on ties), then over the 4 waves
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ob = __shfl_xor(best, off, WAVE);
-        const int oi = __shfl_xor(best_idx, off, WAVE);
-        if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
+    {
+        const float wb = wave_max(best);
+        best_idx = wave_min_i(best == wb ? best_idx : 0x7fffffff);
+        best = wb;
     }
     if (lane == 0) { sc.s_bv[wave] = best; sc.s_bi[wave] = best_idx; }
     sync();

@@ -80,6 +80,7 @@ SIGNATURES = {
     "csm_op_attn_oproj": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "csm_op_embed_sum": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csm_op_sample": (_i, [_i, _i, _i, _vp, _f, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "csm_debug_persist_stamps": (_i, [_vp, _vp, _i]),
 }
 
 # include/mimi_hip.h (bound when the symbols are present; tests/test_abi.py requires them)

@@ -1,0 +1,79 @@
+"""Timeline of the persistent depth-decoder launch (csrc/dec_persist.cuh) on the bench workload: where one decoder
+step's ~90 us go, from the gather wave's s_memrealtime stamps (workgroup 100).  python tools/persist_timeline.py"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "sesameai-tts_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from sesameai import _abi  # noqa: E402
+from sesameai.models import Model, csm_1b_args, synthetic_state_dict  # noqa: E402
+
+
+def main():
+    from types import SimpleNamespace
+    args = SimpleNamespace(ctx_text=40, ctx_frames=125, gen_text=24)
+    margs = csm_1b_args()
+    m = Model(margs, synthetic_state_dict(margs, seed=1234), max_frames=64, max_prefill_rows=256)
+    m.setup_caches(1); m.seed(1)
+    tok, msk = bench.synthetic_prompt(args, 1, margs.text_vocab_size)
+    S = tok.shape[1]
+    m.prefill(tok, msk, torch.arange(S).unsqueeze(0))
+    m.depth(1, 0.9, 50, commit=True)
+    assert _abi.lib.csm_debug_persist_stamps(m._h, None, 0) == 0, "this handle does not run the persistent launch"
+    for _ in range(6):
+        m.step(1, 0.9, 50)
+    buf = (C.c_uint64 * (32 * 32 + 4096))()
+    assert _abi.lib.csm_debug_persist_stamps(m._h, buf, 32 * 32 + 4096) == 0
+    allw = torch.tensor(list(buf), dtype=torch.float64)
+    t = allw[:1024].view(32, 32) * 0.01          # us
+    n_steps = 30
+    names = []
+    seq = []                                                                       # (label, from, to) within a step
+    for l in range(4):
+        if l > 0:
+            seq.append((f"L{l} rows published(L{l-1}) -> x of q|k|v ready (edge + sa_norm)", (l - 1) * 4 + 3, l * 4 + 0))
+            seq.append((f"L{l} x ready -> q/k/v in LDS (q|k|v unit + edge)", l * 4 + 0, l * 4 + 1))
+        seq.append((f"L{l} q/k/v ready -> x of MLP ready (attention + o-proj + edge + mlp_norm)", (l * 4 + 1) if l > 0 else None, l * 4 + 2))
+        seq.append((f"L{l} x of MLP ready -> rows published (gate/up + split down + partials edge + sum)", l * 4 + 2, l * 4 + 3))
+    seq.append(("rows published(L3) -> x of head ready (edge + final norm)", 15, 16))
+    seq.append(("  x of head ready -> head wave 2 saw it", 16, 20))
+    seq.append(("  head wave 2: rows computed and published", 20, 21))
+    seq.append(("  published -> logits in LDS (edge)", 21, 17))
+    seq.append(("  logits in LDS -> sampler waves saw them", 17, 22))
+    seq.append(("  sampler body", 22, 23))
+    seq.append(("  code written -> gather wave saw it", 23, 18))
+    seq.append(("code -> next step's table rows in LDS", 18, 19))
+    tot = 0.0
+    print("persistent depth decoder, workgroup 100, mean over steps 3..28 (us):")
+    for label, a, b in seq:
+        vals = []
+        for s in range(3, n_steps - 1):
+            ta = t[s, a] if a is not None else t[s - 1, 19]
+            if ta > 0 and t[s, b] > 0:
+                vals.append(float(t[s, b] - ta))
+        mean = sum(vals) / max(len(vals), 1)
+        tot += mean
+        print(f"   {label:88s} {mean:6.2f}")
+    print(f"   {'sum = one decoder step':88s} {tot:6.2f}")
+    raw = allw[:1024].view(32, 32)
+    print("   poll passes per sweep (logits, head x, q|k|v [3 layers], partials [4 layers]):",
+          [round(float(raw[3:29, 24 + i].mean()) / 6, 2) for i in range(4)], "(per step; 3 q|k|v and 4 partials sweeps per step)")
+    pub = allw[1024:1024 + 2048].view(256, 8) * 0.01; rdy = allw[3072:3072 + 256] * 0.01; fxa = allw[3328:3328 + 256] * 0.01
+    t0 = float(fxa[fxa > 0].min())
+    print(f"   step 5, head phase over all 256 workgroups (us after the first 'x of head ready'): x ready {float(fxa.min()) - t0:.2f}..{float(fxa.max()) - t0:.2f}")
+    for w in range(2, 7):
+        col = pub[:, w][pub[:, w] > 0]
+        if col.numel():
+            print(f"      wave {w} published: {float(col.min()) - t0:.2f} .. {float(col.max()) - t0:.2f} (slowest CU {int(pub[:, w].argmax())}, {col.numel()} producers)")
+    print(f"      logits in LDS: {float(rdy.min()) - t0:.2f} .. {float(rdy.max()) - t0:.2f}")
+    whole = float(t[n_steps - 2, 19] - t[2, 19]) / (n_steps - 4)
+    print(f"   step period measured directly: {whole:.2f} us")
+
+
+if __name__ == "__main__":
+    main()
