@@ -1154,13 +1154,13 @@ extern "C" double csm_bytes_per_frame(csm_handle m, int B, double p_mean) {
 extern "C" int csm_debug_persist_stamps(csm_handle m, uint64_t* host, int n_words) {
     if (!m || !m->persist) return CSM_E_STATE;
     if (!m->p_stamps) {
-        HIPCHK(m, hipMalloc((void**)&m->p_stamps, (32 * 32 + 4096) * 8));
-        HIPCHK(m, hipMemset(m->p_stamps, 0, (32 * 32 + 4096) * 8));
+        HIPCHK(m, hipMalloc((void**)&m->p_stamps, (32 * 32 + 4096 + 256) * 8));
+        HIPCHK(m, hipMemset(m->p_stamps, 0, (32 * 32 + 4096 + 256) * 8));
         if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }      // re-capture with the stamp pointer
     }
     if (host) {
         HIPCHK(m, hipDeviceSynchronize());
-        HIPCHK(m, hipMemcpy(host, m->p_stamps, (size_t)(n_words < 32 * 32 + 4096 ? n_words : 32 * 32 + 4096) * 8, hipMemcpyDeviceToHost));
+        HIPCHK(m, hipMemcpy(host, m->p_stamps, (size_t)(n_words < 32 * 32 + 4096 + 256 ? n_words : 32 * 32 + 4096 + 256) * 8, hipMemcpyDeviceToHost));
     }
     return CSM_OK;
 }

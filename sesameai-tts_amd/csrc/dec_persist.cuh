@@ -413,7 +413,10 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                         if (IS_A) { if (k < 4) load_ws(l + 1 < DP_NL ? l + 1 : DP_NL, cb, k); else load_cd(l, NCD / 3 + k - 4); }
                         else load_cd(l, k);
                     })) return;
+                const bool st5 = a.stamps != nullptr && cu == 100 && lane == 0 && wave == 5 && l == 2;
+                if (st5) a.stamps[4096 + s * 8 + 0] = __builtin_amdgcn_s_memrealtime();
                 dp_attention_wave(lds, wave, l, cb, lane);
+                if (st5) a.stamps[4096 + s * 8 + 1] = __builtin_amdgcn_s_memrealtime();
             }
             if (IS_B) {
                 // -- o-projection unit + residual, once the four attention waves are done
@@ -427,6 +430,7 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                 const uint32_t outw = dp_resid_pair(a0, a1, h0w);
                 if (lane == 0) misc[DP_M_H1 + (wave - 5)] = outw;
                 if (lane < DP_NREP) dp_gran_store(a.gH1 + lane * 512 + unit, dp_tag(base, s, l, DP_E_H1), outw);
+                if (a.stamps != nullptr && cu == 100 && lane == 0 && wave == 5 && l == 2) a.stamps[4096 + s * 8 + 2] = __builtin_amdgcn_s_memrealtime();
             }
             {
                 // -- the MLP: my (gate, up) pairs -> h values -> LDS -> my row blocks of the split down projection
@@ -436,6 +440,8 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                         else if (IS_A) load_cd(l, 2 * (NCD / 3) + k);
                         else { if (k < 4) load_ws(l + 1 < DP_NL ? l + 1 : DP_NL, cb, k); else load_cd(l, NCD / 2 + k - 4); }
                     })) return;
+                const bool st0 = a.stamps != nullptr && cu == 100 && lane == 0 && wave == 0 && l == 2;
+                if (st0) a.stamps[4096 + s * 8 + 3] = __builtin_amdgcn_s_memrealtime();
                 const dp_lu4* xs = (const dp_lu4*)(lds + DP_OFF_XC);
                 const uint4 x0 = dp_ldq(xs + lane), x1 = dp_ldq(xs + 64 + lane);
 #pragma unroll
@@ -454,6 +460,7 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                         if ((spins & 255u) == 0 && dp_give_up(t0, ab, a.err, 0x950u, lane)) return;
                     asm volatile("" ::: "memory");
                 }
+                if (st0) a.stamps[4096 + s * 8 + 4] = __builtin_amdgcn_s_memrealtime();
                 uint4 h[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) h[q] = dp_ldq((const dp_lu4*)(misc + DP_M_HL) + q);
@@ -463,6 +470,7 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                     const float p = dp_down_partial(wd[b], h);
                     dp_gran_store(a.gP + ((long)(n >> 2) * 256 + cu) * 4 + (n & 3), dp_tag(base, s, l, DP_E_P), __float_as_uint(p));
                 }
+                if (st0) a.stamps[4096 + s * 8 + 5] = __builtin_amdgcn_s_memrealtime();
             }
         }
         // ---- the head of codebook cb: waves 2..6 hold 2 logit rows each (ws slot 4), x = dec_norm(h)

@@ -27,8 +27,8 @@ def main():
     assert _abi.lib.csm_debug_persist_stamps(m._h, None, 0) == 0, "this handle does not run the persistent launch"
     for _ in range(6):
         m.step(1, 0.9, 50)
-    buf = (C.c_uint64 * (32 * 32 + 4096))()
-    assert _abi.lib.csm_debug_persist_stamps(m._h, buf, 32 * 32 + 4096) == 0
+    buf = (C.c_uint64 * (32 * 32 + 4096 + 256))()
+    assert _abi.lib.csm_debug_persist_stamps(m._h, buf, 32 * 32 + 4096 + 256) == 0
     allw = torch.tensor(list(buf), dtype=torch.float64)
     t = allw[:1024].view(32, 32) * 0.01          # us
     n_steps = 30
@@ -71,6 +71,19 @@ def main():
         if col.numel():
             print(f"      wave {w} published: {float(col.min()) - t0:.2f} .. {float(col.max()) - t0:.2f} (slowest CU {int(pub[:, w].argmax())}, {col.numel()} producers)")
     print(f"      logits in LDS: {float(rdy.min()) - t0:.2f} .. {float(rdy.max()) - t0:.2f}")
+    ex = allw[4096:4096 + 256].view(32, 8) * 0.01
+    def mean_d(a_, b_, ref=None):
+        vals = [float(ex[s_, b_] - (ex[s_, a_] if ref is None else ref[s_])) for s_ in range(3, 29) if ex[s_, b_] > 0]
+        return sum(vals) / max(len(vals), 1)
+    print("   layer 2 detail:")
+    print(f"      q/k/v in LDS -> wave 5 starts its attention head      {mean_d(0, 0, t[:, 2 * 4 + 1]):6.2f}")
+    print(f"      wave 5: attention head                                 {mean_d(0, 1):6.2f}")
+    print(f"      wave 5: attention done -> o-proj rows published        {mean_d(1, 2):6.2f}")
+    print(f"      o-proj published -> x of MLP ready (edge + mlp_norm)   {float(sum(float(t[s_, 2 * 4 + 2] - ex[s_, 2]) for s_ in range(3, 29)) / 26):6.2f}")
+    print(f"      x of MLP ready -> wave 0 starts gate/up                {mean_d(3, 3, t[:, 2 * 4 + 2]):6.2f}")
+    print(f"      wave 0: 6 (gate, up) pairs + h exchange                {mean_d(3, 4):6.2f}")
+    print(f"      wave 0: 3 row blocks of the down partial, published    {mean_d(4, 5):6.2f}")
+    print(f"      partials published -> rows published (edge + sum)      {float(sum(float(t[s_, 2 * 4 + 3] - ex[s_, 5]) for s_ in range(3, 29)) / 26):6.2f}")
     whole = float(t[n_steps - 2, 19] - t[2, 19]) / (n_steps - 4)
     print(f"   step period measured directly: {whole:.2f} us")
 
