@@ -78,6 +78,7 @@ struct CsmModel {
     dp_u64 *pg_q, *pg_h1, *pg_h2, *pg_l, *pg_p;
     uint32_t* p_state;                  // [0] tag epoch, [1] give-up code of the last launch (0 = ok)
     uint4* p_w2s[DP_NL];
+    uint4* p_w13p[DP_NL];
     int p_trickle, p_poll;
     dp_u64* p_stamps;                   // debug timeline (csm_debug_persist_stamps), else nullptr
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
@@ -579,7 +580,7 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             // q / k / v and the decoder caches of positions 0, 1 where the kernel picks them up)
             DecPersistArgs p;
             memset(&p, 0, sizeof p);
-            for (int l = 0; l < DP_NL; ++l) { p.lw[l] = m->dec.lw[l]; p.w2s[l] = m->p_w2s[l]; }
+            for (int l = 0; l < DP_NL; ++l) { p.lw[l] = m->dec.lw[l]; p.w2s[l] = m->p_w2s[l]; p.w13p[l] = m->p_w13p[l]; }
             p.dec_norm = (const bf16_t*)m->w.dec_norm; p.head_t = (const bf16_t*)m->w.audio_head_t; p.rope = m->dec.rope;
             p.proj_emb = m->proj_emb; p.qkv0_tab = m->qkv0_tab; p.hdec = m->hdec; p.qd = m->qd;
             p.kc = m->dec.kc; p.vc = m->dec.vc; p.kv_layer_stride = m->dec.layer_stride;
@@ -972,6 +973,9 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
             for (int l = 0; l < DP_NL; ++l) {
                 HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_w2s[l], (size_t)DP_D * DP_FFN * 2));
                 hipLaunchKernelGGL(k_dp_retile_w2, dim3(4096), dim3(256), 0, nullptr, (const bf16_t*)m->w.dec[l].w2, m->p_w2s[l]);
+                HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_w13p[l], (size_t)2 * DP_D * DP_FFN * 2));
+                hipLaunchKernelGGL(k_dp_pack_gateup, dim3(256 * 4 * 32 * 64 / 256), dim3(256), 0, nullptr, (const bf16_t*)m->w.dec[l].w1,
+                                   (const bf16_t*)m->w.dec[l].w3, m->p_w13p[l]);
             }
             HIPCHK((CsmModel*)nullptr, hipGetLastError());
             HIPCHK((CsmModel*)nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_persist),
@@ -998,7 +1002,8 @@ extern "C" void csm_destroy(csm_handle m) {
     for (void* p : ptrs) (void)hipFree(p);
     for (void* p : m->pk_allocs) (void)hipFree(p);
     if (m->persist) {
-        void* pp[] = {m->pg_q, m->pg_h1, m->pg_h2, m->pg_l, m->pg_p, m->p_state, m->p_w2s[0], m->p_w2s[1], m->p_w2s[2], m->p_w2s[3]};
+        void* pp[] = {m->pg_q, m->pg_h1, m->pg_h2, m->pg_l, m->pg_p, m->p_state, m->p_w2s[0], m->p_w2s[1], m->p_w2s[2], m->p_w2s[3],
+                      m->p_w13p[0], m->p_w13p[1], m->p_w13p[2], m->p_w13p[3]};
         for (void* p : pp) (void)hipFree(p);
     }
     delete m;

@@ -13,16 +13,19 @@
 //               order, adds the residual and publishes them; after sampling it fetches the next step's table rows.
 //   waves 0..6  "compute": fixed weight rows per wave; the loads of a wave's next use are issued ONE 1 KB wave load at
 //               a time between polls of the LDS flag the wave waits on anyway (static order -> exact vmcnt(N) waits).
-//               waves 0,1: 6 (gate, up) pairs + 3 row blocks of the split down projection
-//               waves 2-4: one q|k|v unit (2 rows, RoPE) + 4 pairs + 2 row blocks + one head unit
-//               waves 5,6: one o-proj unit (2 rows, + residual) + 4 pairs + 2 row blocks + head unit (5) / tail rows (6)
-//               waves 2-5 ("quad"): attention over the LDS-resident K/V (2 heads each) and the sampler.
+//               waves 0-3: one 16-row tile of the gate/up projection (8 (gate, up) pairs on v_mfma_f32_16x16x32_bf16,
+//                          weights pre-packed in operand order) + 2 row blocks of the split down projection
+//               waves 4-6: 3 / 3 / 2 row blocks of the split down projection
+//               waves 2-4: + one q|k|v unit (2 rows, RoPE) + one head unit
+//               waves 5,6: + one o-proj unit (2 rows, + residual) + head unit (5) / tail rows (6)
+//               all 8 waves: one attention head each over the LDS-resident K/V;  waves 4-7 ("quad"): the sampler.
 //
 // Arithmetic: every dot product, RoPE, attention, RMSNorm, residual and the sampler use the chain path's code or its
 // exact lane/k mapping (k_gemv, stage_attn, stage_x, sample_body), so those values are bit-identical to the launch
-// chain.  ONE thing differs: the down projection is split over the 256 workgroups' 32-column slices (its input never
-// leaves the CU that produced it) and summed by the row owner in a fixed order -- deterministic, but a different fp32
-// summation order than one wave per row.  Every spin is bounded (s_memrealtime); on a timeout the kernel sets *err and
+// chain.  TWO things differ, both only in fp32 summation order: the gate/up dot products run on the matrix cores
+// (16 rows x 32 k per instruction instead of a lane-strided dot2 chain), and the down projection is split over the
+// 256 workgroups' 32-column slices (its input never leaves the CU that produced it) and summed by the row owner in a
+// fixed order.  Deterministic; bf16 rounding points unchanged.  Every spin is bounded (s_memrealtime); on a timeout the kernel sets *err and
 // leaves, and csm_read_frames reports it.
 #pragma once
 #include "gemv.cuh"
@@ -50,6 +53,7 @@ __device__ __forceinline__ void dp_stq(dp_lu4* p, const uint4& v) { u32x4_t t; t
 struct DecPersistArgs {
     CsmLayerWeights lw[DP_NL];
     const uint4* w2s[DP_NL];          // W2 re-tiled [256 cu][4 k chunks][1024 rows] 16-byte pieces (k_dp_retile_w2)
+    const uint4* w13p[DP_NL];         // W1 | W3 in matrix-core operand order [256 cu][4 tiles][32 k steps][64 lanes] (k_dp_pack_gateup)
     const bf16_t* dec_norm;
     const bf16_t* head_t;             // [ncb-1][V][1024]
     const bf16_t* rope;               // [max_seq][64][2]
@@ -88,7 +92,7 @@ struct DecPersistArgs {
 #define DP_OFF_SMAX (DP_OFF_LOGITS + 5120)           // 256 u32
 #define DP_OFF_PS (DP_OFF_SMAX + 1024)               // attention P rows: 8 waves x 32 floats
 #define DP_OFF_MISC (DP_OFF_PS + 1024)
-#define DP_LDS_BYTES (DP_OFF_MISC + 256)
+#define DP_LDS_BYTES (DP_OFF_MISC + 512)
 // misc words
 #define DP_M_HL 0        // 16 words: this CU's 32 h values
 #define DP_M_H0 16       // 2 words: residual rows 4cu..4cu+3 entering the layer
@@ -108,6 +112,7 @@ struct DecPersistArgs {
 #define DP_M_SN 40
 #define DP_M_STOK 41
 #define DP_M_SWTOT 42
+#define DP_M_TILE 48     // 4 tiles x 16 floats: the gate | up sums of a tile on their way to the SwiGLU lanes
 
 enum { DP_E_Q = 0, DP_E_H1 = 1, DP_E_P = 2, DP_E_H2 = 3, DP_E_L = 4 };
 __device__ __forceinline__ uint32_t dp_tag(uint32_t base, int s, int l, int e) { return base + 1u + (uint32_t)((s * DP_NL + l) * 5 + e); }
@@ -206,8 +211,7 @@ __device__ __forceinline__ uint4 dp_chunk_norm(const uint4& v, const uint4& g, f
     o.w = pack_bf(round_bf(lo2f(v.w) * r) * lo2f(g.w), round_bf(hi2f(v.w) * r) * hi2f(g.w));
     return o;
 }
-__device__ __forceinline__ void dp_norm_in_lds(dp_lu4* xs, const bf16_t* scale, float eps, int lane) {
-    const uint4 g0 = reinterpret_cast<const uint4*>(scale)[lane], g1 = reinterpret_cast<const uint4*>(scale)[64 + lane];
+__device__ __forceinline__ void dp_norm_in_lds(dp_lu4* xs, const uint4& g0, const uint4& g1, float eps, int lane) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const uint4 v0 = dp_ldq(xs + lane), v1 = dp_ldq(xs + 64 + lane);
     const float s0 = wave_sum(dp_chunk_ss(v0)), s1 = wave_sum(dp_chunk_ss(v1));
@@ -262,42 +266,44 @@ __device__ __forceinline__ void dp_reduce_partials(const uint32_t (&v)[16], floa
 // 4i + l/16 (i = 0..7) at element offset 8 (l % 16).  Eight waves take one head each.
 __device__ __forceinline__ void dp_attention_head(const dp_lu4* qb, const dp_lu4* kt, const dp_lu32* vt, dp_lf32* myps, dp_lu32* att,
                                                   int h, int nk, float ascale, int lane) {
+    // stage_attn skips whole 4-key groups beyond nk by uniform branches; here every group is walked (its LDS reads and
+    // DPP chains then overlap instead of running one group after the other) and dead keys contribute exact zeros:
+    // score -inf -> p = 0, v read as 0 -> "+ 0.0" leaves every running sum's bits unchanged.
     const int grp = lane >> 4, sub = lane & 15;
     const uint4 qa = dp_ldq(qb + h * 16 + sub);
+    uint4 kv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kv[i] = dp_ldq(kt + i * 64 + lane);
     float s0[8], mx0 = -INFINITY;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        s0[i] = -INFINITY;
-        if (4 * i < nk) {
-            const uint4 kv = dp_ldq(kt + i * 64 + lane);
-            const bool live = (4 * i + grp) < nk;
-            const float d0 = row16_sum(dot8(qa, kv, 0.f)) * ascale;
-            s0[i] = live ? d0 : -INFINITY;
-            mx0 = fmaxf(mx0, s0[i]);
-        }
+        const bool live = (4 * i + grp) < nk;
+        const float d0 = row16_sum(dot8(qa, kv[i], 0.f)) * ascale;
+        s0[i] = live ? d0 : -INFINITY;
+        mx0 = fmaxf(mx0, s0[i]);
     }
     mx0 = wave_max(mx0);
     float l0 = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        if (4 * i < nk) {
-            s0[i] = (s0[i] == -INFINITY) ? 0.f : __expf(s0[i] - mx0);
-            l0 += s0[i];
-            if (sub == 0) myps[4 * i + grp] = s0[i];
-        }
+        s0[i] = (s0[i] == -INFINITY) ? 0.f : __expf(s0[i] - mx0);
+        l0 += s0[i];
+        if (sub == 0) myps[4 * i + grp] = s0[i];
     }
     l0 = wave_sum(l0) * (1.0f / 16.0f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float o00 = 0.f, o01 = 0.f;
 #pragma unroll
-    for (int t4 = 0; t4 < 8; ++t4) {
-        if (4 * t4 < nk) {
-            const float pav[4] = {myps[4 * t4], myps[4 * t4 + 1], myps[4 * t4 + 2], myps[4 * t4 + 3]};
+    for (int t4 = 0; t4 < 8; ++t4) {                         // 4 keys at a time: one broadcast read of their p, four reads of their v
+        const u32x4_t p4 = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>(myps + 4 * t4);
+        const float pw[4] = {__uint_as_float(p4.x), __uint_as_float(p4.y), __uint_as_float(p4.z), __uint_as_float(p4.w)};
+        uint32_t vr[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t raw = (4 * t4 + u) < nk ? vt[(4 * t4 + u) * 64 + lane] : 0u;
-                o00 += pav[u] * lo2f(raw); o01 += pav[u] * hi2f(raw);
-            }
+        for (int u = 0; u < 4; ++u) vr[u] = vt[(4 * t4 + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t raw = (4 * t4 + u) < nk ? vr[u] : 0u;
+            o00 += pw[u] * lo2f(raw); o01 += pw[u] * hi2f(raw);
         }
     }
     const float i0 = 1.0f / l0;
@@ -334,21 +340,52 @@ struct DpQuadSync {
 // compute wave.  Roles: X = waves 0,1;  A = waves 2,3,4 (q|k|v unit; 2,3,4 are in the quad);  B = waves 5,6 (o-proj
 // unit; 5 is in the quad).
 // ---------------------------------------------------------------------------------------------------------------
-template <bool IS_X, bool IS_A, bool IN_QUAD>
+// one sampling step by the 4 waves of the quad (qw = 0..3): sample_body on the logits in LDS; returns the code
+__device__ __forceinline__ int dp_sample_step(const DecPersistArgs& a, char* lds, int qw, int lane, int cu, int cb, int s, uint32_t* quad_phase) {
+    dp_lu32* misc = (dp_lu32*)(lds + DP_OFF_MISC);
+    dp_lvu32* ab = (dp_lvu32*)(misc + DP_M_ABORT);
+    const int tid = qw * 64 + lane;
+    if (a.stamps != nullptr && cu == 100 && tid == 0) a.stamps[s * 32 + 22] = __builtin_amdgcn_s_memrealtime();
+    const dp_lu4* lg = (const dp_lu4*)(lds + DP_OFF_LOGITS);
+    uint32_t w[2][4];
+    {
+        const uint4 v0 = dp_ldq(lg + tid);
+        w[0][0] = v0.x; w[0][1] = v0.y; w[0][2] = v0.z; w[0][3] = v0.w;
+        const uint4 v1 = tid < 64 ? dp_ldq(lg + 256 + tid) : make_uint4(0, 0, 0, 0);
+        w[1][0] = v1.x; w[1][1] = v1.y; w[1][2] = v1.z; w[1][3] = v1.w;
+    }
+    if (a.logits_out != nullptr && cu == 0) {
+        for (int i = tid; i < a.V; i += 256) a.logits_out[(long)cb * a.V + i] = ((const dp_lu16*)lg)[i];
+    }
+    SampleScratch sc;
+    sc.cand_t = (lds_f32_t*)(lds + DP_OFF_CANDT); sc.cand_i = (lds_i32_t*)(lds + DP_OFF_CANDI); sc.s_max = (lds_u32_t*)(lds + DP_OFF_SMAX);
+    sc.s_bv = (lds_f32_t*)(misc + DP_M_SBV); sc.s_bi = (lds_i32_t*)(misc + DP_M_SBI); sc.s_n = (lds_i32_t*)(misc + DP_M_SN);
+    sc.s_tok = (lds_i32_t*)(misc + DP_M_STOK); sc.s_wtot = (lds_i32_t*)(misc + DP_M_SWTOT);
+    DpQuadSync sync{(dp_lvu32*)(misc + DP_M_BAR), ab, a.err, lane, quad_phase};
+    const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
+    const int tok = sample_body<2>(w, a.V, a.temperature, a.topk, a.noise ? a.noise + (long)cb * a.V : nullptr, seed, step, 0, cb, sc, tid, sync);
+    if (a.stamps != nullptr && cu == 100 && tid == 0) a.stamps[s * 32 + 23] = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && cu == 0) a.frame[cb] = tok;
+    return tok;
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 dp_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float dp_f32x4;
+template <bool IS_X, bool IS_A, bool IN_QUAD, bool HAS_TILE, int NBK>
 __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* lds, const int wave, const unsigned lane, const int cu, const uint32_t base) {
     constexpr bool IS_B = !IS_X && !IS_A;
-    constexpr int NP = IS_X ? 6 : 4, NBK = IS_X ? 3 : 2, NCD = NP * 4 + NBK * 4;
+    constexpr int NT = HAS_TILE ? 32 : 0, NCD = NT + NBK * 4;
     dp_lu32* misc = (dp_lu32*)(lds + DP_OFF_MISC);
     dp_lvu32* ab = (dp_lvu32*)(misc + DP_M_ABORT);
     const int ts = a.trickle_sleep & 63;
     const int unit = IS_A ? cu * 3 + (wave - 2) : cu * 2 + (wave - 5);            // q|k|v unit (768) or o-proj unit (512)
-    const int hoff = IS_X ? wave * 6 : 12 + (wave - 2) * 4;
-    const int hbase = cu * 32 + hoff;
+    // row blocks (64 rows) of the split down projection: waves 0-3 own {w, w + 4}; 4: {8, 11, 14}; 5: {9, 12, 15}; 6: {10, 13}
+    auto my_block = [&](int b) { return wave < 4 ? wave + 4 * b : (wave + 4) + 3 * b; };
     // head rows of this wave: waves 2..5 own unit cu*4 + (wave - 2); wave 6 of CU 0 / 1 owns the tail units 1024 / 1025
     const int hunit = IS_X ? -1 : (wave < 6 ? cu * 4 + (wave - 2) : (cu < 2 ? 1024 + cu : -1));
     const int hrow0 = hunit < 0 ? 0 : 2 * hunit, hrow1 = hunit < 0 ? 0 : min(2 * hunit + 1, a.V - 1);
     uint4 ws[2][2];
-    uint4 wc[NP][2][2];
+    uint4 wt[HAS_TILE ? 32 : 1];
     uint4 wd[NBK][4];
 
     // rows of the small op slot `slot`: 0..3 = this wave's layer op, 4 = the head of codebook step cb
@@ -365,12 +402,10 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
         ws[k >> 1][k & 1] = reinterpret_cast<const uint4*>(r)[(k & 1) * 64 + lane];
     };
     auto load_cd = [&](int l, int k) {
-        if (k < NP * 4) {
-            const bf16_t* r = (const bf16_t*)((k >> 1) & 1 ? a.lw[l].w3 : a.lw[l].w1) + (long)(hbase + (k >> 2)) * DP_D;
-            wc[k >> 2][(k >> 1) & 1][k & 1] = reinterpret_cast<const uint4*>(r)[(k & 1) * 64 + lane];
-        } else {
-            const int kk = k - NP * 4;
-            wd[kk >> 2][kk & 3] = a.w2s[l][((long)cu * 4 + (kk & 3)) * 1024 + (wave + 7 * (kk >> 2)) * 64 + lane];
+        if (k < NT) wt[HAS_TILE ? k : 0] = a.w13p[l][(((long)cu * 4 + wave) * 32 + k) * 64 + lane];
+        else {
+            const int kk = k - NT;
+            wd[kk >> 2][kk & 3] = a.w2s[l][((long)cu * 4 + (kk & 3)) * 1024 + my_block(kk >> 2) * 64 + lane];
         }
     };
     if (!IS_X) {
@@ -442,14 +477,47 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                     })) return;
                 const bool st0 = a.stamps != nullptr && cu == 100 && lane == 0 && wave == 0 && l == 2;
                 if (st0) a.stamps[4096 + s * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-                const dp_lu4* xs = (const dp_lu4*)(lds + DP_OFF_XC);
-                const uint4 x0 = dp_ldq(xs + lane), x1 = dp_ldq(xs + 64 + lane);
+                if (HAS_TILE) {
+                    // tile `wave`: rows 0..7 = gate rows of pairs 8 wave .. 8 wave + 7, rows 8..15 = their up rows; k step t covers
+                    // k = 32t .. 32t+31: lane l feeds A[row l & 15][8 (l >> 4) + j] and, as every column of B, x[32t + 8 (l >> 4) + j]
+                    const dp_lu4* xs = (const dp_lu4*)(lds + DP_OFF_XC);
+                    dp_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    // x fragments four k steps at a time, the next four in flight behind the current four's matrix ops
+                    // (one ds_read + wait per step would expose the LDS latency 32 times)
+                    const dp_lu4* xq = xs + (lane >> 4);
+                    uint4 xa[4], xb[4];
 #pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    float ag = dot8(wc[j][0][0], x0, 0.f); ag = dot8(wc[j][0][1], x1, ag);
-                    float au = dot8(wc[j][1][0], x0, 0.f); au = dot8(wc[j][1][1], x1, au);
-                    const uint32_t hv = dp_swiglu(wave_sum(ag), wave_sum(au));
-                    if (lane == 0) ((dp_lu16*)(misc + DP_M_HL))[hoff + j] = (unsigned short)hv;
+                    for (int u = 0; u < 4; ++u) xa[u] = dp_ldq(xq + 4 * u);
+#pragma unroll
+                    for (int tb = 0; tb < 8; tb += 2) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) xb[u] = dp_ldq(xq + 4 * (4 * (tb + 1) + u));
+                        __builtin_amdgcn_sched_barrier(0);            // keep the four reads ahead of the four matrix ops
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dp_bf16x8, wt[HAS_TILE ? 4 * tb + u : 0]), __builtin_bit_cast(dp_bf16x8, xa[u]), acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (tb + 2 < 8) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) xa[u] = dp_ldq(xq + 4 * (4 * (tb + 2) + u));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dp_bf16x8, wt[HAS_TILE ? 4 * (tb + 1) + u : 0]), __builtin_bit_cast(dp_bf16x8, xb[u]), acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // every column equals column 0: lane l holds rows 4 (l >> 4) .. + 3 -> LDS -> lane i < 8 pairs gate i with up i
+                    dp_lf32* tile = (dp_lf32*)(misc + DP_M_TILE) + wave * 16;
+                    if ((lane & 15) == 0) {
+                        tile[(lane >> 4) * 4 + 0] = acc[0]; tile[(lane >> 4) * 4 + 1] = acc[1];
+                        tile[(lane >> 4) * 4 + 2] = acc[2]; tile[(lane >> 4) * 4 + 3] = acc[3];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane < 8) {
+                        const uint32_t hv = dp_swiglu(tile[lane], tile[8 + lane]);
+                        ((dp_lu16*)(misc + DP_M_HL))[wave * 8 + lane] = (unsigned short)hv;
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_fetch_add(misc + DP_M_CD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -466,7 +534,7 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                 for (int q = 0; q < 4; ++q) h[q] = dp_ldq((const dp_lu4*)(misc + DP_M_HL) + q);
 #pragma unroll
                 for (int b = 0; b < NBK; ++b) {
-                    const int n = (wave + 7 * b) * 64 + lane;
+                    const int n = my_block(b) * 64 + lane;
                     const float p = dp_down_partial(wd[b], h);
                     dp_gran_store(a.gP + ((long)(n >> 2) * 256 + cu) * 4 + (n & 3), dp_tag(base, s, l, DP_E_P), __float_as_uint(p));
                 }
@@ -495,36 +563,11 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                 for (int k = 0; k < 4; ++k) load_ws(0, cb, k);
             }
         }
-        // ---- the sampler (quad), on every CU alike: each CU needs the code to fetch its table rows
+        // ---- the sampler (waves 4, 5, 6 and the gather wave), on every CU alike: each CU needs the code for its table rows
         if (IN_QUAD) {
             if (!dp_wait<1, false>((dp_lvu32*)(misc + DP_M_FLG), dp_tag(base, s, DP_NL - 1, DP_E_L), ab, a.err, 0x970u, lane, ts, [&](int) {})) return;
-            const int tid = (wave - 2) * 64 + (int)lane;
-            if (a.stamps != nullptr && cu == 100 && tid == 0) a.stamps[s * 32 + 22] = __builtin_amdgcn_s_memrealtime();
-            const dp_lu4* lg = (const dp_lu4*)(lds + DP_OFF_LOGITS);
-            uint32_t w[2][4];
-            {
-                const uint4 v0 = dp_ldq(lg + tid);
-                w[0][0] = v0.x; w[0][1] = v0.y; w[0][2] = v0.z; w[0][3] = v0.w;
-                const uint4 v1 = tid < 64 ? dp_ldq(lg + 256 + tid) : make_uint4(0, 0, 0, 0);
-                w[1][0] = v1.x; w[1][1] = v1.y; w[1][2] = v1.z; w[1][3] = v1.w;
-            }
-            if (a.logits_out != nullptr && cu == 0) {
-                for (int i = tid; i < a.V; i += 256) a.logits_out[(long)cb * a.V + i] = ((const dp_lu16*)lg)[i];
-            }
-            SampleScratch sc;
-            sc.cand_t = (lds_f32_t*)(lds + DP_OFF_CANDT); sc.cand_i = (lds_i32_t*)(lds + DP_OFF_CANDI); sc.s_max = (lds_u32_t*)(lds + DP_OFF_SMAX);
-            sc.s_bv = (lds_f32_t*)(misc + DP_M_SBV); sc.s_bi = (lds_i32_t*)(misc + DP_M_SBI); sc.s_n = (lds_i32_t*)(misc + DP_M_SN);
-            sc.s_tok = (lds_i32_t*)(misc + DP_M_STOK); sc.s_wtot = (lds_i32_t*)(misc + DP_M_SWTOT);
-            DpQuadSync sync{(dp_lvu32*)(misc + DP_M_BAR), ab, a.err, (int)lane, &quad_phase};
-            const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
-            const int tok = sample_body<2>(w, a.V, a.temperature, a.topk, a.noise ? a.noise + (long)cb * a.V : nullptr, seed, step, 0, cb, sc, tid, sync);
+            (void)dp_sample_step(a, lds, wave - 4, (int)lane, cu, cb, s, &quad_phase);
             if (*ab) return;
-            if (a.stamps != nullptr && cu == 100 && tid == 0) a.stamps[s * 32 + 23] = __builtin_amdgcn_s_memrealtime();
-            if (tid == 0) {
-                if (cu == 0) a.frame[cb] = tok;
-                misc[DP_M_TOK] = (uint32_t)tok;
-                dp_flag((dp_lvu32*)(misc + DP_M_FTOK), dp_tag(base, s, DP_NL - 1, DP_E_L));
-            }
         }
     }
 }
@@ -536,7 +579,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
     dp_lu32* misc = (dp_lu32*)(lds + DP_OFF_MISC);
     dp_lvu32* ab = (dp_lvu32*)(misc + DP_M_ABORT);
     // ---- LDS image of the step's starting state (all 512 threads) ----
-    for (int i = threadIdx.x; i < 64; i += 512) misc[i] = 0;
+    for (int i = threadIdx.x; i < 128; i += 512) misc[i] = 0;
     for (int i = threadIdx.x; i < 2560 / 2; i += 512) ((dp_lu32*)(lds + DP_OFF_LOGITS))[i] = 0;
     {   // K/V rows of positions 0..cb_first (rows the chain has not written hold stale bits; they are overwritten before use)
         const int npos = a.cb_first + 1;
@@ -557,6 +600,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
         const dp_u64 *rgQ = a.gQ + rep * 768, *rgH1 = a.gH1 + rep * 512, *rgH2 = a.gH2 + rep * 512, *rgL = a.gL + rep * DP_LSLOTS;
         const dp_u64* rgP = a.gP + (long)cu * 1024;
         const int n_steps = a.cb_last - a.cb_first + 1;
+        uint32_t quad_phase = 0;
         dp_flag((dp_lvu32*)(misc + DP_M_FQ), dp_tag(base, 0, 0, DP_E_Q));          // layer 0's q / k / v of the first step are in place
         const bool st = a.stamps != nullptr && cu == 100 && lane == 0;
 #define DP_STAMP(s_, i_) do { if (st) a.stamps[(s_) * 32 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -566,10 +610,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
                 if (l > 0) {
                     {   // rows of the previous layer -> sa_norm -> xA
                         uint32_t v[8];
+                        const uint4 g0 = reinterpret_cast<const uint4*>(a.lw[l].sa_norm)[ln], g1 = reinterpret_cast<const uint4*>(a.lw[l].sa_norm)[64 + ln];
                         if (!dp_sweep<4>(rgH2, 512, dp_tag(base, s, l - 1, DP_E_H2), v, ln, ab, a.err, 0x100u + l, a.poll_sleep)) return;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { ((dp_lu32*)(lds + DP_OFF_XA))[2 * (j * 64 + ln)] = v[2 * j]; ((dp_lu32*)(lds + DP_OFF_XA))[2 * (j * 64 + ln) + 1] = v[2 * j + 1]; }
-                        dp_norm_in_lds((dp_lu4*)(lds + DP_OFF_XA), (const bf16_t*)a.lw[l].sa_norm, a.eps, ln);
+                        dp_norm_in_lds((dp_lu4*)(lds + DP_OFF_XA), g0, g1, a.eps, ln);
                         dp_flag((dp_lvu32*)(misc + DP_M_FXA), dp_tag(base, s, l - 1, DP_E_H2));
                         DP_STAMP(s, l * 4 + 0);
                     }
@@ -591,10 +636,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
                 dp_attention_wave(lds, 7, l, cb, ln);              // (layer 0: q / k / v were placed by the table fetch)
                 {   // rows after the o-projection -> mlp_norm -> xC
                     uint32_t v[8];
+                    const uint4 g0 = reinterpret_cast<const uint4*>(a.lw[l].mlp_norm)[ln], g1 = reinterpret_cast<const uint4*>(a.lw[l].mlp_norm)[64 + ln];
                     if (!dp_sweep<4>(rgH1, 512, dp_tag(base, s, l, DP_E_H1), v, ln, ab, a.err, 0x300u + l, a.poll_sleep)) return;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { ((dp_lu32*)(lds + DP_OFF_XC))[2 * (j * 64 + ln)] = v[2 * j]; ((dp_lu32*)(lds + DP_OFF_XC))[2 * (j * 64 + ln) + 1] = v[2 * j + 1]; }
-                    dp_norm_in_lds((dp_lu4*)(lds + DP_OFF_XC), (const bf16_t*)a.lw[l].mlp_norm, a.eps, ln);
+                    dp_norm_in_lds((dp_lu4*)(lds + DP_OFF_XC), g0, g1, a.eps, ln);
                     dp_flag((dp_lvu32*)(misc + DP_M_FXC), dp_tag(base, s, l, DP_E_H1));
                     DP_STAMP(s, l * 4 + 2);
                 }
@@ -618,10 +664,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
             }
             {   // the stack's output rows -> final norm -> x of the head
                 uint32_t v[8];
+                const uint4 g0 = reinterpret_cast<const uint4*>(a.dec_norm)[ln], g1 = reinterpret_cast<const uint4*>(a.dec_norm)[64 + ln];
                 if (!dp_sweep<4>(rgH2, 512, dp_tag(base, s, DP_NL - 1, DP_E_H2), v, ln, ab, a.err, 0x500u, a.poll_sleep, st ? a.stamps + s * 32 + 25 : nullptr)) return;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { ((dp_lu32*)(lds + DP_OFF_XA))[2 * (j * 64 + ln)] = v[2 * j]; ((dp_lu32*)(lds + DP_OFF_XA))[2 * (j * 64 + ln) + 1] = v[2 * j + 1]; }
-                dp_norm_in_lds((dp_lu4*)(lds + DP_OFF_XA), a.dec_norm, a.eps, ln);
+                dp_norm_in_lds((dp_lu4*)(lds + DP_OFF_XA), g0, g1, a.eps, ln);
                 dp_flag((dp_lvu32*)(misc + DP_M_FXA), dp_tag(base, s, DP_NL - 1, DP_E_H2));
                 DP_STAMP(s, 16);
                 if (a.stamps != nullptr && s == 5 && lane == 0) a.stamps[1024 + 2048 + 256 + cu] = __builtin_amdgcn_s_memrealtime();
@@ -641,16 +688,13 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
                 DP_STAMP(s, 17);
                 if (a.stamps != nullptr && s == 5 && lane == 0) a.stamps[1024 + 2048 + cu] = __builtin_amdgcn_s_memrealtime();
             }
-            {   // the sampled code -> the next step's input row and layer-0 q / k / v (table rows), like k_sample's tail
-                const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
-                for (uint32_t spins = 1; *(dp_lvu32*)(misc + DP_M_FTOK) != dp_tag(base, s, DP_NL - 1, DP_E_L); ++spins) {
-                    if ((spins & 255u) == 0 && dp_give_up(t0, ab, a.err, 0x700u, ln)) return;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                asm volatile("" ::: "memory");
+            {   // sample with waves 4..6 (this wave is the quad's fourth), then the code -> the next step's input row and layer-0
+                // q / k / v (table rows), like k_sample's tail
+                const int tok = dp_sample_step(a, lds, 3, ln, cu, cb, s, &quad_phase);
+                if (*ab) return;
                 DP_STAMP(s, 18);
                 if (cb + 1 < a.ncb) {
-                    int fed = a.forced ? a.forced[cb] : (int)*(dp_lvu32*)(misc + DP_M_TOK);
+                    int fed = a.forced ? a.forced[cb] : tok;
                     fed = min(max(fed, 0), a.V - 1);
                     const uint32_t* hrow = reinterpret_cast<const uint32_t*>(a.proj_emb + ((long)cb * a.V + fed) * DP_D);
                     const uint32_t* qrow = reinterpret_cast<const uint32_t*>(a.qkv0_tab + ((long)(cb - 1) * a.V + fed) * DP_NQKV);
@@ -672,10 +716,22 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
         if (cu == 0 && lane == 0) __hip_atomic_store(a.epoch, base + (uint32_t)(n_steps * DP_NL * 5 + 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    if (wave < 2) dp_compute_wave<true, false, false>(a, lds, wave, lane, cu, base);
-    else if (wave < 5) dp_compute_wave<false, true, true>(a, lds, wave, lane, cu, base);
-    else if (wave == 5) dp_compute_wave<false, false, true>(a, lds, wave, lane, cu, base);
-    else dp_compute_wave<false, false, false>(a, lds, wave, lane, cu, base);
+    if (wave < 2) dp_compute_wave<true, false, false, true, 2>(a, lds, wave, lane, cu, base);
+    else if (wave < 4) dp_compute_wave<false, true, false, true, 2>(a, lds, wave, lane, cu, base);
+    else if (wave == 4) dp_compute_wave<false, true, true, false, 3>(a, lds, wave, lane, cu, base);
+    else if (wave == 5) dp_compute_wave<false, false, true, false, 3>(a, lds, wave, lane, cu, base);
+    else dp_compute_wave<false, false, true, false, 2>(a, lds, wave, lane, cu, base);
+}
+
+// W1, W3 [8192][1024] -> [256 cu][4 tiles][32 k steps][64 lanes] 16-byte operand pieces: tile q of workgroup cu holds the
+// gate rows (tile rows 0..7) and up rows (8..15) of pairs cu*32 + 8q .. + 7; lane l of step t: row l & 15, k = 32t + 8 (l >> 4)
+__global__ void k_dp_pack_gateup(const bf16_t* w1, const bf16_t* w3, uint4* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 256L * 4 * 32 * 64) return;
+    const int lane = (int)(i & 63), t = (int)((i >> 6) & 31), q = (int)((i >> 11) & 3), c = (int)(i >> 13);
+    const int r = lane & 15, pair = c * 32 + 8 * q + (r & 7);
+    const bf16_t* w = r < 8 ? w1 : w3;
+    out[i] = *reinterpret_cast<const uint4*>(w + (long)pair * DP_D + 32 * t + 8 * (lane >> 4));
 }
 
 // W2 [1024][8192] -> [256 cu][4 k chunks][1024 rows] 16-byte pieces (workgroup cu's 32 columns, 8 at a time)
