@@ -301,10 +301,7 @@ __device__ __forceinline__ void dp_attention_head(const dp_lu4* qb, const dp_lu4
 #pragma unroll
         for (int u = 0; u < 4; ++u) vr[u] = vt[(4 * t4 + u) * 64 + lane];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t raw = (4 * t4 + u) < nk ? vr[u] : 0u;
-            o00 += pw[u] * lo2f(raw); o01 += pw[u] * hi2f(raw);
-        }
+        for (int u = 0; u < 4; ++u) { o00 += pw[u] * lo2f(vr[u]); o01 += pw[u] * hi2f(vr[u]); }
     }
     const float i0 = 1.0f / l0;
     att[h * 64 + lane] = pack_bf(o00 * i0, o01 * i0);
@@ -581,7 +578,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
     // ---- LDS image of the step's starting state (all 512 threads) ----
     for (int i = threadIdx.x; i < 128; i += 512) misc[i] = 0;
     for (int i = threadIdx.x; i < 2560 / 2; i += 512) ((dp_lu32*)(lds + DP_OFF_LOGITS))[i] = 0;
-    {   // K/V rows of positions 0..cb_first (rows the chain has not written hold stale bits; they are overwritten before use)
+    // every K / V slot starts as zeros: slots past the current position are then finite, and a dead key's exact-zero
+    // probability times its (zero or stale-but-finite) value adds +0.0 -- no per-key select in the attention loop
+    for (int i = threadIdx.x; i < 131072 / 16; i += 512) dp_stq((dp_lu4*)lds + i, make_uint4(0, 0, 0, 0));
+    __syncthreads();
+    {   // K/V rows of positions 0..cb_first (rows of later positions are written before they are used)
         const int npos = a.cb_first + 1;
         for (int i = threadIdx.x; i < DP_NL * 2 * npos * 16; i += 512) {
             const int c = i & 15, pos = (i >> 4) % npos, lk = (i >> 4) / npos;           // lk = layer * 2 + kv head
@@ -596,6 +597,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
     const uint32_t base = *a.epoch;
     if (wave == 7) {
         // ------------------------------------------------------------------------------------------------ gather wave
+        __builtin_amdgcn_s_setprio(2);
         const int rep = cu % DP_NREP, ln = (int)lane;
         const dp_u64 *rgQ = a.gQ + rep * 768, *rgH1 = a.gH1 + rep * 512, *rgH2 = a.gH2 + rep * 512, *rgL = a.gL + rep * DP_LSLOTS;
         const dp_u64* rgP = a.gP + (long)cu * 1024;
