@@ -92,6 +92,15 @@ __device__ __forceinline__ int wave_min_i(int v) {
     v = min(v, dpp_i<0x143, 0xC>(v, v));
     return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ int wave_max_i(int v) {
+    v = max(v, dpp_i<0xB1, 0xF>(v, v));
+    v = max(v, dpp_i<0x4E, 0xF>(v, v));
+    v = max(v, dpp_i<0x141, 0xF>(v, v));
+    v = max(v, dpp_i<0x140, 0xF>(v, v));
+    v = max(v, dpp_i<0x142, 0xA>(v, v));
+    v = max(v, dpp_i<0x143, 0xC>(v, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 // exclusive prefix sum over the wave of a small non-negative count (< 2^BITS per lane), bit-sliced: one ballot and one
 // mbcnt per bit, no LDS round trips (a __shfl_up scan is six ds_bpermute)
 template <int BITS>

@@ -98,8 +98,9 @@ __device__ __forceinline__ uint32_t order_key(float t) {     // monotone map of 
     return (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
 }
 
-// k-th largest of a wave-distributed key list (each lane holds NC keys, 0 = empty slot):
-// the largest X with count(key >= X) >= k, by bisection on the 16 key bits with ballots.
+// k-th largest of a wave-distributed key list (each lane holds NC keys, 0 = empty slot): the largest X with
+// count(key >= X) >= k (0 if fewer than k keys), by bisection on the 16 key bits with ballots.  One wave runs this
+// dependent chain at ~4 ns per instruction and a step is 3 NC + 2 instructions, so callers keep NC as small as they can.
 template <int NC>
 __device__ __forceinline__ uint32_t kth_largest_key(const uint32_t (&key)[NC], int k) {
     uint32_t prefix = 0;
@@ -130,6 +131,7 @@ struct SampleScratch {
     lds_f32_t* cand_t;      // [V] (up to SAMPLE_MAX_ITERS * 512)
     lds_i32_t* cand_i;      // [V]
     lds_u32_t* s_max;       // [256], 16-byte aligned
+    lds_f32_t* cand_q;      // [256] Exp(1) draws of the first 256 candidates (may alias s_max: that is dead by then)
     lds_f32_t* s_bv;        // [4]
     lds_i32_t* s_bi;        // [4]
     lds_i32_t* s_n;         // [1]
@@ -137,16 +139,30 @@ struct SampleScratch {
     lds_i32_t* s_wtot;      // [4]
 };
 
+// q ~ Exp(1) of vocabulary index idx, rounded to bf16 (torch's exponential_ on a bf16 tensor): the caller's noise row, or
+// Philox keyed by (seed, step) at counter (idx, sequence, codebook)
+__device__ __forceinline__ float exp1_draw(int idx, const bf16_t* noise_row, uint64_t seed, uint64_t step, int b, int codebook) {
+    if (noise_row) return bf2f(noise_row[idx]);
+    const uint4 rnd = philox4x32(make_uint4((uint32_t)idx, (uint32_t)b, (uint32_t)codebook, (uint32_t)step),
+                                 make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32)));
+    const float u = ((float)rnd.x + 0.5f) * 2.3283064365386963e-10f;   // (0,1]
+    const float q = round_bf(-logf(u));
+    return q > 0.f ? q : 1e-30f;
+}
+
 // 4 waves (tid 0..255) sample ONE sequence.  Thread t owns logits [8t, 8t+8) (+ [2048+8t, ..) for V > 2048), handed
 // in as w[i][0..3] (packed bf16 pairs; zero beyond the row).  `sync` is the 4-wave barrier (k_sample: __syncthreads;
 // the persistent decoder: an LDS counter barrier).
-//  1. per-thread max of the RAW bf16 keys -> LDS; the kth largest of those 256 maxima is a lower
-//     bound L of the kth-largest logit (k distinct elements are >= it);
-//  2. every element with raw key >= L - margin is a candidate: only candidates are divided by the
-//     temperature (t = bf16(l/T) is monotone in l, and at most 2*ceil(T)+2 neighbouring bf16 inputs
-//     can round to one output, hence the margin) and appended to an LDS list (~k..3k entries);
-//  3. wave 0 finds the exact kth-largest t among the candidates by 16-bit bisection (ties kept),
-//     then log-softmax / softmax / Exp(1) race exactly as torch-CPU rounds them, one element per lane;
+//  1. per-thread max of the RAW bf16 keys -> LDS; the kth largest of the 128 thread-PAIR maxima is a lower bound L of
+//     the kth-largest logit (k distinct elements are >= it);
+//  2. every element with raw key >= L - margin is a candidate (t = bf16(l/T) is monotone in l, and at most 2*ceil(T)+2
+//     neighbouring bf16 inputs can round to one output, hence the margin): appended, undivided, to an LDS list in index
+//     order (~k..3k entries);
+//  3. wave 0 takes the list two entries per lane, divides by the temperature, finds the exact kth-largest t by bisection
+//     (ties kept), re-packs the ~k survivors one per lane and does log-softmax / softmax exactly as torch-CPU rounds
+//     them in registers, while waves 1..3 draw the candidates' Exp(1) variates (Philox: ~150 instructions each, off
+//     wave 0's critical path); then the race argmax(p / q) on wave 0.  (More than 128 candidates or more than 64
+//     survivors -- many ties -- take a generic looped form of the same arithmetic.)
 //  4. returns the sampled index (valid in every thread after the final sync).
 template <int ITERS, class Sync>
 __device__ __forceinline__ int sample_body(const uint32_t (&w)[ITERS][4], int V, float temperature, int topk, const bf16_t* noise_row,
@@ -166,6 +182,8 @@ __device__ __forceinline__ int sample_body(const uint32_t (&w)[ITERS][4], int V,
             }
     } else {
         const int k = min(topk, V);
+        // order keys of this thread's elements, 0 = not an element (beyond V, NaN); kept in registers for all three passes
+        uint32_t key[ITERS][8];
         uint32_t lmax = 0;
 #pragma unroll
         for (int i = 0; i < ITERS; ++i)
@@ -174,29 +192,32 @@ __device__ __forceinline__ int sample_body(const uint32_t (&w)[ITERS][4], int V,
                 const int idx = i * 2048 + tid * 8 + j;
                 const uint32_t bits = (j & 1) ? (w[i][j >> 1] >> 16) : (w[i][j >> 1] & 0xffffu);
                 const bool nan = (bits & 0x7fffu) > 0x7f80u;
-                if (idx < V && !nan) lmax = max(lmax, raw_key(bits));
+                key[i][j] = (idx < V && !nan) ? raw_key(bits) : 0u;
+                lmax = max(lmax, key[i][j]);
             }
         sc.s_max[tid] = lmax;
+        sync.mark(0);
         sync();
         uint32_t L = 0;
         if (k <= 256) {
             const u32x4_t mv = reinterpret_cast<lds_u32x4_t*>(sc.s_max)[lane];
-            const uint32_t mk[4] = {mv.x, mv.y, mv.z, mv.w};
-            L = kth_largest_key<4>(mk, k);
+            if (k <= 128) {      // maxima of thread PAIRS: still k distinct elements >= the kth largest of them, half the bisection work
+                const uint32_t mk[2] = {max(mv.x, mv.y), max(mv.z, mv.w)};
+                L = kth_largest_key<2>(mk, k);
+            } else {
+                const uint32_t mk[4] = {mv.x, mv.y, mv.z, mv.w};
+                L = kth_largest_key<4>(mk, k);
+            }
         }
+        sync.mark(1);
         const uint32_t margin = 2u * (uint32_t)ceilf(fmaxf(temperature, 1.0f)) + 2u;
-        const uint32_t Lm = L > margin ? L - margin : 0u;
+        const uint32_t Lm = L > margin ? L - margin : 1u;             // >= 1: key 0 is "not an element"
         // deterministic compaction in index order: per-thread count -> wave scan -> wave bases
         int cnt = 0;
 #pragma unroll
         for (int i = 0; i < ITERS; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int idx = i * 2048 + tid * 8 + j;
-                const uint32_t bits = (j & 1) ? (w[i][j >> 1] >> 16) : (w[i][j >> 1] & 0xffffu);
-                const bool nan = (bits & 0x7fffu) > 0x7f80u;
-                cnt += (idx < V && !nan && raw_key(bits) >= Lm) ? 1 : 0;
-            }
+            for (int j = 0; j < 8; ++j) cnt += key[i][j] >= Lm ? 1 : 0;
         // (cnt <= 8 * ITERS <= 64: 7 bits)
         const int incl = wave_excl_scan_small<7>(cnt) + cnt;
         if (lane == 63) sc.s_wtot[wave] = incl;
@@ -204,85 +225,121 @@ __device__ __forceinline__ int sample_body(const uint32_t (&w)[ITERS][4], int V,
         int o = incl - cnt;
         for (int x = 0; x < wave; ++x) o += sc.s_wtot[x];
         if (tid == 255) *sc.s_n = o + cnt;
+        // the list holds the UNDIVIDED logit (as a float) and its index; wave 0 divides the ~k survivors, one or two per lane
 #pragma unroll
         for (int i = 0; i < ITERS; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int idx = i * 2048 + tid * 8 + j;
-                const uint32_t bits = (j & 1) ? (w[i][j >> 1] >> 16) : (w[i][j >> 1] & 0xffffu);
-                const bool nan = (bits & 0x7fffu) > 0x7f80u;
-                if (idx < V && !nan && raw_key(bits) >= Lm) {
-                    sc.cand_t[o] = round_bf(__uint_as_float(bits << 16) / temperature);
-                    sc.cand_i[o] = idx;
+            for (int j = 0; j < 8; ++j)
+                if (key[i][j] >= Lm) {
+                    const uint32_t bits = (j & 1) ? (w[i][j >> 1] >> 16) : (w[i][j >> 1] & 0xffffu);
+                    sc.cand_t[o] = __uint_as_float(bits << 16);
+                    sc.cand_i[o] = i * 2048 + tid * 8 + j;
                     ++o;
                 }
-            }
         sync();
+        sync.mark(2);
         const int n = *sc.s_n;
         if (wave == 0) {
-            // ---- exact kth-largest t among the candidates -> keep t >= kth (ties kept) ---------
-            uint32_t kth = 0;
-            if (n > k) {
-                if (n <= 256) {
-                    uint32_t ck[4];
+            bool fast = false;
+            if (n <= 128) {
+                // ---- two list slots per lane in registers: t = bf16(logit / T), exact kth-largest t (ties kept) ------
+                float tv[2]; int ix[2]; uint32_t ck[2];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) ck[c] = (c * 64 + lane < n) ? order_key(sc.cand_t[c * 64 + lane]) : 0u;
-                    kth = kth_largest_key<4>(ck, k);
-                } else {                               // rare (k > 256 or massive ties): generic loop
-                    uint32_t prefix = 0;
+                for (int u = 0; u < 2; ++u) {
+                    const int c = u * 64 + lane;
+                    const bool live = c < n;
+                    tv[u] = round_bf(sc.cand_t[live ? c : 0] / temperature);
+                    ix[u] = sc.cand_i[live ? c : 0] | (c << 16);            // (V <= 16384: the index fits 14 bits)
+                    ck[u] = live ? order_key(tv[u]) : 0u;
+                }
+                const uint32_t kth = n > k ? kth_largest_key<2>(ck, k) : 0u;
+                const bool keep0 = ck[0] != 0u && ck[0] >= kth, keep1 = ck[1] != 0u && ck[1] >= kth;
+                const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
+                const int kept0 = __popcll(m0), kept = kept0 + __popcll(m1);
+                sync.mark(3);
+                if (kept <= 64) {
+                    // ---- the survivors, one per lane (list order kept): everything below stays in registers ----------
+                    fast = true;
+                    const int p0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u));
+                    const int p1 = kept0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
+                    if (keep0) { sc.cand_t[128 + p0] = tv[0]; sc.cand_i[128 + p0] = ix[0]; }      // (slots 0..127 are still being read by waves 1..3)
+                    if (keep1) { sc.cand_t[128 + p1] = tv[1]; sc.cand_i[128 + p1] = ix[1]; }
+                    const bool live = lane < kept;
+                    const float v = sc.cand_t[128 + (live ? lane : 0)];
+                    const int pk = sc.cand_i[128 + (live ? lane : 0)];
+                    // log_softmax / softmax with torch-CPU's bf16 rounding points
+                    const float mx = wave_max(live ? v : -INFINITY);
+                    const float sum = wave_sum(live ? expf(v - mx) : 0.f);
+                    const float logsum = round_bf(logf(round_bf(sum)));
+                    const float mx2 = round_bf(0.f - logsum);      // log-prob of the max element
+                    const float e3 = live ? expf(round_bf(round_bf(v - mx) - logsum) - mx2) : 0.f;
+                    const float s2 = wave_sum(e3);
+                    sync.mark(4);
+                    sync();                                    // the Exp(1) draws of waves 1..3 are in cand_q
+                    // argmax(p / q), q ~ Exp(1); first index wins ties
+                    const float p = round_bf(e3 / s2);
+                    if (live && p > 0.f) { best = round_bf(p / sc.cand_q[pk >> 16]); best_idx = pk & 0xffff; }
+                }
+            }
+            if (!fast) {
+                // ---- generic form (more than 128 candidates, or more than 64 survivors through ties) -------------------
+                for (int c = lane; c < n; c += 64) sc.cand_t[c] = round_bf(sc.cand_t[c] / temperature);
+                uint32_t kth = 0;
+                if (n > k) {
                     for (int bit = 15; bit >= 0; --bit) {
-                        const uint32_t cnd = prefix | (1u << bit);
+                        const uint32_t cnd = kth | (1u << bit);
                         int cnt2 = 0;
                         for (int c = lane; c < ((n + 63) & ~63); c += 64)
                             cnt2 += __popcll(__ballot(c < n && order_key(sc.cand_t[c]) >= cnd));
-                        if (cnt2 >= k) prefix = cnd;
+                        if (cnt2 >= k) kth = cnd;
                     }
-                    kth = prefix;
+                }
+                float mx = -INFINITY;
+                for (int c = lane; c < n; c += 64) {
+                    const float v = sc.cand_t[c];
+                    if (order_key(v) >= kth) mx = fmaxf(mx, v);
+                }
+                mx = wave_max(mx);
+                float sum = 0.f;
+                for (int c = lane; c < n; c += 64) {
+                    const float v = sc.cand_t[c];
+                    if (order_key(v) >= kth) sum += expf(v - mx);
+                }
+                sum = wave_sum(sum);
+                const float logsum = round_bf(logf(round_bf(sum)));
+                const float mx2 = round_bf(0.f - logsum);
+                float s2 = 0.f;
+                for (int c = lane; c < n; c += 64) {
+                    const float v = sc.cand_t[c];
+                    if (order_key(v) >= kth) s2 += expf(round_bf(round_bf(v - mx) - logsum) - mx2);
+                }
+                s2 = wave_sum(s2);
+                sync();
+                for (int c = lane; c < n; c += 64) {
+                    const float v = sc.cand_t[c];
+                    if (order_key(v) < kth) continue;
+                    const int idx = sc.cand_i[c];
+                    const float p = round_bf(expf(round_bf(round_bf(v - mx) - logsum) - mx2) / s2);
+                    if (!(p > 0.f)) continue;
+                    const float q = c < 256 ? sc.cand_q[c] : exp1_draw(idx, noise_row, seed, step, b, codebook);
+                    const float r = round_bf(p / q);
+                    if (r > best || (r == best && idx < best_idx)) { best = r; best_idx = idx; }
                 }
             }
-            // ---- log_softmax (torch-CPU bf16 rounding points) over the kept candidates ---------
-            float mx = -INFINITY;
-            for (int c = lane; c < n; c += 64) {
-                const float v = sc.cand_t[c];
-                if (order_key(v) >= kth) mx = fmaxf(mx, v);
-            }
-            mx = wave_max(mx);
-            float sum = 0.f;
-            for (int c = lane; c < n; c += 64) {
-                const float v = sc.cand_t[c];
-                if (order_key(v) >= kth) sum += expf(v - mx);
-            }
-            sum = wave_sum(sum);
-            const float logsum = round_bf(logf(round_bf(sum)));
-            const float mx2 = round_bf(0.f - logsum);      // log-prob of the max element
-            float s2 = 0.f;
-            for (int c = lane; c < n; c += 64) {
-                const float v = sc.cand_t[c];
-                if (order_key(v) >= kth) s2 += expf(round_bf(round_bf(v - mx) - logsum) - mx2);
-            }
-            s2 = wave_sum(s2);
-            // ---- argmax(p / q), q ~ Exp(1); first index wins ties ----------------------------------
-            for (int c = lane; c < n; c += 64) {
-                const float v = sc.cand_t[c];
-                if (order_key(v) < kth) continue;
-                const int idx = sc.cand_i[c];
-                const float p = round_bf(expf(round_bf(round_bf(v - mx) - logsum) - mx2) / s2);
-                if (!(p > 0.f)) continue;
-                float q;
-                if (noise_row) q = bf2f(noise_row[idx]);
-                else {
-                    const uint4 rnd = philox4x32(make_uint4((uint32_t)idx, (uint32_t)b, (uint32_t)codebook, (uint32_t)step),
-                                                 make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32)));
-                    const float u = ((float)rnd.x + 0.5f) * 2.3283064365386963e-10f;   // (0,1]
-                    q = round_bf(-logf(u));
-                    if (!(q > 0.f)) q = 1e-30f;
-                }
-                const float r = round_bf(p / q);
-                if (r > best || (r == best && idx < best_idx)) { best = r; best_idx = idx; }
-            }
+            sync.mark(5);
+            const float wb = wave_max(best);
+            best_idx = wave_min_i(best == wb ? best_idx : 0x7fffffff);
+            if (lane == 0) *sc.s_tok = best_idx == 0x7fffffff ? 0 : best_idx;
+        } else {
+            // waves 1..3 meanwhile: the Exp(1) draw of every listed candidate (a pure function of its index)
+            for (int c = (wave - 1) * 64 + lane; c < min(n, 256); c += 192)
+                sc.cand_q[c] = exp1_draw(sc.cand_i[c], noise_row, seed, step, b, codebook);
+            sync();
         }
+        sync();
+        return *sc.s_tok;
     }
-    // argmax over the wave (lowest index on ties), then over the 4 waves
+    // greedy: argmax over the wave (lowest index on ties), then over the 4 waves
     {
         const float wb = wave_max(best);
         best_idx = wave_min_i(best == wb ? best_idx : 0x7fffffff);
@@ -301,7 +358,10 @@ __device__ __forceinline__ int sample_body(const uint32_t (&w)[ITERS][4], int V,
     return *sc.s_tok;
 }
 
-struct SyncThreads { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
+struct SyncThreads {
+    __device__ __forceinline__ void operator()() const { __syncthreads(); }
+    __device__ __forceinline__ void mark(int) const {}      // (the persistent decoder's barrier records a debug timeline here)
+};
 
 // One block of 4 waves per sequence (the standalone launch of the chain path).
 template <int ITERS>
@@ -324,7 +384,7 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
         w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
     }
     SampleScratch sc;
-    sc.cand_t = (lds_f32_t*)cand_t; sc.cand_i = (lds_i32_t*)cand_i; sc.s_max = (lds_u32_t*)s_max; sc.s_bv = (lds_f32_t*)s_bv;
+    sc.cand_t = (lds_f32_t*)cand_t; sc.cand_i = (lds_i32_t*)cand_i; sc.s_max = (lds_u32_t*)s_max; sc.cand_q = (lds_f32_t*)s_max; sc.s_bv = (lds_f32_t*)s_bv;
     sc.s_bi = (lds_i32_t*)s_bi; sc.s_n = (lds_i32_t*)&s_n; sc.s_tok = (lds_i32_t*)&s_tok; sc.s_wtot = (lds_i32_t*)s_wtot;
     const int tok = sample_body<ITERS>(w, a.V, a.temperature, a.topk, a.noise ? a.noise + (long)b * a.V : nullptr, seed, step, b,
                                        a.codebook, sc, tid, SyncThreads());

@@ -84,6 +84,19 @@ def main():
     print(f"      wave 0: 6 (gate, up) pairs + h exchange                {mean_d(3, 4):6.2f}")
     print(f"      wave 0: 3 row blocks of the down partial, published    {mean_d(4, 5):6.2f}")
     print(f"      partials published -> rows published (edge + sum)      {float(sum(float(t[s_, 2 * 4 + 3] - ex[s_, 5]) for s_ in range(3, 29)) / 26):6.2f}")
+    sm = allw[4352:4352 + 512].view(32, 16) * 0.01
+    names = ["flag seen -> per-thread maxima stored", "barrier + kth bound of the 128 pair maxima", "count, scan, barrier, candidate list, barrier",
+             "t = logit / T, exact kth, survivors re-packed (wave 0)", "log-softmax, softmax", "barrier (Exp(1) draws ready) + race"]
+    print("   sampler detail (thread 0 of the quad):")
+    prev = t[:, 22]
+    for i, nm in enumerate(names):
+        vals = [float(sm[s_, i] - prev[s_]) for s_ in range(3, 29) if sm[s_, i] > 0]
+        print(f"      {nm:58s} {sum(vals) / max(len(vals), 1):6.2f}")
+        prev = sm[:, i]
+    vals = [float(t[s_, 23] - sm[s_, 5]) for s_ in range(3, 29) if sm[s_, 5] > 0]
+    print(f"      {'argmax over the wave, last barrier':58s} {sum(vals) / max(len(vals), 1):6.2f}")
+    vals = [float(sm[s_, 7] - sm[s_, 6]) for s_ in range(3, 29) if sm[s_, 7] > 0]
+    print(f"      {'sampler body alone, last pass (CSM_PERSIST_TRICKLE=134 runs it twice: warm instruction cache)':58s} {sum(vals) / max(len(vals), 1):6.2f}")
     whole = float(t[n_steps - 2, 19] - t[2, 19]) / (n_steps - 4)
     print(f"   step period measured directly: {whole:.2f} us")
 
