@@ -1158,6 +1158,10 @@ extern "C" double csm_bytes_per_frame(csm_handle m, int B, double p_mean) {
 // debug: enable (host == nullptr) or read back the persistent decoder's gather-wave timeline, [32 steps][32] 100 MHz ticks
 extern "C" int csm_debug_persist_stamps(csm_handle m, uint64_t* host, int n_words) {
     if (!m || !m->persist) return CSM_E_STATE;
+#ifndef DP_TIMELINE
+    m->err = "csm_debug_persist_stamps: this build has no timeline stamps (use libcsm_hip_timeline.so: make timeline, CSM_HIP_TIMELINE=1)";
+    return CSM_E_STATE;
+#endif
     if (!m->p_stamps) {
         HIPCHK(m, hipMalloc((void**)&m->p_stamps, (32 * 32 + 4096 + 256) * 8));
         HIPCHK(m, hipMemset(m->p_stamps, 0, (32 * 32 + 4096 + 256) * 8));

@@ -79,6 +79,13 @@ struct DecPersistArgs {
 };
 
 // LDS image (dynamic shared memory; byte offsets)
+// Debug timeline (tools/persist_timeline.py): compiled in only with -DDP_TIMELINE (libcsm_hip_timeline.so).  In the product
+// build every stamp folds away -- ~170 sites whose stores otherwise put waits and SGPR pressure into the compute waves.
+#ifdef DP_TIMELINE
+#define DP_STAMPS(a_) ((a_).stamps)
+#else
+#define DP_STAMPS(a_) ((dp_u64*)nullptr)
+#endif
 #define DP_OFF_K 0                                   // [4][2][32][128] bf16
 #define DP_OFF_V 65536
 #define DP_OFF_U 131072                              // layers: xA | xC | q | att (2 KB each); sampling: cand_t | cand_i (8448 B each)
@@ -341,11 +348,12 @@ struct DpQuadSync {
 // unit; 5 is in the quad).
 // ---------------------------------------------------------------------------------------------------------------
 // one sampling step by the 4 waves of the quad (qw = 0..3): sample_body on the logits in LDS; returns the code
+template <bool DEBUG_OUT>
 __device__ __forceinline__ int dp_sample_step(const DecPersistArgs& a, char* lds, int qw, int lane, int cu, int cb, int s, uint32_t* quad_phase) {
     dp_lu32* misc = (dp_lu32*)(lds + DP_OFF_MISC);
     dp_lvu32* ab = (dp_lvu32*)(misc + DP_M_ABORT);
     const int tid = qw * 64 + lane;
-    if (a.stamps != nullptr && cu == 100 && tid == 0) a.stamps[s * 32 + 22] = __builtin_amdgcn_s_memrealtime();
+    if (DP_STAMPS(a) != nullptr && cu == 100 && tid == 0) DP_STAMPS(a)[s * 32 + 22] = __builtin_amdgcn_s_memrealtime();
     const dp_lu4* lg = (const dp_lu4*)(lds + DP_OFF_LOGITS);
     uint32_t w[2][4];
     {
@@ -354,14 +362,14 @@ __device__ __forceinline__ int dp_sample_step(const DecPersistArgs& a, char* lds
         const uint4 v1 = tid < 64 ? dp_ldq(lg + 256 + tid) : make_uint4(0, 0, 0, 0);
         w[1][0] = v1.x; w[1][1] = v1.y; w[1][2] = v1.z; w[1][3] = v1.w;
     }
-    if (a.logits_out != nullptr && cu == 0) {
-        for (int i = tid; i < a.V; i += 256) a.logits_out[(long)cb * a.V + i] = ((const dp_lu16*)lg)[i];
+    if (DEBUG_OUT && a.logits_out != nullptr && cu == 0) {       // (gather wave only: its stores would put a vmcnt(0) in a compute wave's path)
+        for (int i = lane; i < a.V; i += 64) a.logits_out[(long)cb * a.V + i] = ((const dp_lu16*)lg)[i];
     }
     SampleScratch sc;
     sc.cand_t = (lds_f32_t*)(lds + DP_OFF_CANDT); sc.cand_i = (lds_i32_t*)(lds + DP_OFF_CANDI); sc.s_max = (lds_u32_t*)(lds + DP_OFF_SMAX); sc.cand_q = (lds_f32_t*)(lds + DP_OFF_SMAX);
     sc.s_bv = (lds_f32_t*)(misc + DP_M_SBV); sc.s_bi = (lds_i32_t*)(misc + DP_M_SBI); sc.s_n = (lds_i32_t*)(misc + DP_M_SN);
     sc.s_tok = (lds_i32_t*)(misc + DP_M_STOK); sc.s_wtot = (lds_i32_t*)(misc + DP_M_SWTOT);
-    DpQuadSync sync{(dp_lvu32*)(misc + DP_M_BAR), ab, a.err, lane, quad_phase, a.stamps != nullptr && cu == 100 && qw == 0 ? a.stamps + 4352 + s * 16 : nullptr};
+    DpQuadSync sync{(dp_lvu32*)(misc + DP_M_BAR), ab, a.err, lane, quad_phase, DP_STAMPS(a) != nullptr && cu == 100 && qw == 0 ? DP_STAMPS(a) + 4352 + s * 16 : nullptr};
     const uint64_t seed = (uint64_t)misc[DP_M_RNG] | ((uint64_t)misc[DP_M_RNG + 1] << 32), step = (uint64_t)misc[DP_M_RNG + 2] | ((uint64_t)misc[DP_M_RNG + 3] << 32);
     int tok = 0;
     const int reps = (a.trickle_sleep & 128) ? 2 : 1;          // experiment: the second pass runs from a warm instruction cache
@@ -371,7 +379,7 @@ __device__ __forceinline__ int dp_sample_step(const DecPersistArgs& a, char* lds
         tok = sample_body<2>(w, a.V, a.temperature, a.topk, a.noise ? a.noise + (long)cb * a.V : nullptr, seed, step, 0, cb, sc, tid, sync);
         sync.mark(7);
     }
-    if (a.stamps != nullptr && cu == 100 && tid == 0) a.stamps[s * 32 + 23] = __builtin_amdgcn_s_memrealtime();
+    if (DP_STAMPS(a) != nullptr && cu == 100 && tid == 0) DP_STAMPS(a)[s * 32 + 23] = __builtin_amdgcn_s_memrealtime();
     if (tid == 0 && cu == 0) a.frame[cb] = tok;
     return tok;
 }
@@ -379,7 +387,8 @@ __device__ __forceinline__ int dp_sample_step(const DecPersistArgs& a, char* lds
 typedef __attribute__((ext_vector_type(8))) __bf16 dp_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float dp_f32x4;
 template <bool IS_X, bool IS_A, bool IN_QUAD, bool HAS_TILE, int NBK>
-__device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* lds, const int wave, const unsigned lane, const int cu, const uint32_t base) {
+__device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* lds, const int wave, const unsigned lane, const int cu, const uint32_t base,
+                                                const uint32_t ropev) {
     constexpr bool IS_B = !IS_X && !IS_A;
     constexpr int NT = HAS_TILE ? 32 : 0, NCD = NT + NBK * 4;
     dp_lu32* misc = (dp_lu32*)(lds + DP_OFF_MISC);
@@ -442,7 +451,7 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                     a0 = wave_sum(a0); a1 = wave_sum(a1);
                     const int row = 2 * unit;                              // q rows 0..1023, k 1024..1279, v 1280..1535
                     const int e = (row < 1024 ? row : row - 1024) % DP_HD;
-                    const uint32_t cs = reinterpret_cast<const uint32_t*>(a.rope)[cb * (DP_HD / 2) + e / 2];
+                    const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)ropev, cb);   // (cos, sin) of this unit's pair at position cb
                     const uint32_t outw = dp_rope_pair(a0, a1, cs, row < 1280);
                     if (lane < DP_NREP) dp_gran_store(a.gQ + lane * 768 + unit, dp_tag(base, s, l, DP_E_Q), outw);
                 }
@@ -455,10 +464,10 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                         if (IS_A) { if (k < 4) load_ws(l + 1 < DP_NL ? l + 1 : DP_NL, cb, k); else load_cd(l, NCD / 3 + k - 4); }
                         else load_cd(l, k);
                     })) return;
-                const bool st5 = a.stamps != nullptr && cu == 100 && lane == 0 && wave == 5 && l == 2;
-                if (st5) a.stamps[4096 + s * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+                const bool st5 = DP_STAMPS(a) != nullptr && cu == 100 && lane == 0 && wave == 5 && l == 2;
+                if (st5) DP_STAMPS(a)[4096 + s * 8 + 0] = __builtin_amdgcn_s_memrealtime();
                 dp_attention_wave(lds, wave, l, cb, lane);
-                if (st5) a.stamps[4096 + s * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+                if (st5) DP_STAMPS(a)[4096 + s * 8 + 1] = __builtin_amdgcn_s_memrealtime();
             }
             if (IS_B) {
                 // -- o-projection unit + residual, once the four attention waves are done
@@ -472,7 +481,7 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                 const uint32_t outw = dp_resid_pair(a0, a1, h0w);
                 if (lane == 0) misc[DP_M_H1 + (wave - 5)] = outw;
                 if (lane < DP_NREP) dp_gran_store(a.gH1 + lane * 512 + unit, dp_tag(base, s, l, DP_E_H1), outw);
-                if (a.stamps != nullptr && cu == 100 && lane == 0 && wave == 5 && l == 2) a.stamps[4096 + s * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+                if (DP_STAMPS(a) != nullptr && cu == 100 && lane == 0 && wave == 5 && l == 2) DP_STAMPS(a)[4096 + s * 8 + 2] = __builtin_amdgcn_s_memrealtime();
             }
             {
                 // -- the MLP: my (gate, up) pairs -> h values -> LDS -> my row blocks of the split down projection
@@ -482,8 +491,8 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                         else if (IS_A) load_cd(l, 2 * (NCD / 3) + k);
                         else { if (k < 4) load_ws(l + 1 < DP_NL ? l + 1 : DP_NL, cb, k); else load_cd(l, NCD / 2 + k - 4); }
                     })) return;
-                const bool st0 = a.stamps != nullptr && cu == 100 && lane == 0 && wave == 0 && l == 2;
-                if (st0) a.stamps[4096 + s * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+                const bool st0 = DP_STAMPS(a) != nullptr && cu == 100 && lane == 0 && wave == 0 && l == 2;
+                if (st0) DP_STAMPS(a)[4096 + s * 8 + 3] = __builtin_amdgcn_s_memrealtime();
                 if (HAS_TILE) {
                     // tile `wave`: rows 0..7 = gate rows of pairs 8 wave .. 8 wave + 7, rows 8..15 = their up rows; k step t covers
                     // k = 32t .. 32t+31: lane l feeds A[row l & 15][8 (l >> 4) + j] and, as every column of B, x[32t + 8 (l >> 4) + j]
@@ -535,7 +544,7 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                         if ((spins & 255u) == 0 && dp_give_up(t0, ab, a.err, 0x950u, lane)) return;
                     asm volatile("" ::: "memory");
                 }
-                if (st0) a.stamps[4096 + s * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+                if (st0) DP_STAMPS(a)[4096 + s * 8 + 4] = __builtin_amdgcn_s_memrealtime();
                 uint4 h[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) h[q] = dp_ldq((const dp_lu4*)(misc + DP_M_HL) + q);
@@ -545,14 +554,14 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                     const float p = dp_down_partial(wd[b], h);
                     dp_gran_store(a.gP + ((long)(n >> 2) * 256 + cu) * 4 + (n & 3), dp_tag(base, s, l, DP_E_P), __float_as_uint(p));
                 }
-                if (st0) a.stamps[4096 + s * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+                if (st0) DP_STAMPS(a)[4096 + s * 8 + 5] = __builtin_amdgcn_s_memrealtime();
             }
         }
         // ---- the head of codebook cb: waves 2..6 hold 2 logit rows each (ws slot 4), x = dec_norm(h)
         if (!IS_X) {
             if (!dp_wait<1, false>((dp_lvu32*)(misc + DP_M_FXA), dp_tag(base, s, DP_NL - 1, DP_E_H2), ab, a.err, 0x960u, lane, ts, [&](int) {})) return;
-            const bool st2 = a.stamps != nullptr && cu == 100 && lane == 0 && wave == 2;
-            if (st2) a.stamps[s * 32 + 20] = __builtin_amdgcn_s_memrealtime();
+            const bool st2 = DP_STAMPS(a) != nullptr && cu == 100 && lane == 0 && wave == 2;
+            if (st2) DP_STAMPS(a)[s * 32 + 20] = __builtin_amdgcn_s_memrealtime();
             if (hunit >= 0) {
                 const dp_lu4* xs = (const dp_lu4*)(lds + DP_OFF_XA);
                 const uint4 x0 = dp_ldq(xs + lane), x1 = dp_ldq(xs + 64 + lane);
@@ -560,10 +569,9 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                 float a1 = dot8(ws[1][0], x0, 0.f); a1 = dot8(ws[1][1], x1, a1);
                 a0 = wave_sum(a0); a1 = wave_sum(a1);
                 if (lane < DP_NREP) dp_gran_store(a.gL + lane * DP_LSLOTS + hunit, dp_tag(base, s, DP_NL - 1, DP_E_L), pack_bf(a0, a1));
-                if (a.trickle_sleep & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // experiment: drain the publishing store
             }
-            if (st2) a.stamps[s * 32 + 21] = __builtin_amdgcn_s_memrealtime();
-            if (a.stamps != nullptr && s == 5 && lane == 0 && hunit >= 0) a.stamps[1024 + cu * 8 + wave] = __builtin_amdgcn_s_memrealtime();
+            if (st2) DP_STAMPS(a)[s * 32 + 21] = __builtin_amdgcn_s_memrealtime();
+            if (DP_STAMPS(a) != nullptr && s == 5 && lane == 0 && hunit >= 0) DP_STAMPS(a)[1024 + cu * 8 + wave] = __builtin_amdgcn_s_memrealtime();
             // next use of the small-op rows: the B waves' layer-0 o-proj of the next step (the A waves reload theirs in layer 0)
             if (IS_B) {
 #pragma unroll
@@ -573,7 +581,7 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
         // ---- the sampler (waves 4, 5, 6 and the gather wave), on every CU alike: each CU needs the code for its table rows
         if (IN_QUAD) {
             if (!dp_wait<1, false>((dp_lvu32*)(misc + DP_M_FLG), dp_tag(base, s, DP_NL - 1, DP_E_L), ab, a.err, 0x970u, lane, ts, [&](int) {})) return;
-            (void)dp_sample_step(a, lds, wave - 4, (int)lane, cu, cb, s, &quad_phase);
+            (void)dp_sample_step<false>(a, lds, wave - 4, (int)lane, cu, cb, s, &quad_phase);
             if (*ab) return;
         }
     }
@@ -585,6 +593,15 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
     const unsigned lane = threadIdx.x & 63;
     dp_lu32* misc = (dp_lu32*)(lds + DP_OFF_MISC);
     dp_lvu32* ab = (dp_lvu32*)(misc + DP_M_ABORT);
+    // RoPE (cos, sin) of the pair a q|k|v wave (2, 3, 4) rotates, for every position of this launch: lane p holds position
+    // p's.  Read here, once: a global load inside the step would sit on the q|k|v edge and, vmcnt being in order, behind
+    // every weight load the wave has in flight.
+    uint32_t ropev = 0;
+    if (wave >= 2 && wave <= 4 && lane < 32) {
+        const int row = 2 * (cu * 3 + (wave - 2));
+        const int e = (row < 1024 ? row : row - 1024) % DP_HD;
+        ropev = reinterpret_cast<const uint32_t*>(a.rope)[lane * (DP_HD / 2) + e / 2];
+    }
     // ---- LDS image of the step's starting state (all 512 threads) ----
     for (int i = threadIdx.x; i < 128; i += 512) misc[i] = 0;
     for (int i = threadIdx.x; i < 2560 / 2; i += 512) ((dp_lu32*)(lds + DP_OFF_LOGITS))[i] = 0;
@@ -615,8 +632,8 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
         const int n_steps = a.cb_last - a.cb_first + 1;
         uint32_t quad_phase = 0;
         dp_flag((dp_lvu32*)(misc + DP_M_FQ), dp_tag(base, 0, 0, DP_E_Q));          // layer 0's q / k / v of the first step are in place
-        const bool st = a.stamps != nullptr && cu == 100 && lane == 0;
-#define DP_STAMP(s_, i_) do { if (st) a.stamps[(s_) * 32 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+        const bool st = DP_STAMPS(a) != nullptr && cu == 100 && lane == 0;
+#define DP_STAMP(s_, i_) do { if (st) DP_STAMPS(a)[(s_) * 32 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
         for (int s = 0; s < n_steps; ++s) {
             const int cb = a.cb_first + s;
             for (int l = 0; l < DP_NL; ++l) {
@@ -633,7 +650,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
                     }
                     {   // q | k | v -> q buffer and this position's K / V rows
                         uint32_t v[12];
-                        if (!dp_sweep<6>(rgQ, 768, dp_tag(base, s, l, DP_E_Q), v, ln, ab, a.err, 0x200u + l, a.poll_sleep, st ? a.stamps + s * 32 + 26 : nullptr)) return;
+                        if (!dp_sweep<6>(rgQ, 768, dp_tag(base, s, l, DP_E_Q), v, ln, ab, a.err, 0x200u + l, a.poll_sleep, st ? DP_STAMPS(a) + s * 32 + 26 : nullptr)) return;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { ((dp_lu32*)(lds + DP_OFF_QB))[2 * (j * 64 + ln)] = v[2 * j]; ((dp_lu32*)(lds + DP_OFF_QB))[2 * (j * 64 + ln) + 1] = v[2 * j + 1]; }
                         {   // load 4: granules 512 + 2 ln (k: head ln >> 5), load 5: 640 + 2 ln (v)
@@ -659,7 +676,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
                 }
                 {   // the 256 down-projection partials of my 4 rows -> sum + residual -> the layer's output rows
                     uint32_t v[16];
-                    if (!dp_sweep<8>(rgP, 1024, dp_tag(base, s, l, DP_E_P), v, ln, ab, a.err, 0x400u + l, a.poll_sleep, st ? a.stamps + s * 32 + 27 : nullptr)) return;
+                    if (!dp_sweep<8>(rgP, 1024, dp_tag(base, s, l, DP_E_P), v, ln, ab, a.err, 0x400u + l, a.poll_sleep, st ? DP_STAMPS(a) + s * 32 + 27 : nullptr)) return;
                     float t0_, t1_;
                     dp_reduce_partials(v, t0_, t1_);                 // rows 2 (ln & 1), 2 (ln & 1) + 1 of this CU's four
                     const uint32_t h1w = *(dp_lvu32*)(misc + DP_M_H1 + (ln & 1));
@@ -678,18 +695,18 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
             {   // the stack's output rows -> final norm -> x of the head
                 uint32_t v[8];
                 const uint4 g0 = reinterpret_cast<const uint4*>(a.dec_norm)[ln], g1 = reinterpret_cast<const uint4*>(a.dec_norm)[64 + ln];
-                if (!dp_sweep<4>(rgH2, 512, dp_tag(base, s, DP_NL - 1, DP_E_H2), v, ln, ab, a.err, 0x500u, a.poll_sleep, st ? a.stamps + s * 32 + 25 : nullptr)) return;
+                if (!dp_sweep<4>(rgH2, 512, dp_tag(base, s, DP_NL - 1, DP_E_H2), v, ln, ab, a.err, 0x500u, a.poll_sleep, st ? DP_STAMPS(a) + s * 32 + 25 : nullptr)) return;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { ((dp_lu32*)(lds + DP_OFF_XA))[2 * (j * 64 + ln)] = v[2 * j]; ((dp_lu32*)(lds + DP_OFF_XA))[2 * (j * 64 + ln) + 1] = v[2 * j + 1]; }
                 dp_norm_in_lds((dp_lu4*)(lds + DP_OFF_XA), g0, g1, a.eps, ln);
                 dp_flag((dp_lvu32*)(misc + DP_M_FXA), dp_tag(base, s, DP_NL - 1, DP_E_H2));
                 DP_STAMP(s, 16);
-                if (a.stamps != nullptr && s == 5 && lane == 0) a.stamps[1024 + 2048 + 256 + cu] = __builtin_amdgcn_s_memrealtime();
+                if (DP_STAMPS(a) != nullptr && s == 5 && lane == 0) DP_STAMPS(a)[1024 + 2048 + 256 + cu] = __builtin_amdgcn_s_memrealtime();
             }
             {   // logits -> LDS
                 uint32_t v[18];
                 const int ng = (a.V + 1) / 2;
-                if (!dp_sweep<9>(rgL, ng, dp_tag(base, s, DP_NL - 1, DP_E_L), v, ln, ab, a.err, 0x600u, a.poll_sleep, st ? a.stamps + s * 32 + 24 : nullptr)) return;
+                if (!dp_sweep<9>(rgL, ng, dp_tag(base, s, DP_NL - 1, DP_E_L), v, ln, ab, a.err, 0x600u, a.poll_sleep, st ? DP_STAMPS(a) + s * 32 + 24 : nullptr)) return;
 #pragma unroll
                 for (int j = 0; j < 9; ++j) {
                     const int g0 = 2 * (j * 64 + ln);
@@ -699,11 +716,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
                 if ((a.V & 1) && ln == 0) ((dp_lu16*)(lds + DP_OFF_LOGITS))[a.V] = 0;       // the tail unit's second half is not a logit
                 dp_flag((dp_lvu32*)(misc + DP_M_FLG), dp_tag(base, s, DP_NL - 1, DP_E_L));
                 DP_STAMP(s, 17);
-                if (a.stamps != nullptr && s == 5 && lane == 0) a.stamps[1024 + 2048 + cu] = __builtin_amdgcn_s_memrealtime();
+                if (DP_STAMPS(a) != nullptr && s == 5 && lane == 0) DP_STAMPS(a)[1024 + 2048 + cu] = __builtin_amdgcn_s_memrealtime();
             }
             {   // sample with waves 4..6 (this wave is the quad's fourth), then the code -> the next step's input row and layer-0
                 // q / k / v (table rows), like k_sample's tail
-                const int tok = dp_sample_step(a, lds, 3, ln, cu, cb, s, &quad_phase);
+                const int tok = dp_sample_step<true>(a, lds, 3, ln, cu, cb, s, &quad_phase);
                 if (*ab) return;
                 DP_STAMP(s, 18);
                 if (cb + 1 < a.ncb) {
@@ -729,11 +746,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
         if (cu == 0 && lane == 0) __hip_atomic_store(a.epoch, base + (uint32_t)(n_steps * DP_NL * 5 + 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    if (wave < 2) dp_compute_wave<true, false, false, true, 2>(a, lds, wave, lane, cu, base);
-    else if (wave < 4) dp_compute_wave<false, true, false, true, 2>(a, lds, wave, lane, cu, base);
-    else if (wave == 4) dp_compute_wave<false, true, true, false, 3>(a, lds, wave, lane, cu, base);
-    else if (wave == 5) dp_compute_wave<false, false, true, false, 3>(a, lds, wave, lane, cu, base);
-    else dp_compute_wave<false, false, true, false, 2>(a, lds, wave, lane, cu, base);
+    if (wave < 2) dp_compute_wave<true, false, false, true, 2>(a, lds, wave, lane, cu, base, ropev);
+    else if (wave < 4) dp_compute_wave<false, true, false, true, 2>(a, lds, wave, lane, cu, base, ropev);
+    else if (wave == 4) dp_compute_wave<false, true, true, false, 3>(a, lds, wave, lane, cu, base, ropev);
+    else if (wave == 5) dp_compute_wave<false, false, true, false, 3>(a, lds, wave, lane, cu, base, ropev);
+    else dp_compute_wave<false, false, true, false, 2>(a, lds, wave, lane, cu, base, ropev);
 }
 
 // W1, W3 [8192][1024] -> [256 cu][4 tiles][32 k steps][64 lanes] 16-byte operand pieces: tile q of workgroup cu holds the

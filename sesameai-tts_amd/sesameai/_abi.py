@@ -12,7 +12,9 @@ import torch  # noqa: F401  -- FIRST: libcsm_hip.so must bind to the HIP runtime
 #                         libamdhip64); loading ours before torch puts two runtimes in the process ("no ROCm-capable device")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcsm_hip.so")
+# CSM_HIP_TIMELINE=1: the build with the persistent decoder's debug stamps compiled in (make -C csrc timeline)
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib",
+                        "libcsm_hip_timeline.so" if os.environ.get("CSM_HIP_TIMELINE", "0") == "1" else "libcsm_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -1,8 +1,11 @@
 """Timeline of the persistent depth-decoder launch (csrc/dec_persist.cuh) on the bench workload: where one decoder
-step's ~90 us go, from the gather wave's s_memrealtime stamps (workgroup 100).  python tools/persist_timeline.py"""
+step's time goes, from s_memrealtime stamps of workgroup 100.  Needs the stamped build of the library:
+    make -C sesameai-tts_amd/csrc timeline && python tools/persist_timeline.py"""
 import ctypes as C
 import os
 import sys
+
+os.environ["CSM_HIP_TIMELINE"] = "1"      # the library build with the stamps compiled in (make -C sesameai-tts_amd/csrc timeline)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "sesameai-tts_amd")):
