@@ -50,7 +50,8 @@ int csm_op_sample(int B, int V, int ldl, const void* logits, float temperature, 
  * on, later calls copy [32 steps][32] s_memrealtime ticks (100 MHz) of workgroup 100's gather wave to `host`.
  * Per step s: words l*4 + {0: x of q|k|v ready, 1: q/k/v in LDS, 2: x of the MLP ready, 3: layer-l rows published},
  * 16: x of the head ready, 17: logits in LDS, 18: code sampled, 19: next step's table rows in LDS, 20-23: head / sampler waves, 24-27: poll passes of the logits / head-x / q|k|v / partials sweeps.   CSM_E_STATE when the
- * handle does not run the persistent launch.                                                                          */
+ * handle does not run the persistent launch, or when the library is the product build: the stamps exist only in
+ * libcsm_hip_timeline.so (make -C sesameai-tts_amd/csrc timeline, loaded with CSM_HIP_TIMELINE=1).                      */
 int csm_debug_persist_stamps(csm_handle h, uint64_t* host, int n_words);
 
 #ifdef __cplusplus
