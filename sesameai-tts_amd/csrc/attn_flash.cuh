@@ -141,14 +141,21 @@ __global__ __launch_bounds__(256) void k_attn_flash(const AttnArgs a) {
         // ---- out[query][hq][d] = O^T / l: registers 4g4 .. 4g4+3 are 4 consecutive d -> one 8-byte store ---------
         if (r < nr) {
             const float inv = 1.0f / lrun;
+            // (out_packed: matrix-core operand order for the o-projection, common.cuh xp_off -- 8-byte halves of its 16-byte pieces)
             bf16_t* dst = a.out + ((long)(m_base + r) * a.H + hq) * HD;
+            const long KO = (long)a.H * HD;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 u32x2_t w0, w1;
                 w0[0] = pack_bf(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv); w0[1] = pack_bf(o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv);
                 w1[0] = pack_bf(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv); w1[1] = pack_bf(o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv);
-                *reinterpret_cast<u32x2_t*>(dst + 8 * g4 + 4 * h) = w0;
-                *reinterpret_cast<u32x2_t*>(dst + 32 + 8 * g4 + 4 * h) = w1;
+                if (a.out_packed) {
+                    *reinterpret_cast<u32x2_t*>(a.out + xp_off(m_base + r, hq * HD + 8 * g4 + 4 * h, KO)) = w0;
+                    *reinterpret_cast<u32x2_t*>(a.out + xp_off(m_base + r, hq * HD + 32 + 8 * g4 + 4 * h, KO)) = w1;
+                } else {
+                    *reinterpret_cast<u32x2_t*>(dst + 8 * g4 + 4 * h) = w0;
+                    *reinterpret_cast<u32x2_t*>(dst + 32 + 8 * g4 + 4 * h) = w1;
+                }
             }
         }
     }

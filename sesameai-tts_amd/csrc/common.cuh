@@ -141,7 +141,9 @@ __device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
 
 // RMSNorm of one row by one wave (torchtune rounding: fp32 normalise -> bf16 -> * bf16 scale).  Shared by
 // k_rmsnorm_rows (mm.cuh) and the sampler's fused "next decoder input" norm so both give the same bits.
-__device__ __forceinline__ void rmsnorm_row_wave(const bf16_t* x, int K, const bf16_t* scale, float eps, bf16_t* out, int lane) {
+__device__ __forceinline__ long xp_off(int m, int k, long K);
+// out_row >= 0: `out` is the base of an operand-order buffer (xp_off) and the row is written as row `out_row` of it
+__device__ __forceinline__ void rmsnorm_row_wave(const bf16_t* x, int K, const bf16_t* scale, float eps, bf16_t* out, int lane, int out_row = -1) {
     const uint4* src = reinterpret_cast<const uint4*>(x);
     float ss = 0.f;
     for (int c = lane; c < K / 8; c += 64) {
@@ -159,7 +161,8 @@ __device__ __forceinline__ void rmsnorm_row_wave(const bf16_t* x, int K, const b
         o.y = pack_bf(round_bf(lo2f(v.y) * r) * lo2f(g.y), round_bf(hi2f(v.y) * r) * hi2f(g.y));
         o.z = pack_bf(round_bf(lo2f(v.z) * r) * lo2f(g.z), round_bf(hi2f(v.z) * r) * hi2f(g.z));
         o.w = pack_bf(round_bf(lo2f(v.w) * r) * lo2f(g.w), round_bf(hi2f(v.w) * r) * hi2f(g.w));
-        reinterpret_cast<uint4*>(out)[c] = o;
+        if (out_row >= 0) *reinterpret_cast<uint4*>(out + xp_off(out_row, 8 * c, K)) = o;
+        else reinterpret_cast<uint4*>(out)[c] = o;
     }
 }
 

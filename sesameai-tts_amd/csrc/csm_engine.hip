@@ -71,6 +71,7 @@ struct CsmModel {
     int wide_path;                      // MFMA path for M >= wide_min (env CSM_WIDE=0 disables)
     int wide_min;                       // WIDE_MIN_ROWS unless env CSM_WIDE_MIN overrides (tuning knob)
     int xpack;                          // batched decode steps keep activations in operand order (env CSM_XPACK=0 disables)
+    int xpack_prompt;                   // prompts below the LDS-tiled kernels' row count too (env CSM_XPACK_PROMPT=0 disables)
     int fp8_wide;                       // fp8 mode: batched decode steps stream e4m3 on the matrix-core path too (env CSM_FP8_WIDE=0 disables)
     int fuse_dec_attn;                  // depth-decoder attention fused into the O-projection (env CSM_FUSE_DEC_ATTN=0 disables)
     // persistent depth decoder (dec_persist.cuh): steps 2..ncb-1 of a batch-1 frame as one launch (env CSM_PERSIST=0 disables)
@@ -207,6 +208,52 @@ static hipError_t launch_mm(int kind, int K, int hd, const GemvArgs& a, hipStrea
     return f8 ? launch_mm_t<1, false>(kind, K, hd, a, st) : launch_mm_t<0, false>(kind, K, hd, a, st);
 }
 
+// prompts of 64..255 rows (mm.cuh k_mmt / k_mmq): k_mm32's bits with several output tiles per wave.  w0/w1/w2 PACKED.
+static const int MMT_MIN_ROWS = getenv("CSM_MMT_MIN_ROWS") ? atoi(getenv("CSM_MMT_MIN_ROWS")) : 64;
+// which projections take them (bit 0 q|k|v, 1 gate/up, 2 o-proj, 3 down).  Measured per backbone layer at 190 rows, operand-order
+// x, us: q|k|v 21.3 vs k_mm32 14.9 (96 fat blocks leave 160 CUs idle and a CU pulls only ~30 GB/s from HBM whatever the
+// prefetch depth), gate/up 28.4 vs 41.6, o-proj 11.5 vs 13.0, down 37.4 vs 31.0  ->  default: gate/up and o-proj
+static const int MMT_OPS = getenv("CSM_MMT_OPS") ? atoi(getenv("CSM_MMT_OPS")) : 6;
+static bool mmt_ok(int M, int K, int N) { return M >= MMT_MIN_ROWS && M <= 256 && K % 1024 == 0 && N % 64 == 0; }   // K/4 quarters in rings of up to 8 half-chunks
+#define MMT_NBUF(TM_) 2                              // ring depth: 4 measured no faster than 2 at 190 rows and costs the second resident block (gate/up 31 vs 28 us)
+template <int TM, bool XP>
+static hipError_t launch_mmt_tm(int kind, int hd, int K, const GemvArgs& a, hipStream_t st) {
+    const int mgroups = (a.M + 32 * TM - 1) / (32 * TM);
+    if (kind == 3) {
+        const unsigned blocks = (unsigned)(8L * ((a.N / 64 + 7) / 8) * mgroups);
+        if (hd == 64) hipLaunchKernelGGL((k_mmt<EPI_QKV_ROPE, 64, TM, 2, XP, MMT_NBUF(TM)>), dim3(blocks), dim3(256), 0, st, a, K, mgroups);
+        else hipLaunchKernelGGL((k_mmt<EPI_QKV_ROPE, 128, TM, 2, XP, MMT_NBUF(TM)>), dim3(blocks), dim3(256), 0, st, a, K, mgroups);
+    } else if (kind == 4) {
+        const unsigned blocks = (unsigned)(8L * ((a.N / 32 + 7) / 8) * mgroups);
+        hipLaunchKernelGGL((k_mmt<EPI_SWIGLU, 64, TM, 1, XP, MMT_NBUF(TM)>), dim3(blocks), dim3(256), 0, st, a, K, mgroups);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+// xp: a.x in operand order (xp_off, row stride K)
+static hipError_t launch_mmt(int kind, int hd, int K, const GemvArgs& a, hipStream_t st, bool xp = false) {
+    // 96-row groups unless 64-row groups pad fewer rows
+    const int pad3 = (a.M + 95) / 96 * 96, pad2 = (a.M + 63) / 64 * 64;
+    if (xp) return pad3 <= pad2 ? launch_mmt_tm<3, true>(kind, hd, K, a, st) : launch_mmt_tm<2, true>(kind, hd, K, a, st);
+    return pad3 <= pad2 ? launch_mmt_tm<3, false>(kind, hd, K, a, st) : launch_mmt_tm<2, false>(kind, hd, K, a, st);
+}
+// residual projection of a prompt: the four K-quarter slabs (the finisher adds them in order: KG = 4)
+template <bool XP>
+static hipError_t launch_mmq_t(int K, const GemvArgs& a, hipStream_t st) {
+    const unsigned blocks = (unsigned)(8L * ((a.N / 64 + 7) / 8) * 4);
+    const int rt = (a.M + 31) / 32, tm = (rt + 1) / 2;
+    switch (tm) {
+        case 1: hipLaunchKernelGGL((k_mmq<1, XP, 8>), dim3(blocks), dim3(256), 0, st, a, K); break;
+        case 2: hipLaunchKernelGGL((k_mmq<2, XP, 8>), dim3(blocks), dim3(256), 0, st, a, K); break;
+        case 3: hipLaunchKernelGGL((k_mmq<3, XP, 4>), dim3(blocks), dim3(256), 0, st, a, K); break;
+        case 4: hipLaunchKernelGGL((k_mmq<4, XP, 4>), dim3(blocks), dim3(256), 0, st, a, K); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+static hipError_t launch_mmq(int K, const GemvArgs& a, hipStream_t st, bool xp = false) {
+    return xp ? launch_mmq_t<true>(K, a, st) : launch_mmq_t<false>(K, a, st);
+}
+
 // long prompts / batched prefill: LDS-tiled 128 x 128 kernel (gemm128.cuh); weights UNPACKED [N][K]
 // rows from which prefill takes the LDS-tiled kernels (measured: 190 rows 5.8 vs 6.7 ms with them, 380 rows 8.4 vs 7.8)
 static const int G128_MIN_ROWS = getenv("CSM_G128_MIN_ROWS") ? atoi(getenv("CSM_G128_MIN_ROWS")) : 256;
@@ -277,18 +324,18 @@ static hipError_t launch_resid_norm(bf16_t* h, const float* slab, int kg, int M,
         else hipLaunchKernelGGL((k_resid_norm_row<4>), dim3(M_out), dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, scale, eps, xn, xn_stride, (int)xn_packed);
         return hipGetLastError();
     }
-    if (xn_packed) return hipErrorInvalidValue;
     dim3 grid((M_out + 3) / 4);
-    if (N <= 512) hipLaunchKernelGGL((k_resid_norm<1>), grid, dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, M_out, scale, eps, xn, xn_stride);
-    else if (N <= 1024) hipLaunchKernelGGL((k_resid_norm<2>), grid, dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, M_out, scale, eps, xn, xn_stride);
-    else if (N <= 2048) hipLaunchKernelGGL((k_resid_norm<4>), grid, dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, M_out, scale, eps, xn, xn_stride);
+    const int xpk = xn_packed ? 1 : 0;
+    if (N <= 512) hipLaunchKernelGGL((k_resid_norm<1>), grid, dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, M_out, scale, eps, xn, xn_stride, xpk);
+    else if (N <= 1024) hipLaunchKernelGGL((k_resid_norm<2>), grid, dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, M_out, scale, eps, xn, xn_stride, xpk);
+    else if (N <= 2048) hipLaunchKernelGGL((k_resid_norm<4>), grid, dim3(256), 0, st, h, slab, kg, M, N, row_step, row_first, M_out, scale, eps, xn, xn_stride, xpk);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 static hipError_t launch_rmsnorm_rows(const bf16_t* x, long stride, long offset, int M, int K, const bf16_t* scale, float eps,
-                                      bf16_t* out, long out_stride, hipStream_t st) {
-    hipLaunchKernelGGL(k_rmsnorm_rows, dim3((M + 3) / 4), dim3(256), 0, st, x, stride, offset, M, K, scale, eps, out, out_stride);
+                                      bf16_t* out, long out_stride, hipStream_t st, bool out_packed = false) {
+    hipLaunchKernelGGL(k_rmsnorm_rows, dim3((M + 3) / 4), dim3(256), 0, st, x, stride, offset, M, K, scale, eps, out, out_stride, out_packed ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -409,11 +456,19 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         // the kernels of a layer (common.cuh xp_off): producers write it, consumers read 1 KB pieces
         // (from 24 rows: a 1 KB piece always carries 32 rows, so for a few rows the row-major gather touches fewer lines:
         //  B=8 5.39 vs 5.52 ms packed, B=32 6.15 vs 6.01, B=64 7.42 vs 6.93, B=128 10.29 vs 9.07)
-        const bool xp = m->xpack && !prompt && rows_per_seq <= 2 && M >= 24 && M < g128_gateup_rows && (d == 512 || d == 1024 || d == 2048);
+        const bool xp_decode = m->xpack && !prompt && rows_per_seq <= 2 && M >= 24 && M < g128_gateup_rows && (d == 512 || d == 1024 || d == 2048);
+        // prompts below the LDS-tiled kernels' row count do the same (round 2): their projections were bound by exactly those
+        // gathers (TA address cycles, 64 lines per fragment), not by bytes
+        const bool xp_prompt = m->xpack_prompt && (prompt || rows_per_seq > 2) && !f8 && M >= 24 && d % 64 == 0 && S.nq % 64 == 0 && S.d.ffn % 64 == 0 && d <= 2048;
+        const bool xp = xp_decode || xp_prompt;
+        const bool xp0 = xp_prompt && !x_normed;            // layer 0's normalised input is written here: operand order too
+        // prompts of 64..256 rows (prompt mode or a plain multi-row prefill; never decode steps): the several-tiles-per-wave
+        // forms of k_mm32 (prompt mode: same bits; half the L2 traffic)
+        const bool mid = (prompt || rows_per_seq > 2) && !f8 && mmt_ok(M, d, S.nq + 2 * S.nkv) && mmt_ok(M, S.nq, d) && mmt_ok(M, d, S.d.ffn) && mmt_ok(M, S.d.ffn, d);
         // layer 0 normalises h directly; later layers got xn from the previous down-projection's finisher.
         // (layer 0 of a depth-decoder step >= 2: q/k/v were gathered from the precomputed table by the sampler)
         if (!(l == 0 && qkv0_done)) {
-            if (l == 0 && !x_normed && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st)) != hipSuccess) return e;
+            if (l == 0 && !x_normed && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st, xp0)) != hipSuccess) return e;
             memset(&a, 0, sizeof a);
             a.x = att; a.x_row_stride = d; a.M = M;
             a.w0 = (const bf16_t*)pk.wq; a.w1 = (const bf16_t*)pk.wk; a.w2 = (const bf16_t*)pk.wv;
@@ -424,7 +479,10 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
                 a.w0 = (const bf16_t*)p8.wq; a.w1 = (const bf16_t*)p8.wk; a.w2 = (const bf16_t*)p8.wv;
                 a.s0 = (const float*)S.w8s[l].wq; a.s1 = (const float*)S.w8s[l].wk; a.s2 = (const float*)S.w8s[l].wv;
             }
-            if ((e = launch_mm(3, d, S.hd, a, st, f8, xp && l > 0)) != hipSuccess) return e;   // layer 0's input comes row-major
+            const bool xq = l > 0 ? xp : xp0;                  // (decode steps: layer 0's input comes row-major)
+            if (mid && (MMT_OPS & 1)) e = launch_mmt(3, S.hd, d, a, st, xq);
+            else e = launch_mm(3, d, S.hd, a, st, f8, xq);
+            if (e != hipSuccess) return e;
         }
         AttnArgs t;
         t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
@@ -440,9 +498,11 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         // o-proj -> fp32 slabs; finisher: h += sum(slabs), xn = mlp_norm(h)
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)pk.wo; a.N = d; a.slab = m->slab;
-        int kg = slab_groups(S.nq, prompt);
+        int kg = mid && (MMT_OPS & 4) ? 4 : slab_groups(S.nq, prompt);
         if (f8) { a.w0 = (const bf16_t*)p8.wo; a.s0 = (const float*)S.w8s[l].wo; }
-        if ((e = launch_mm_slab(S.nq, kg, a, st, f8, xp)) != hipSuccess) return e;
+        if (mid && (MMT_OPS & 4)) e = launch_mmq(S.nq, a, st, xp);
+        else e = launch_mm_slab(S.nq, kg, a, st, f8, xp);
+        if (e != hipSuccess) return e;
         if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st, prompt, xp)) != hipSuccess) return e;
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = d; a.M = M; a.w0 = (const bf16_t*)pk.w1; a.w1 = (const bf16_t*)pk.w3; a.N = S.d.ffn;
@@ -454,14 +514,18 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
             if ((e = launch_g128(4, d, S.hd, a, st)) != hipSuccess) return e;
         } else {
             if (f8) { a.w0 = (const bf16_t*)p8.w1; a.w1 = (const bf16_t*)p8.w3; a.s0 = (const float*)S.w8s[l].w1; a.s1 = (const float*)S.w8s[l].w3; }
-            if ((e = launch_mm(4, d, S.hd, a, st, f8, xp)) != hipSuccess) return e;
+            if (mid && (MMT_OPS & 2)) e = launch_mmt(4, S.hd, d, a, st, xp);
+            else e = launch_mm(4, d, S.hd, a, st, f8, xp);
+            if (e != hipSuccess) return e;
         }
         // down-proj -> slabs; finisher applies the NEXT layer's sa_norm (or nothing after the last layer)
         memset(&a, 0, sizeof a);
         a.x = act; a.x_row_stride = S.d.ffn; a.M = M; a.w0 = (const bf16_t*)pk.w2; a.N = d; a.slab = m->slab;
-        kg = slab_groups(S.d.ffn, prompt);
+        kg = mid && (MMT_OPS & 8) ? 4 : slab_groups(S.d.ffn, prompt);
         if (f8) { a.w0 = (const bf16_t*)p8.w2; a.s0 = (const float*)S.w8s[l].w2; }
-        if ((e = launch_mm_slab(S.d.ffn, kg, a, st, f8, xp)) != hipSuccess) return e;
+        if (mid && (MMT_OPS & 8)) e = launch_mmq(S.d.ffn, a, st, xp);
+        else e = launch_mm_slab(S.d.ffn, kg, a, st, f8, xp);
+        if (e != hipSuccess) return e;
         if (l + 1 < S.d.n_layers) {
             if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)S.lw[l + 1].sa_norm, S.d.norm_eps, att, d, st, prompt, xp)) != hipSuccess) return e;
         } else {
@@ -849,6 +913,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     { const char* ev = getenv("CSM_WIDE_MIN"); m->wide_min = ev && atoi(ev) > 0 ? atoi(ev) : WIDE_MIN_ROWS; }
     { const char* ev = getenv("CSM_FP8_WIDE"); m->fp8_wide = !(ev && ev[0] == '0'); }
     { const char* ev = getenv("CSM_XPACK"); m->xpack = !(ev && ev[0] == '0'); }
+    { const char* ev = getenv("CSM_XPACK_PROMPT"); m->xpack_prompt = !(ev && ev[0] == '0'); }
     // Cache policy (measured, tools/microbench/gemv_bench.hip and whole frames): the backbone (1.9 GB, read once per
     // frame) and the heads stream non-temporally so they do not evict the depth decoder, whose 222 MB are re-read on
     // each of its 31 steps and about fit the 256 MB Infinity Cache.  The decoder itself keeps the default policy:
@@ -1190,8 +1255,9 @@ extern "C" int csm_op_gemv(int kind, int M, int K, int N, const void* x, long x_
     // kinds 10/11/13/14: the wide-M matrix-core path (mm.cuh) of kinds 0/1/3/4 (x already normalised);
     // the hook re-tiles the row-major test weights into the matrix-core operand order first
     // kinds 20/21/23/24: the same through the 128 x 128 LDS-tiled kernel of long prompts (gemm128.cuh, row-major weights)
+    // kinds 31/33/34: the same through the several-tiles-per-wave prompt kernels (mm.cuh k_mmq + finisher / k_mmt), 64..256 rows
     hipError_t e;
-    if (kind >= 20) {
+    if (kind >= 20 && kind < 30) {
         e = launch_g128(kind - 20, K, head_dim, a, (hipStream_t)stream);
     } else if (kind >= 10) {
         std::vector<void*> tmp;
@@ -1204,9 +1270,23 @@ extern "C" int csm_op_gemv(int kind, int M, int K, int N, const void* x, long x_
             hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, n, K, (bf16_t*)t);
             return (const bf16_t*)t;
         };
-        if (kind == 13) { a.w0 = pack(a.w0, nq); a.w1 = pack(a.w1, nkv); a.w2 = pack(a.w2, nkv); }
-        else if (kind == 14) { a.w0 = pack(a.w0, N); a.w1 = pack(a.w1, N); }
+        if (kind % 10 == 3) { a.w0 = pack(a.w0, nq); a.w1 = pack(a.w1, nkv); a.w2 = pack(a.w2, nkv); }
+        else if (kind % 10 == 4) { a.w0 = pack(a.w0, N); a.w1 = pack(a.w1, N); }
         else a.w0 = pack(a.w0, N);
+        if (kind >= 30) {
+            if (!mmt_ok(M, K, N)) e = hipErrorInvalidValue;
+            else if (kind == 31) {
+                void* slab = nullptr;
+                e = hipMalloc(&slab, (size_t)4 * M * N * 4);
+                if (e == hipSuccess) {
+                    tmp.push_back(slab);
+                    a.slab = (float*)slab;
+                    e = launch_mmq(K, a, (hipStream_t)stream);
+                    if (e == hipSuccess && out != resid) e = hipMemcpyAsync(out, resid, (size_t)M * N * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+                    if (e == hipSuccess) e = launch_resid_norm((bf16_t*)out, (const float*)slab, 4, M, N, 1, 0, M, nullptr, 0.f, nullptr, 0, (hipStream_t)stream);
+                }
+            } else e = launch_mmt(kind - 30, head_dim, K, a, (hipStream_t)stream);
+        } else
         e = launch_mm(kind - 10, K, head_dim, a, (hipStream_t)stream);
         (void)hipStreamSynchronize((hipStream_t)stream);
         for (void* t : tmp) (void)hipFree(t);

@@ -20,10 +20,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 // RMSNorm of M rows (torchtune rounding: fp32 normalise -> bf16 -> * bf16 scale); one wave per row
 __global__ __launch_bounds__(256) void k_rmsnorm_rows(const bf16_t* x, long x_row_stride, long x_row_offset, int M, int K,
-                                                      const bf16_t* scale, float eps, bf16_t* out, long out_stride) {
+                                                      const bf16_t* scale, float eps, bf16_t* out, long out_stride, int out_packed) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
-    rmsnorm_row_wave(x + (long)row * x_row_stride + x_row_offset, K, scale, eps, out + (long)row * out_stride, lane);
+    if (out_packed) rmsnorm_row_wave(x + (long)row * x_row_stride + x_row_offset, K, scale, eps, out, lane, row);
+    else rmsnorm_row_wave(x + (long)row * x_row_stride + x_row_offset, K, scale, eps, out + (long)row * out_stride, lane);
 }
 
 // Finishes a split-K residual projection of the wide path and (optionally) applies the next RMSNorm:
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm_rows(const bf16_t* x, long x_ro
 // One wave per row; the row stays in registers between the two passes (N <= 64 * 8 * NCH).
 template <int NCH>
 __global__ __launch_bounds__(256) void k_resid_norm(bf16_t* h, const float* slab, int KG, int M, int N, long row_step, long row_first,
-                                                    int M_out, const bf16_t* scale, float eps, bf16_t* xn, long xn_stride) {
+                                                    int M_out, const bf16_t* scale, float eps, bf16_t* xn, long xn_stride, int xn_packed) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= M_out) return;
     const long r = (long)i * row_step + row_first;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void k_resid_norm(bf16_t* h, const float* slab
         o.y = pack_bf(round_bf(v[c][2] * rs) * lo2f(g.y), round_bf(v[c][3] * rs) * hi2f(g.y));
         o.z = pack_bf(round_bf(v[c][4] * rs) * lo2f(g.z), round_bf(v[c][5] * rs) * hi2f(g.z));
         o.w = pack_bf(round_bf(v[c][6] * rs) * lo2f(g.w), round_bf(v[c][7] * rs) * hi2f(g.w));
-        *reinterpret_cast<uint4*>(xn + (long)i * xn_stride + col) = o;
+        *reinterpret_cast<uint4*>(xn_packed ? xn + xp_off(i, col, N) : xn + (long)i * xn_stride + col) = o;
     }
 }
 
@@ -394,4 +395,211 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K,
             mm_finish<EPI, HD>(a, m, n, s0, s1);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Prompt rows, 64 <= M < 256 (a voice prompt of one segment: ~190 rows).  k_mm32 there moves 1.25 GB per backbone
+// layer through the L2s for 122 MB of weights (every 32 x 32 output tile re-reads its x rows and its weight rows:
+// x N/32 times, W M/32 times) and is bound by exactly that.  The two kernels below are k_mm32's arithmetic with more
+// output tiles per wave, so a fragment fetched once feeds several MFMAs:
+//   k_mmt  TM x TN tiles of 32 x 32 per wave, the four waves of a block = the four K quarters (as in k_mm32), fold
+//          through LDS tile by tile, epilogue in the kernel (q|k|v + RoPE + KV append, SwiGLU);
+//   k_mmq  residual projections: a block = (64 columns, ALL rows, ONE K quarter), its waves split the block's tiles and
+//          each chains its quarter alone; the fp32 quarter goes to slab[quarter] and k_resid_norm adds the four in order.
+// Both produce k_mm32's bits: per output tile the same MFMA chain per K quarter (k ascending, the same operand
+// pieces) and the same fold ((0 + q0) + q1) + q2) + q3 -- rows keep their value whatever kernel or row count
+// (tests: test_prompt_kernels_give_the_same_bits_at_every_row_count, test_csm1b_prefix_reuse_bit_identical).
+// Weights are the k_pack_w copies; x is row-major or (XP) in operand order like the weights: a wave's x fragment is then
+// one contiguous 1 KB read instead of a 64-cache-line gather, which is what bounds these kernels otherwise (measured:
+// the row-major forms were SLOWER than k_mm32 at 190 rows, 2.85 vs 2.46 ms per prefill -- fewer, fatter waves, same gathers).
+// ---------------------------------------------------------------------------------------------------------------
+template <int EPI, int HD>
+__device__ __forceinline__ const uint4* mmt_weight_tile(const GemvArgs& a, const int n, const long tile_u4, const int which) {
+    if (EPI == EPI_QKV_ROPE) {
+        if (n < a.nq) return reinterpret_cast<const uint4*>(a.w0) + (long)(n / 32) * tile_u4;
+        if (n < a.nq + a.nkv) return reinterpret_cast<const uint4*>(a.w1) + (long)((n - a.nq) / 32) * tile_u4;
+        return reinterpret_cast<const uint4*>(a.w2) + (long)((n - a.nq - a.nkv) / 32) * tile_u4;
+    }
+    return reinterpret_cast<const uint4*>(which ? a.w1 : a.w0) + (long)(n / 32) * tile_u4;
+}
+
+template <int EPI, int HD, int TM, int TN, bool XP, int NBUF>
+__global__ __launch_bounds__(256) void k_mmt(const GemvArgs a, const int K, const int mgroups) {
+    constexpr bool SW = EPI == EPI_SWIGLU;
+    __shared__ float red[SW ? 2 : 1][4][16][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int mg = j % mgroups, ng = (j / mgroups) * 8 + xcd;         // XCD c owns the column groups c, c + 8, ...
+    const int n0 = ng * 32 * TN, m0 = mg * 32 * TM;
+    if (n0 >= a.N) return;
+    const long tile_u4 = (long)(K / 64) * 256;
+    const uint4* wa[TN];
+    const uint4* wb[TN];
+    const bf16_t* xa[TM];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        wa[tn] = mmt_weight_tile<EPI, HD>(a, n0 + 32 * tn, tile_u4, 0);
+        wb[tn] = SW ? mmt_weight_tile<EPI, HD>(a, n0 + 32 * tn, tile_u4, 1) : nullptr;
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)       // XP: base of the row tile's operand-order pieces (tiles past the last row re-read the last tile)
+        xa[tm] = XP ? a.x + (long)min(m0 / 32 + tm, (a.M - 1) / 32) * 32 * a.x_row_stride
+                    : a.x + (long)min(m0 + 32 * tm + r, a.M - 1) * a.x_row_stride + a.x_row_offset;
+    const int kspan = K / 4, kbeg = wave * kspan;
+    f32x16_t acc0[TM][TN], acc1[SW ? TM : 1][SW ? TN : 1];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[tm][tn][i] = 0.f; if (SW) acc1[tm][tn][i] = 0.f; }
+    // A ring of NBUF register buffers, each one HALF (MFMA steps 0-1 or 2-3) of a 64-deep chunk: NBUF - 1 halves of loads
+    // are in flight while one feeds the MFMAs.  With one block per CU (few, fat waves) that depth is all the latency hiding
+    // there is: two buffers left the q|k|v projection at 22 us against k_mm32's 15.
+    uint4 av[NBUF][TM][2], bv[NBUF][TN][2], cv[NBUF][SW ? TN : 1][2];
+    const int nh = kspan / 32;
+    auto load = [&](int buf, int t) {                     // t = half index along this wave's K quarter
+        const int kc = kbeg + (t >> 1) * 64;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int q = (t & 1) * 2 + qq;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                av[buf][tm][qq] = XP ? reinterpret_cast<const uint4*>(xa[tm])[((kc >> 6) * 4 + q) * 64 + lane]
+                                     : *reinterpret_cast<const uint4*>(xa[tm] + kc + h * 32 + q * 8);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                bv[buf][tn][qq] = wld(wa[tn] + ((kc >> 6) * 4 + q) * 64 + lane);
+                if (SW) cv[buf][tn][qq] = wld(wb[tn] + ((kc >> 6) * 4 + q) * 64 + lane);
+            }
+        }
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc0[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[buf][tm][qq]), as_bf16x8(bv[buf][tn][qq]), acc0[tm][tn], 0, 0, 0);
+                    if (SW) acc1[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[buf][tm][qq]), as_bf16x8(cv[buf][tn][qq]), acc1[tm][tn], 0, 0, 0);
+                }
+    };
+    // (nh is a multiple of NBUF -- checked at launch.  No conditional load inside the steady-state loop: with one, hipcc's
+    //  wait-count pass takes the minimum over both paths and the loop waits on vmcnt(0), i.e. prefetches nothing.)
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) load(i, i);
+    int t0 = 0;
+    for (; t0 + 2 * NBUF <= nh; t0 += NBUF) {
+#pragma unroll
+        for (int u = 0; u < NBUF; ++u) {
+            load((u + NBUF - 1) % NBUF, t0 + u + NBUF - 1);
+            mma(u);
+            __builtin_amdgcn_sched_barrier(0);         // keep load / MFMA groups interleaved (the scheduler would hoist all loads of the body)
+        }
+    }
+    load(NBUF - 1, t0 + NBUF - 1);
+#pragma unroll
+    for (int u = 0; u < NBUF; ++u) mma(u);
+    // fold the four K quarters tile by tile (the same order as k_mm32) and finish
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            if (tm + tn > 0) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                red[0][wave][i][lane] = acc0[tm][tn][i];
+                if constexpr (SW) red[1][wave][i][lane] = acc1[tm][tn][i];
+            }
+            __syncthreads();
+            {
+#pragma clang fp contract(off)
+                const int n = n0 + 32 * tn + r;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int reg = wave * 4 + i;
+                    const int m = m0 + 32 * tm + 8 * wave + 4 * h + i;
+                    float s0 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) s0 += red[0][w][reg][lane];
+                    float s1 = 0.f;
+                    if constexpr (SW) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) s1 += red[1][w][reg][lane];
+                    }
+                    mm_finish<EPI, HD>(a, m, n, s0, s1);
+                }
+            }
+        }
+}
+
+// grid: 8 * ceil(column groups / 8) * 4 blocks; block = (column group of 64, K quarter); wave w: column tile w & 1, row
+// tiles (w >> 1) * TM .. + TM of the (up to) 2 TM row tiles, i.e. M <= 64 TM.  slab[quarter][M][N] fp32.
+template <int TM, bool XP, int NBUF>
+__global__ __launch_bounds__(256) void k_mmq(const GemvArgs a, const int K) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int quarter = j & 3, ng = (j >> 2) * 8 + xcd;
+    const int n0 = ng * 64 + 32 * (wave & 1), m0 = (wave >> 1) * 32 * TM;
+    if (ng * 64 >= a.N || m0 >= a.M) return;
+    const long tile_u4 = (long)(K / 64) * 256;
+    const uint4* wa = reinterpret_cast<const uint4*>(a.w0) + (long)(n0 / 32) * tile_u4;
+    const bf16_t* xa[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)       // XP: base of the row tile's operand-order pieces (tiles past the last row re-read the last tile)
+        xa[tm] = XP ? a.x + (long)min(m0 / 32 + tm, (a.M - 1) / 32) * 32 * a.x_row_stride
+                    : a.x + (long)min(m0 + 32 * tm + r, a.M - 1) * a.x_row_stride + a.x_row_offset;
+    const int kspan = K / 4, kbeg = quarter * kspan;
+    f32x16_t acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tm][i] = 0.f;
+    uint4 av[NBUF][TM][2], bv[NBUF][2];
+    const int nh = kspan / 32;
+    auto load = [&](int buf, int t) {
+        const int kc = kbeg + (t >> 1) * 64;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int q = (t & 1) * 2 + qq;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                av[buf][tm][qq] = XP ? reinterpret_cast<const uint4*>(xa[tm])[((kc >> 6) * 4 + q) * 64 + lane]
+                                     : *reinterpret_cast<const uint4*>(xa[tm] + kc + h * 32 + q * 8);
+            bv[buf][qq] = wld(wa + ((kc >> 6) * 4 + q) * 64 + lane);
+        }
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[buf][tm][qq]), as_bf16x8(bv[buf][qq]), acc[tm], 0, 0, 0);
+    };
+    // (nh is a multiple of NBUF -- checked at launch.  No conditional load inside the steady-state loop: with one, hipcc's
+    //  wait-count pass takes the minimum over both paths and the loop waits on vmcnt(0), i.e. prefetches nothing.)
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) load(i, i);
+    int t0 = 0;
+    for (; t0 + 2 * NBUF <= nh; t0 += NBUF) {
+#pragma unroll
+        for (int u = 0; u < NBUF; ++u) {
+            load((u + NBUF - 1) % NBUF, t0 + u + NBUF - 1);
+            mma(u);
+            __builtin_amdgcn_sched_barrier(0);         // keep load / MFMA groups interleaved (the scheduler would hoist all loads of the body)
+        }
+    }
+    load(NBUF - 1, t0 + NBUF - 1);
+#pragma unroll
+    for (int u = 0; u < NBUF; ++u) mma(u);
+    // accumulator register i of lane (r, h): row 8 (i / 4) + 4 h + (i % 4) of the tile, column r
+    const int n = n0 + r;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + 32 * tm + 8 * (i >> 2) + 4 * h + (i & 3);
+            if (m < a.M && n < a.N) a.slab[((long)quarter * a.M + m) * a.N + n] = acc[tm][i];
+        }
 }

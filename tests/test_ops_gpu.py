@@ -196,6 +196,42 @@ def test_gemm128_equals_mm32_bitwise(abi, M, K, hd):
     assert outs[1][1].abs().sum() > 0
 
 
+@pytest.mark.parametrize("M,K,hd", [(64, 2048, 64), (96, 2048, 64), (190, 2048, 64), (190, 8192, 64), (131, 1024, 128), (256, 2048, 64)])
+def test_prompt_kernels_give_the_same_bits_at_every_row_count(abi, M, K, hd):
+    """Prompts of 64..256 rows run k_mmt / k_mmq (several 32 x 32 output tiles per wave, residual projections as four
+    K-quarter slabs; kinds 31/33/34) instead of k_mm32 (kinds 11/13/14).  Same MFMA chains, same fold: SAME BITS --
+    a prompt row must not depend on how many rows share its prefill call."""
+    from oracle.csm_ref import LlamaShape, rope_table
+    g = torch.Generator().manual_seed(7 * M + K)
+    H, KV, smax = (8, 2, 640) if hd == 128 else (16, 4, 640)
+    x = dev(rnd((M, K), g))
+    N = 1024
+    w = dev(rnd((N, K), g, 0.02))
+    r = rnd((M, N), g)
+    r1, r2 = dev(r), dev(r)
+    op_gemv(abi, 11, x, w, out=r1, resid=r1); op_gemv(abi, 31, x, w, out=r2, resid=r2)
+    assert torch.equal(r1, r2), "linear + residual (quarter slabs + finisher)"
+    ffn = 1152                                                     # a multiple of 64 (the kernels' column group)
+    w1, w3 = dev(rnd((ffn, K), g, 0.05)), dev(rnd((ffn, K), g, 0.05))
+    a1 = torch.zeros(M, ffn, dtype=torch.bfloat16, device="cuda"); a2 = torch.zeros_like(a1)
+    op_gemv(abi, 14, x, w1, w1=w3, out=a1, N=ffn); op_gemv(abi, 34, x, w1, w1=w3, out=a2, N=ffn)
+    assert torch.equal(a1, a2), "swiglu"
+    assert a2.float().abs().sum() > 0
+    table = dev(rope_table(LlamaShape(1, H, KV, H * hd, 1024, max_seq_len=smax)))
+    wq, wk, wv = dev(rnd((H * hd, K), g, 0.02)), dev(rnd((KV * hd, K), g, 0.02)), dev(rnd((KV * hd, K), g, 0.02))
+    pos = dev(torch.arange(5, 5 + M), torch.int32)
+    outs = []
+    for kind in (13, 33):
+        q = torch.zeros(M, H * hd, dtype=torch.bfloat16, device="cuda")
+        kc = torch.zeros(1, KV, smax, hd, dtype=torch.bfloat16, device="cuda"); vc = torch.zeros_like(kc)
+        op_gemv(abi, kind, x, wq, w1=wk, w2=wv, out=q, ldo=H * hd, N=(H + 2 * KV) * hd, head_dim=hd, nq=H * hd,
+                nkv=KV * hd, kv_heads=KV, smax=smax, rows_per_seq=M, pos=pos, rope=table, kcache=kc, vcache=vc)
+        outs.append((q, kc, vc))
+    for t1, t2, what in zip(outs[0], outs[1], ("q", "k cache", "v cache")):
+        assert torch.equal(t1, t2), what
+    assert outs[1][1].abs().sum() > 0
+
+
 @pytest.mark.parametrize("H,KV,hd,nsplit", [(32, 8, 64, 1), (32, 8, 64, 8), (8, 2, 128, 1), (8, 2, 128, 3)])
 def test_attention(abi, H, KV, hd, nsplit):
     g = torch.Generator().manual_seed(H + hd + nsplit)
