@@ -343,25 +343,29 @@ __global__ __launch_bounds__(NW * 64) void k_mm32(const GemvArgs a, const int K,
             if (EPI == EPI_SWIGLU) cv[buf][q] = wld(wb + ((kc >> 6) * 4 + q) * 64 + lane);
         }
     };
-    load(0, kbeg);
-    for (int kc = kbeg; kc < kend; kc += 128) {
-        if (kc + 64 < kend) load(1, kc + 64);
+    auto mma = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[0][q]), wfrag_bf16x8(bv[0][q]), acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[buf][q]), wfrag_bf16x8(bv[buf][q]), acc0, 0, 0, 0);
             if (EPI == EPI_SWIGLU)
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[0][q]), wfrag_bf16x8(cv[0][q]), acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[buf][q]), wfrag_bf16x8(cv[buf][q]), acc1, 0, 0, 0);
         }
-        if (kc + 64 < kend) {
-            if (kc + 128 < kend) load(0, kc + 128);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[1][q]), wfrag_bf16x8(bv[1][q]), acc0, 0, 0, 0);
-                if (EPI == EPI_SWIGLU)
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(av[1][q]), wfrag_bf16x8(cv[1][q]), acc1, 0, 0, 0);
-            }
-        }
+    };
+    // No conditional load inside the steady-state loop (round 2): with `if (more) load(...)` in the body hipcc's wait-count
+    // pass merges both paths and put s_waitcnt vmcnt(0) in front of the MFMAs -- the chunk in flight was waited for as
+    // well, i.e. the double buffer prefetched nothing.  Same MFMA order as before: same bits.
+    load(0, kbeg);
+    int kc = kbeg;
+    for (; kc + 128 < kend; kc += 128) {
+        load(1, kc + 64);
+        mma(0);
+        __builtin_amdgcn_sched_barrier(0);
+        load(0, kc + 128);
+        mma(1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (kc + 64 < kend) { load(1, kc + 64); mma(0); mma(1); }
+    else mma(0);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {

@@ -26,13 +26,16 @@ def main():
     for _ in range(2):
         m.reset_caches(); m.prefill(tok, msk, pos)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    times = []
+    for _ in range(reps):                 # one prefill at a time (a queue of 10 x 100+ launches stalls the runtime for tens of ms)
+        t0 = time.perf_counter()
         m.reset_caches(); m.prefill(tok, msk, pos)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) * 1e3 / reps
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    times.sort()
+    ms = times[len(times) // 2]           # median
     flop = 2.0 * S * (16 * (2048 * 3072 + 2048 * 2048 + 3 * 2048 * 8192))
-    print(f"prefill S={S}: {ms:.3f} ms per call, {flop / ms / 1e9:.1f} TFLOP/s of projection work "
+    print(f"prefill S={S}: {ms:.3f} ms per call (median of {reps}, max {times[-1]:.2f}), {flop / ms / 1e9:.1f} TFLOP/s of projection work "
           f"(G128_MIN_ROWS={os.environ.get('CSM_G128_MIN_ROWS', 'default')})")
 
 
