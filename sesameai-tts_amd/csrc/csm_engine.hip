@@ -1022,7 +1022,9 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev_);
         const bool shape_ok = dc.n_layers == DP_NL && dc.dim == DP_D && dc.ffn == DP_FFN && dc.n_heads == 8 && dc.n_kv_heads == 2 &&
                               cfg->n_codebooks >= 3 && cfg->n_codebooks <= 32 && cfg->audio_vocab <= 2 * DP_LSLOTS && cfg->audio_vocab <= 2560;
-        if (!(ev && ev[0] == '0') && shape_ok && ncu >= DP_NB && m->qkv0_tab != nullptr && !w->fp8) {
+        // (fp8 mode too: the launch streams the bf16 weights, which there ARE the dequantised e4m3 values -- byte * scale is
+        //  exactly a bf16 -- so it computes what the fp8 chain computes; the decoder is bound by its hand-offs, not by bytes)
+        if (!(ev && ev[0] == '0') && shape_ok && ncu >= DP_NB && m->qkv0_tab != nullptr) {
             HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pg_q, (size_t)DP_NREP * 768 * 8));
             HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pg_h1, (size_t)DP_NREP * 512 * 8));
             HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pg_h2, (size_t)DP_NREP * 512 * 8));
