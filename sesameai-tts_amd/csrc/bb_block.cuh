@@ -1,0 +1,270 @@
+// Attention block of ONE backbone layer for a batch-1 decode step as ONE launch (round 2):
+//   RMSNorm -> q|k|v projections -> RoPE -> KV append -> attention over keys [0, p] -> output projection + residual
+// (sesameai/models.py:154-158 through torchtune's TransformerSelfAttentionLayer), CSM-1B backbone shape: d 2048, 32 heads /
+// 8 KV heads of 64.  It replaces three launches of the chain (k_gemv q|k|v 4.7 us, k_attn split-K 4.0, k_gemv merge +
+// o-proj 6.4, and the two gaps between them) with the hand-off machinery of the persistent depth decoder
+// (dec_persist.cuh): 256 workgroups, one per CU;
+//   * every wave issues ALL its weight loads at entry (a CU's slice is 6 q|k|v row pairs + 8 o-proj rows = 80 KB: it
+//     fits the register file, so the whole 21 MB of the block is in flight ~0.3 us after launch),
+//   * the 1536 (even, odd) q|k|v row pairs are one per wave (RoPE needs exactly that pair): 6 per CU, published as 8-byte
+//     {tag, bf16 pair} granules in 8 replicas; k / v pairs also go to the KV cache for later steps,
+//   * attention: CU h < 32 = head h, keys 0..p-1 from the cache (prefetched at entry: they do not depend on this step),
+//     key p from the granules; 8 waves x 8 key slots, fp32 online softmax (k_attn's arithmetic), merged through LDS,
+//   * the 2048 attention outputs travel as granules to every CU; wave w of CU c owns output row 8c + w.
+// Bounded spins (dp_give_up) -> *err.  Any position: keys beyond the BB_KMAX prefetched at entry are walked in further
+// rounds loaded on the spot.  Batches and the fp8 decode stream use the chain.
+#pragma once
+#include "dec_persist.cuh"
+
+#define BB_D 2048
+#define BB_HD 64
+#define BB_NH 32
+#define BB_NKV 8
+#define BB_KMAX 768                       // keys per round: 12 K (and V) loads per lane, 8 waves x 8 slots x 12
+#define BB_NQKV_PAIRS 1536
+
+struct BbBlockArgs {
+    const bf16_t *wq, *wk, *wv, *wo, *sa_norm;
+    const bf16_t* rope;                   // [max_seq][32][2]
+    bf16_t* h;                            // [2048] residual stream, updated in place
+    bf16_t *kc, *vc;                      // this layer's cache [8][smax][64]
+    const int* pos;                       // device: position of this step
+    int smax;
+    float eps;
+    dp_u64 *gQ, *gA;                      // [8][1536], [8][1024] granules
+    uint32_t *err, *epoch;
+    int poll_sleep;
+};
+
+#define BB_L_Q 0                          // LDS bytes: q head (128) | k_new (128) | v_new (128)
+#define BB_L_ATT 512                      // 4096: the attention output vector
+#define BB_L_PART 4608                    // 9 partials x (64 + 2) floats
+#define BB_L_MISC 7168                    // flags / counters
+#define BB_LDS_BYTES 7232
+#define BB_M_FQ 0
+#define BB_M_FATT 1
+#define BB_M_CNT 2
+#define BB_M_ABORT 3
+
+__device__ __forceinline__ float bb_sum8(float v) {           // sum over the 8 lanes of a key slot
+    v += dpp_f<0xB1, 0xF>(0.f, v);
+    v += dpp_f<0x4E, 0xF>(0.f, v);
+    v += dpp_f<0x141, 0xF>(0.f, v);
+    return v;
+}
+
+__device__ __forceinline__ bool bb_wait_flag(dp_lvu32* f, uint32_t tag, dp_lvu32* ab, uint32_t* err, uint32_t code, int lane) {
+    const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t spins = 1; *f != tag; ++spins) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 255u) == 0 && dp_give_up(t0, ab, err, code, lane)) return false;
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+
+__global__ __launch_bounds__(512) void k_bb_attn_block(const BbBlockArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[BB_LDS_BYTES];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cu = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    dp_lu32* misc = (dp_lu32*)(lds + BB_L_MISC);
+    dp_lvu32* ab = (dp_lvu32*)(misc + BB_M_ABORT);
+    if (threadIdx.x < 16) misc[threadIdx.x] = 0;
+    // ---- everything that does not depend on the step's position: issued now, in the order it is consumed ---------------
+    uint4 hv[4], g[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hv[i] = reinterpret_cast<const uint4*>(a.h)[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[i] = reinterpret_cast<const uint4*>(a.sa_norm)[i * 64 + lane];
+    const int orow = 8 * cu + wave;
+    const bf16_t hres = a.h[orow];
+    const int pair = 6 * cu + wave;                                   // waves 0..5: rows 2 pair, 2 pair + 1 of [q; k; v]
+    const int R0 = 2 * (wave < 6 ? pair : 0);
+    const bf16_t* wr = R0 < 2048 ? a.wq + (long)R0 * BB_D : R0 < 2560 ? a.wk + (long)(R0 - 2048) * BB_D : a.wv + (long)(R0 - 2560) * BB_D;
+    uint4 w0[4], w1[4], wo[4];
+    if (wave < 6) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { w0[i] = ldg16<true>(reinterpret_cast<const uint4*>(wr) + i * 64 + lane); w1[i] = ldg16<true>(reinterpret_cast<const uint4*>(wr + BB_D) + i * 64 + lane); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wo[i] = ldg16<true>(reinterpret_cast<const uint4*>(a.wo + (long)orow * BB_D) + i * 64 + lane);
+    const uint32_t base = *a.epoch;
+    const int p = min(max(*a.pos, 0), a.smax - 1);
+    // (cos, sin) of this wave's pair at position p
+    const int e0 = R0 % BB_HD;
+    const uint32_t cs = reinterpret_cast<const uint32_t*>(a.rope)[(long)p * (BB_HD / 2) + e0 / 2];
+    // attention CUs: K / V rows of keys 0..p-1 of this head's KV group.  Load j of wave w: keys 64 j + 8 w + (lane >> 3),
+    // 16-byte piece lane & 7 of each 128-byte row (8 rows = one contiguous 1 KB per wave load)
+    const bool attn_cu = cu < BB_NH;
+    const int slot = lane >> 3, e8 = lane & 7;
+    uint4 kr[BB_KMAX / 64], vr[BB_KMAX / 64];
+    if (attn_cu) {
+        const int kvh = cu / (BB_NH / BB_NKV);
+        const bf16_t* kb = a.kc + (long)kvh * a.smax * BB_HD;
+        const bf16_t* vb = a.vc + (long)kvh * a.smax * BB_HD;
+#pragma unroll
+        for (int j = 0; j < BB_KMAX / 64; ++j) {
+            // (slots past the last key re-read key p - 1: finite values, weight 0; with p == 0 the round loop does not run)
+            const int key = min(64 * j + 8 * wave + slot, max(p - 1, 0));
+            kr[j] = *reinterpret_cast<const uint4*>(kb + (long)key * BB_HD + e8 * 8);
+            vr[j] = *reinterpret_cast<const uint4*>(vb + (long)key * BB_HD + e8 * 8);
+        }
+    }
+    __syncthreads();                                                   // (misc zeroed; also the one full vmcnt(0) of the kernel)
+    const uint32_t tagQ = base + 1u, tagA = base + 2u;
+
+    // ---- RMSNorm of the whole row, per wave, in registers (chunk i * 64 + lane = elements 8 (i * 64 + lane) ..) ---------
+    uint4 xn[4];
+    {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ss += dp_chunk_ss(hv[i]);
+        ss = wave_sum(ss);
+        const float r = 1.0f / sqrtf(ss / (float)BB_D + a.eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xn[i] = dp_chunk_norm(hv[i], g[i], r);
+    }
+    // ---- q | k | v pair of this wave -> RoPE -> granule (8 replicas) + KV cache ----------------------------------------
+    if (wave < 6) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a0 = dot8(w0[i], xn[i], a0); a1 = dot8(w1[i], xn[i], a1); }
+        a0 = wave_sum(a0); a1 = wave_sum(a1);
+        const uint32_t outw = dp_rope_pair(a0, a1, cs, R0 < 2560);
+        if (lane < DP_NREP) dp_gran_store(a.gQ + lane * BB_NQKV_PAIRS + pair, tagQ, outw);
+        if (R0 >= 2048 && lane == 0) {
+            const int rk = R0 < 2560 ? R0 - 2048 : R0 - 2560;            // row inside k or v: KV head rk / 64, element rk % 64
+            bf16_t* dst = (R0 < 2560 ? a.kc : a.vc) + ((long)(rk / BB_HD) * a.smax + p) * BB_HD + rk % BB_HD;
+            *reinterpret_cast<uint32_t*>(dst) = outw;
+        }
+    }
+    // ---- attention (CUs 0..31) -----------------------------------------------------------------------------------------
+    if (attn_cu) {
+        const int kvh = cu / (BB_NH / BB_NKV);
+        dp_lf32* part = (dp_lf32*)(lds + BB_L_PART);
+        if (wave == 7) {
+            // q of head cu (pairs 32 cu ..), k_new / v_new of KV head kvh (pairs 1024 + 32 kvh .., 1280 + 32 kvh ..)
+            const dp_u64* rg = a.gQ + (cu % DP_NREP) * BB_NQKV_PAIRS;
+            const int i0 = lane < 32 ? 32 * cu + lane : 1024 + 32 * kvh + (lane - 32);
+            const int i1 = 1280 + 32 * kvh + (lane & 31);
+            const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
+            uint32_t v0, v1;
+            for (;;) {
+                const dp_u64 x0 = dp_gran_load(rg + i0), x1 = dp_gran_load(rg + i1);
+                v0 = (uint32_t)x0; v1 = (uint32_t)x1;
+                if (__all((uint32_t)(x0 >> 32) == tagQ && (uint32_t)(x1 >> 32) == tagQ)) break;
+                if (dp_give_up(t0, ab, a.err, 0xC01u, lane)) return;
+                for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+            }
+            ((dp_lu32*)(lds + BB_L_Q))[lane] = v0;                       // q (words 0..31) | k_new (32..63)
+            if (lane < 32) ((dp_lu32*)(lds + BB_L_Q))[64 + lane] = v1;    // v_new
+            dp_flag((dp_lvu32*)(misc + BB_M_FQ), tagQ);
+        } else if (!bb_wait_flag((dp_lvu32*)(misc + BB_M_FQ), tagQ, ab, a.err, 0xC02u, lane)) return;
+        const uint4 qv = dp_ldq((const dp_lu4*)(lds + BB_L_Q) + e8);
+        float mx = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+        // keys 0..p-1 in rounds of BB_KMAX: round 0 is the set prefetched at entry, later rounds (p > BB_KMAX) load here
+        for (int k0 = 0; k0 < p; k0 += BB_KMAX) {
+            if (k0 > 0) {
+                const bf16_t* kb = a.kc + (long)kvh * a.smax * BB_HD;
+                const bf16_t* vb = a.vc + (long)kvh * a.smax * BB_HD;
+#pragma unroll
+                for (int j = 0; j < BB_KMAX / 64; ++j) {
+                    const int key = min(k0 + 64 * j + 8 * wave + slot, p - 1);
+                    kr[j] = *reinterpret_cast<const uint4*>(kb + (long)key * BB_HD + e8 * 8);
+                    vr[j] = *reinterpret_cast<const uint4*>(vb + (long)key * BB_HD + e8 * 8);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < BB_KMAX / 64; ++j) {
+                const bool live = k0 + 64 * j + 8 * wave + slot < p;
+                float s = bb_sum8(dot8(qv, kr[j], 0.f)) * 0.125f;
+                s = live ? s : -INFINITY;
+                const float mn = fmaxf(mx, s);
+                const float corr = (mx == -INFINITY) ? 0.f : __expf(mx - mn);
+                const float pw = live ? __expf(s - mn) : 0.f;
+                l = l * corr + pw;
+                o[0] = o[0] * corr + pw * lo2f(vr[j].x); o[1] = o[1] * corr + pw * hi2f(vr[j].x);
+                o[2] = o[2] * corr + pw * lo2f(vr[j].y); o[3] = o[3] * corr + pw * hi2f(vr[j].y);
+                o[4] = o[4] * corr + pw * lo2f(vr[j].z); o[5] = o[5] * corr + pw * hi2f(vr[j].z);
+                o[6] = o[6] * corr + pw * lo2f(vr[j].w); o[7] = o[7] * corr + pw * hi2f(vr[j].w);
+                mx = live ? mn : mx;
+            }
+        }
+        // merge the 8 key slots of the wave (lanes sharing e8)
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            const float mo = __shfl_xor(mx, off, WAVE), lo = __shfl_xor(l, off, WAVE);
+            const float mn = fmaxf(mx, mo);
+            const float c0 = (mx == -INFINITY) ? 0.f : __expf(mx - mn), c1 = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+            l = l * c0 + lo * c1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float oo = __shfl_xor(o[i], off, WAVE); o[i] = o[i] * c0 + oo * c1; }
+            mx = mn;
+        }
+        if (slot == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) part[wave * 66 + e8 * 8 + i] = o[i];
+            if (e8 == 0) { part[wave * 66 + 64] = mx; part[wave * 66 + 65] = l; }
+        }
+        if (wave == 7) {
+            // the step's own key (position p): one more partial with a single key
+            const uint4 kn = dp_ldq((const dp_lu4*)(lds + BB_L_Q + 128) + e8), vn = dp_ldq((const dp_lu4*)(lds + BB_L_Q + 256) + e8);
+            const float s = bb_sum8(dot8(qv, kn, 0.f)) * 0.125f;
+            if (slot == 1) {
+            part[8 * 66 + e8 * 8 + 0] = lo2f(vn.x); part[8 * 66 + e8 * 8 + 1] = hi2f(vn.x);
+            part[8 * 66 + e8 * 8 + 2] = lo2f(vn.y); part[8 * 66 + e8 * 8 + 3] = hi2f(vn.y);
+            part[8 * 66 + e8 * 8 + 4] = lo2f(vn.z); part[8 * 66 + e8 * 8 + 5] = hi2f(vn.z);
+            part[8 * 66 + e8 * 8 + 6] = lo2f(vn.w); part[8 * 66 + e8 * 8 + 7] = hi2f(vn.w);
+            if (e8 == 0) { part[8 * 66 + 64] = s; part[8 * 66 + 65] = 1.0f; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(misc + BB_M_CNT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (wave == 0) {
+            const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
+            for (uint32_t spins = 1; *(dp_lvu32*)(misc + BB_M_CNT) < 8u; ++spins) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 255u) == 0 && dp_give_up(t0, ab, a.err, 0xC03u, lane)) return;
+            }
+            asm volatile("" ::: "memory");
+            // lane = output dimension: fold the 9 partials in order
+            float M = -INFINITY, L = 0.f, O = 0.f;
+#pragma unroll
+            for (int w = 0; w < 9; ++w) {
+                const float mw = part[w * 66 + 64], lw = part[w * 66 + 65], ow = part[w * 66 + lane];
+                const float mn = fmaxf(M, mw);
+                const float c0 = (M == -INFINITY) ? 0.f : __expf(M - mn), c1 = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
+                L = L * c0 + lw * c1; O = O * c0 + ow * c1; M = mn;
+            }
+            const float y = O / L;
+            const float yn = __shfl_xor(y, 1, WAVE);
+            if ((lane & 1) == 0) {
+                const uint32_t pw = pack_bf(y, yn);
+#pragma unroll
+                for (int rep = 0; rep < DP_NREP; ++rep) dp_gran_store(a.gA + rep * 1024 + 32 * cu + (lane >> 1), tagA, pw);
+            }
+        }
+    }
+    // ---- every CU: the attention vector -> o-projection row 8 cu + wave + residual ----------------------------------------
+    if (wave == 7) {
+        uint32_t v[16];
+        if (!dp_sweep<8>(a.gA + (cu % DP_NREP) * 1024, 1024, tagA, v, lane, ab, a.err, 0xC04u, a.poll_sleep)) return;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ((dp_lu32*)(lds + BB_L_ATT))[2 * (j * 64 + lane)] = v[2 * j]; ((dp_lu32*)(lds + BB_L_ATT))[2 * (j * 64 + lane) + 1] = v[2 * j + 1]; }
+        dp_flag((dp_lvu32*)(misc + BB_M_FATT), tagA);
+    } else if (!bb_wait_flag((dp_lvu32*)(misc + BB_M_FATT), tagA, ab, a.err, 0xC05u, lane)) return;
+    {
+        const dp_lu4* xs = (const dp_lu4*)(lds + BB_L_ATT);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = dot8(wo[i], dp_ldq(xs + i * 64 + lane), acc);
+        acc = wave_sum(acc);
+        if (lane == 0) {
+#pragma clang fp contract(off)
+            a.h[orow] = f2bf(round_bf(acc) + bf2f(hres));
+        }
+    }
+    if (cu == 0 && threadIdx.x == 0) *a.epoch = base + 4u;
+}

@@ -21,6 +21,7 @@
 #include "attn_flash.cuh"
 #include "sampler.cuh"
 #include "dec_persist.cuh"
+#include "bb_block.cuh"
 
 #define BB_NSPLIT_MAX 8
 #define PART_ROWS 32
@@ -78,6 +79,10 @@ struct CsmModel {
     bool persist;
     dp_u64 *pg_q, *pg_h1, *pg_h2, *pg_l, *pg_p;
     uint32_t* p_state;                  // [0] tag epoch, [1] give-up code of the last launch (0 = ok)
+    // backbone attention block of a batch-1 decode step as one launch per layer (bb_block.cuh)
+    bool bb_block;
+    dp_u64 *bg_q, *bg_a;
+    uint32_t* b_state;                  // [0] tag epoch, [1] give-up code
     uint4* p_w2s[DP_NL];
     uint4* p_w13p[DP_NL];
     int p_trickle, p_poll;
@@ -578,11 +583,23 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
             a.w0 = (const bf16_t*)S.w8[l].wq; a.w1 = (const bf16_t*)S.w8[l].wk; a.w2 = (const bf16_t*)S.w8[l].wv;
             a.s0 = (const float*)S.w8s[l].wq; a.s1 = (const float*)S.w8s[l].wk; a.s2 = (const float*)S.w8s[l].wv;
         }
+        bool block_done = false;
+        if (&S == &m->bb && M == 1 && m->bb_block && !f8 && pos != nullptr) {
+            // (1)-(3) as ONE launch (bb_block.cuh): q|k|v + RoPE + KV append -> attention -> o-projection + residual
+            BbBlockArgs b;
+            memset(&b, 0, sizeof b);
+            b.wq = (const bf16_t*)w.wq; b.wk = (const bf16_t*)w.wk; b.wv = (const bf16_t*)w.wv; b.wo = (const bf16_t*)w.wo;
+            b.sa_norm = (const bf16_t*)w.sa_norm; b.rope = S.rope; b.h = h; b.kc = kc; b.vc = vc; b.pos = pos; b.smax = S.cache_len;
+            b.eps = S.d.norm_eps; b.gQ = m->bg_q; b.gA = m->bg_a; b.err = m->b_state + 1; b.epoch = m->b_state; b.poll_sleep = m->p_poll > 0 ? m->p_poll : 2;
+            hipLaunchKernelGGL(k_bb_attn_block, dim3(DP_NB), dim3(512), 0, st, b);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            block_done = true;
+        }
         // (layer 0 of a depth-decoder step >= 2: the sampler already gathered q/k/v from the precomputed table)
-        if (!(l == 0 && qkv0_done) && (e = f8 ? launch_gemv8(3, d, S.hd, a, st) : launch_gemv(3, d, S.hd, a, st)) != hipSuccess) return e;
+        if (!block_done && !(l == 0 && qkv0_done) && (e = f8 ? launch_gemv8(3, d, S.hd, a, st) : launch_gemv(3, d, S.hd, a, st)) != hipSuccess) return e;
         bool fuse_comb = false;
         const bool fuse_attn = S.hd == 128 && S.cache_len <= 32 && m->fuse_dec_attn && (S.d.n_heads / S.d.n_kv_heads) % 2 == 0;
-        if (!fuse_attn) {
+        if (!fuse_attn && !block_done) {
             // (2) attention over keys [0, pos]
             AttnArgs t;
             t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
@@ -602,7 +619,7 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
         }
         if (fuse_comb) { a.part = m->part; a.nsplit = nsplit; a.aH = S.d.n_heads; }
         if (f8) { a.w0 = (const bf16_t*)S.w8[l].wo; a.s0 = (const float*)S.w8s[l].wo; }
-        {
+        if (!block_done) {
             const int kind = fuse_attn ? 5 : (fuse_comb ? 6 : 1);
             if ((e = f8 ? launch_gemv8(kind, S.nq, S.hd, a, st) : launch_gemv(kind, S.nq, S.hd, a, st)) != hipSuccess) return e;
         }
@@ -1054,6 +1071,25 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
         }
     }
     m->p_stamps = nullptr;
+    // ---- backbone attention block: the CSM-1B backbone shape on a 256-CU device, bf16 weight stream ----
+    m->bb_block = false;
+    {
+        const char* ev = getenv("CSM_BB_BLOCK");
+        const CsmLlamaDims& bc = cfg->backbone;
+        int ncu = 0, dev_ = 0;
+        (void)hipGetDevice(&dev_);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev_);
+        if (!(ev && ev[0] == '0') && bc.dim == BB_D && bc.n_heads == BB_NH && bc.n_kv_heads == BB_NKV && ncu >= DP_NB && !w->fp8) {
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->bg_q, (size_t)DP_NREP * BB_NQKV_PAIRS * 8));
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->bg_a, (size_t)DP_NREP * 1024 * 8));
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->b_state, 16));
+            HIPCHK((CsmModel*)nullptr, hipMemset(m->bg_q, 0, (size_t)DP_NREP * BB_NQKV_PAIRS * 8));
+            HIPCHK((CsmModel*)nullptr, hipMemset(m->bg_a, 0, (size_t)DP_NREP * 1024 * 8));
+            HIPCHK((CsmModel*)nullptr, hipMemset(m->b_state, 0, 16));
+            HIPCHK((CsmModel*)nullptr, hipDeviceSynchronize());
+            m->bb_block = true;
+        }
+    }
     *out = m;
     return CSM_OK;
 }
@@ -1068,6 +1104,7 @@ extern "C" void csm_destroy(csm_handle m) {
                     m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos, m->qkv0_tab};
     for (void* p : ptrs) (void)hipFree(p);
     for (void* p : m->pk_allocs) (void)hipFree(p);
+    if (m->bb_block) { (void)hipFree(m->bg_q); (void)hipFree(m->bg_a); (void)hipFree(m->b_state); }
     if (m->persist) {
         void* pp[] = {m->pg_q, m->pg_h1, m->pg_h2, m->pg_l, m->pg_p, m->p_state, m->p_w2s[0], m->p_w2s[1], m->p_w2s[2], m->p_w2s[3],
                       m->p_w13p[0], m->p_w13p[1], m->p_w13p[2], m->p_w13p[3]};
@@ -1189,8 +1226,15 @@ extern "C" int csm_read_frames(csm_handle m, int B, int first, int n, int32_t* h
     int overflow = 0;
     uint32_t pcode = 0;
     HIPCHK(m, hipMemcpyAsync(&overflow, m->n_frames + 1, 4, hipMemcpyDeviceToHost, st));
+    uint32_t bcode = 0;
     if (m->persist) HIPCHK(m, hipMemcpyAsync(&pcode, m->p_state + 1, 4, hipMemcpyDeviceToHost, st));
+    if (m->bb_block) HIPCHK(m, hipMemcpyAsync(&bcode, m->b_state + 1, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(m, hipStreamSynchronize(st));
+    if (bcode) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "backbone attention-block launch gave up waiting (code 0x%x): frames are invalid; set CSM_BB_BLOCK=0", bcode);
+        return fail(m, CSM_E_HIP, buf);
+    }
     if (pcode) {
         char buf[160];
         snprintf(buf, sizeof buf, "persistent depth-decoder launch gave up waiting (code 0x%x): frames are invalid; set CSM_PERSIST=0", pcode);

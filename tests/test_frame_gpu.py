@@ -957,6 +957,50 @@ def test_persistent_decoder_vs_launch_chain_and_golden(csm1b, monkeypatch):
     #  the sampler INSIDE the launch is the reference's: next test)
 
 
+def test_backbone_attention_block_vs_launch_chain(csm1b, monkeypatch):
+    """Batch-1 decode steps run q|k|v -> attention -> o-projection of every backbone layer as ONE launch
+    (csrc/bb_block.cuh) instead of three.  Same rounding points, different fp32 summation orders (per-wave RMSNorm sums,
+    attention over 8 waves x 8 key slots instead of split-K blocks): teacher-forced on the golden codes through the
+    graph step, the logits of both paths must agree within the oracle's own bf16-vs-fp32 gap and greedy picks may differ
+    only at near-ties.  Also at a long context (keys beyond the 768 prefetched at kernel entry)."""
+    from sesameai.models import Model, csm_1b_args
+    gold, sd = csm1b
+    tok, msk = gold["prompt_tokens"], gold["prompt_mask"]
+    S = tok.shape[0]
+    noise = float(gold["bf16_vs_fp32_gap"].max())
+    g = torch.Generator().manual_seed(5)
+    long_S = 900
+    ltok = torch.zeros(long_S, 33, dtype=torch.long); ltok[:, :32] = torch.randint(0, 2048, (long_S, 32), generator=g)
+    lmsk = torch.ones(long_S, 33, dtype=torch.bool); lmsk[:, 32] = False
+    outs = {}
+    for name, env in (("block", "1"), ("chain", "0")):
+        monkeypatch.setenv("CSM_BB_BLOCK", env)
+        m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=1024)
+        m.setup_caches(1)
+        res = []
+        for (t_, m_, S_) in ((tok, msk, S), (ltok, lmsk, long_S)):
+            m.reset_caches()
+            m.prefill(t_.unsqueeze(0), m_.unsqueeze(0), torch.arange(S_).unsqueeze(0))
+            m.depth(1, 1.0, 1, forced=gold["codes"][0].unsqueeze(0), commit=True)
+            for f in range(1, 4):
+                row = torch.zeros(1, 1, 33, dtype=torch.long); row[0, 0, :32] = gold["codes"][f - 1].long()
+                rmask = torch.ones(1, 1, 33, dtype=torch.bool); rmask[0, 0, 32] = False
+                m.prefill(row, rmask, torch.tensor([[S_ + f - 1]]))          # one-row decode step of the backbone (narrow path)
+                out, logits = m.depth(1, 1.0, 1, forced=gold["codes"][f].unsqueeze(0), want_logits=True, commit=False)
+                res.append((out.cpu(), logits[:, 0].float().cpu()))
+        outs[name] = res
+        del m
+    worst = 0.0
+    for (ob, lb), (oc, lc) in zip(outs["block"], outs["chain"]):
+        worst = max(worst, (lb - lc).abs().max().item())
+        top2 = torch.topk(lc, 2, dim=-1)[0]
+        for cb in (ob[0] != oc[0]).nonzero().flatten().tolist():
+            assert float(top2[cb, 0] - top2[cb, 1]) <= 2 * noise, f"codebook {cb}: greedy index differs away from a tie"
+    print(f"backbone block vs chain: max|dlogit| = {worst:.4f} (oracle noise floor {noise:.4f})")
+    assert worst > 0.0, "both runs took the same path"
+    assert worst <= noise
+
+
 def test_persistent_decoder_samples_like_the_oracle_on_its_own_logits(csm1b):
     """The sampler runs inside the persistent launch (on every CU alike).  Given Exp(1) noise, its picks for codebooks
     2..31 must be the oracle's sample_topk of the very logits the launch produced (misses only at 1-ulp ties of p/q),
