@@ -110,7 +110,8 @@ __global__ __launch_bounds__(512) void k_bb_attn_block(const BbBlockArgs a) {
             vr[j] = *reinterpret_cast<const uint4*>(vb + (long)key * BB_HD + e8 * 8);
         }
     }
-    __syncthreads();                                                   // (misc zeroed; also the one full vmcnt(0) of the kernel)
+    // (misc zeroed.  A bare s_barrier: __syncthreads() would also wait for every load issued above)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const uint32_t tagQ = base + 1u, tagA = base + 2u;
 
     // ---- RMSNorm of the whole row, per wave, in registers (chunk i * 64 + lane = elements 8 (i * 64 + lane) ..) ---------
