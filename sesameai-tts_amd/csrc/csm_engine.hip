@@ -670,6 +670,8 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             p.gQ = m->pg_q; p.gH1 = m->pg_h1; p.gH2 = m->pg_h2; p.gL = m->pg_l; p.gP = m->pg_p;
             p.err = m->p_state + 1; p.epoch = m->p_state; p.eps = c.decoder.norm_eps; p.trickle_sleep = m->p_trickle; p.poll_sleep = m->p_poll;
             p.stamps = m->p_stamps;
+            { static int faults_left = getenv("CSM_PERSIST_FAULT") ? atoi(getenv("CSM_PERSIST_FAULT")) : 0;     // timeline build: the first n launches withhold a granule
+              p.fault = faults_left > 0 ? 1 : 0; if (faults_left > 0) --faults_left; }
             hipLaunchKernelGGL(k_dec_persist, dim3(DP_NB), dim3(512), DP_LDS_BYTES, st, p);
             return hipGetLastError();
         }
@@ -1115,9 +1117,17 @@ extern "C" void csm_destroy(csm_handle m) {
 
 extern "C" const char* csm_last_error(csm_handle m) { return m ? m->err.c_str() : g_create_err.c_str(); }
 
+// After a launch that gave up (bounded spin timed out) stale granules may carry tags the next launch would accept: move the
+// tag epoch far ahead and clear the error word, so the handle is usable again after csm_reset.
+__global__ void k_persist_recover(uint32_t* state) {
+    if (state[1] != 0u) { state[0] += 0x100000u; state[1] = 0u; }
+}
+
 extern "C" int csm_reset(csm_handle m, void* stream) {
     if (!m) return CSM_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    if (m->persist) hipLaunchKernelGGL(k_persist_recover, dim3(1), dim3(1), 0, st, m->p_state);
+    if (m->bb_block) hipLaunchKernelGGL(k_persist_recover, dim3(1), dim3(1), 0, st, m->b_state);
     HIPCHK(m, hipMemsetAsync(m->n_frames, 0, 8, st));          // frame counter + position-overflow flag
     HIPCHK(m, hipMemsetAsync(m->cur_pos, 0, (size_t)m->max_batch * 4, st));
     HIPCHK(m, hipMemsetAsync(m->eos_at, 0xff, (size_t)m->max_batch * 4, st));

@@ -75,6 +75,7 @@ struct DecPersistArgs {
     uint32_t* epoch;
     float eps;
     int trickle_sleep, poll_sleep;
+    int fault;                        // timeline build only (CSM_PERSIST_FAULT=1): see DP_FAULT
     dp_u64* stamps;                   // optional (csm_debug_persist_stamps): s_memrealtime of workgroup 100's gather wave, [step][32]
 };
 
@@ -83,8 +84,10 @@ struct DecPersistArgs {
 // build every stamp folds away -- ~170 sites whose stores otherwise put waits and SGPR pressure into the compute waves.
 #ifdef DP_TIMELINE
 #define DP_STAMPS(a_) ((a_).stamps)
+#define DP_FAULT(a_) ((a_).fault)            // fault injection (tests): one workgroup withholds one hand-off granule
 #else
 #define DP_STAMPS(a_) ((dp_u64*)nullptr)
+#define DP_FAULT(a_) 0
 #endif
 #define DP_OFF_K 0                                   // [4][2][32][128] bf16
 #define DP_OFF_V 65536
@@ -480,7 +483,8 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
                 const uint32_t h0w = *(dp_lvu32*)(misc + DP_M_H0 + (wave - 5));
                 const uint32_t outw = dp_resid_pair(a0, a1, h0w);
                 if (lane == 0) misc[DP_M_H1 + (wave - 5)] = outw;
-                if (lane < DP_NREP) dp_gran_store(a.gH1 + lane * 512 + unit, dp_tag(base, s, l, DP_E_H1), outw);
+                if (lane < DP_NREP && !(DP_FAULT(a) && s == 3 && l == 1 && cu == 17))
+                    dp_gran_store(a.gH1 + lane * 512 + unit, dp_tag(base, s, l, DP_E_H1), outw);
                 if (DP_STAMPS(a) != nullptr && cu == 100 && lane == 0 && wave == 5 && l == 2) DP_STAMPS(a)[4096 + s * 8 + 2] = __builtin_amdgcn_s_memrealtime();
             }
             {

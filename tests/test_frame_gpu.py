@@ -957,6 +957,57 @@ def test_persistent_decoder_vs_launch_chain_and_golden(csm1b, monkeypatch):
     #  the sampler INSIDE the launch is the reference's: next test)
 
 
+_FAULT_SCRIPT = r"""
+import os, sys, time
+os.environ["CSM_HIP_TIMELINE"] = "1"          # the library build that carries the fault-injection hook
+os.environ["CSM_PERSIST_FAULT"] = "1"         # the first persistent launch withholds one hand-off granule
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "sesameai-tts_amd"))
+import torch
+from sesameai.models import Model, csm_1b_args, synthetic_state_dict
+margs = csm_1b_args()
+m = Model(margs, synthetic_state_dict(margs, seed=1234), max_frames=16, max_prefill_rows=256)
+m.setup_caches(1); m.seed(3)
+g = torch.Generator().manual_seed(0)
+S = 20
+tok = torch.zeros(1, S, 33, dtype=torch.long); tok[0, :, :32] = torch.randint(0, 2048, (S, 32), generator=g)
+msk = torch.ones(1, S, 33, dtype=torch.bool); msk[0, :, 32] = False
+def run():
+    m.reset_caches(); m.seed(3)
+    m.prefill(tok, msk, torch.arange(S).unsqueeze(0))
+    m.depth(1, 0.9, 50, commit=True)
+    for _ in range(3): m.step(1, 0.9, 50)
+    return m.read_frames(1)[0].clone()
+t0 = time.perf_counter()
+try:
+    run(); torch.cuda.synchronize()
+    print("NO_ERROR")
+except RuntimeError as e:
+    print("ERROR_OK" if "gave up" in str(e) else "OTHER_ERROR " + str(e), f"{time.perf_counter() - t0:.2f}s")
+a = run(); b = run()
+print("RECOVERED" if torch.equal(a, b) and int(a.abs().sum()) > 0 else "NOT_RECOVERED")
+"""
+
+
+def test_persistent_launch_gives_up_instead_of_hanging_and_the_handle_recovers(tmp_path):
+    """Every spin of the persistent launch is bounded: with one hand-off granule withheld (fault injection of the
+    timeline build, CSM_PERSIST_FAULT) the launch must END within its 50 ms budget, read_frames must report it
+    (CSM_E_HIP, "gave up"), and after reset_caches the same handle must generate again (the tag epoch moves past
+    whatever the aborted launch left in the granule buffers)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "sesameai-tts_amd", "lib", "libcsm_hip_timeline.so")
+    if not os.path.exists(lib):
+        pytest.skip("libcsm_hip_timeline.so not built (make -C sesameai-tts_amd/csrc timeline)")
+    script = tmp_path / "fault.py"
+    script.write_text(_FAULT_SCRIPT)
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=240)
+    out = r.stdout
+    assert "ERROR_OK" in out, f"the faulted launch was not reported:\n{out}\n{r.stderr[-2000:]}"
+    assert "RECOVERED" in out and "NOT_RECOVERED" not in out, f"the handle did not recover:\n{out}\n{r.stderr[-2000:]}"
+
+
 def test_backbone_attention_block_vs_launch_chain(csm1b, monkeypatch):
     """Batch-1 decode steps run q|k|v -> attention -> o-projection of every backbone layer as ONE launch
     (csrc/bb_block.cuh) instead of three.  Same rounding points, different fp32 summation orders (per-wave RMSNorm sums,
