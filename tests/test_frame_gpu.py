@@ -1087,3 +1087,26 @@ def test_persistent_decoder_samples_like_the_oracle_on_its_own_logits(csm1b):
         total += 32; agree += 32 - int(bad.numel())
     print(f"sampler inside the persistent launch: {agree}/{total} picks identical to the oracle's on the launch's logits")
     assert agree / total >= 0.95
+
+
+def test_model_from_pretrained_reads_reference_and_transformers_checkpoints(tmp_path, csm1b):
+    """Model.from_pretrained (reference: PyTorchModelHubMixin.from_pretrained("sesame/csm-1b"), sesameai/generator.py:338):
+    a local model.safetensors in the reference's (torchtune) tensor names gives the same frames as the state dict
+    itself.  (The transformers-format branch is the name / RoPE-row conversion tested in test_host_logic.)"""
+    from safetensors.torch import save_file
+    from sesameai.models import Model, csm_1b_args
+    gold, sd = csm1b
+    d = tmp_path / "csm-1b"
+    d.mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "model.safetensors"))
+    tok, msk = gold["prompt_tokens"], gold["prompt_mask"]
+    S = tok.shape[0]
+    outs = []
+    for m in (Model.from_pretrained(str(d), device="cuda", max_frames=8, max_prefill_rows=64),
+              Model(csm_1b_args(), sd, max_frames=8, max_prefill_rows=64)):
+        m.setup_caches(1)
+        m.prefill(tok.unsqueeze(0), msk.unsqueeze(0), torch.arange(S).unsqueeze(0))
+        out, logits = m.depth(1, 1.0, 1, want_logits=True, commit=False)
+        outs.append((out.cpu(), logits.cpu()))
+        del m
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -351,6 +351,37 @@ def test_generator_batch_stops_when_every_sequence_has_hit_eos():
     assert frames.shape[0] == 30 and gen.last_eos_at.tolist() == [5, -1, 12]
 
 
+def moshi_name(n: str, ns: int) -> str:
+    """canonical tensor name (sesameai.mimi.state_dict_layout) -> its name in a moshi 0.2.2 Mimi checkpoint, written out from
+    moshi's module tree (ns = number of SEANet stages)"""
+    p = n.split(".")
+    if p[0] == "rvq":
+        k = int(p[1]); base = "quantizer.rvq_first.vq.layers.0" if k == 0 else f"quantizer.rvq_rest.vq.layers.{k - 1}"
+        return f"{base}._codebook.{p[2]}"
+    if n in ("rvq_first.output_proj.weight", "rvq_rest.output_proj.weight", "rvq_first.input_proj.weight", "rvq_rest.input_proj.weight"):
+        return "quantizer." + n
+    if n == "upsample.convtr.weight": return "upsample.convtr.convtr.convtr.weight"
+    if n == "downsample.conv.weight": return "downsample.conv.conv.conv.weight"
+    if p[0] in ("transformer", "enc_transformer"):
+        pre = ("decoder_transformer" if p[0] == "transformer" else "encoder_transformer") + f".transformer.layers.{p[1]}."
+        tail = ".".join(p[2:])
+        tail = {"in_proj_weight": "self_attn.in_proj_weight", "out_proj.weight": "self_attn.out_proj.weight"}.get(tail, tail)
+        return pre + tail
+    if p[0] == "seanet":
+        if p[1] == "conv_in": return f"decoder.model.0.conv.conv.{p[2]}"
+        if p[1] == "conv_out": return f"decoder.model.{2 + 3 * ns}.conv.conv.{p[2]}"
+        j = int(p[2])
+        if p[3] == "convtr": return f"decoder.model.{2 + 3 * j}.convtr.convtr.{p[4]}"
+        return f"decoder.model.{3 + 3 * j}.block.{1 if p[4] == 'conv1' else 3}.conv.conv.{p[5]}"
+    if p[0] == "enc":
+        if p[1] == "conv_in": return f"encoder.model.0.conv.conv.{p[2]}"
+        if p[1] == "conv_out": return f"encoder.model.{2 + 3 * ns}.conv.conv.{p[2]}"
+        j = int(p[2])
+        if p[3] == "conv": return f"encoder.model.{3 + 3 * j}.conv.conv.{p[4]}"
+        return f"encoder.model.{1 + 3 * j}.block.{1 if p[4] == 'conv1' else 3}.conv.conv.{p[5]}"
+    raise AssertionError(n)
+
+
 def test_moshi_checkpoint_name_map_round_trip():
     """from_moshi_state_dict maps every decode- AND encode-side tensor (name and shape) of a moshi-format Mimi
     checkpoint; the inverse map below is written out independently from moshi 0.2.2's module tree."""
@@ -360,35 +391,7 @@ def test_moshi_checkpoint_name_map_round_trip():
         canon = {n: torch.empty(shp, dtype=torch.float32).fill_(float(i)) for i, (n, shp, _) in enumerate(names)}
         ns = len(s.ratios)
 
-        def moshi_name(n: str) -> str:
-            p = n.split(".")
-            if p[0] == "rvq":
-                k = int(p[1]); base = "quantizer.rvq_first.vq.layers.0" if k == 0 else f"quantizer.rvq_rest.vq.layers.{k - 1}"
-                return f"{base}._codebook.{p[2]}"
-            if n in ("rvq_first.output_proj.weight", "rvq_rest.output_proj.weight", "rvq_first.input_proj.weight", "rvq_rest.input_proj.weight"):
-                return "quantizer." + n
-            if n == "upsample.convtr.weight": return "upsample.convtr.convtr.convtr.weight"
-            if n == "downsample.conv.weight": return "downsample.conv.conv.conv.weight"
-            if p[0] in ("transformer", "enc_transformer"):
-                pre = ("decoder_transformer" if p[0] == "transformer" else "encoder_transformer") + f".transformer.layers.{p[1]}."
-                tail = ".".join(p[2:])
-                tail = {"in_proj_weight": "self_attn.in_proj_weight", "out_proj.weight": "self_attn.out_proj.weight"}.get(tail, tail)
-                return pre + tail
-            if p[0] == "seanet":
-                if p[1] == "conv_in": return f"decoder.model.0.conv.conv.{p[2]}"
-                if p[1] == "conv_out": return f"decoder.model.{2 + 3 * ns}.conv.conv.{p[2]}"
-                j = int(p[2])
-                if p[3] == "convtr": return f"decoder.model.{2 + 3 * j}.convtr.convtr.{p[4]}"
-                return f"decoder.model.{3 + 3 * j}.block.{1 if p[4] == 'conv1' else 3}.conv.conv.{p[5]}"
-            if p[0] == "enc":
-                if p[1] == "conv_in": return f"encoder.model.0.conv.conv.{p[2]}"
-                if p[1] == "conv_out": return f"encoder.model.{2 + 3 * ns}.conv.conv.{p[2]}"
-                j = int(p[2])
-                if p[3] == "conv": return f"encoder.model.{3 + 3 * j}.conv.conv.{p[4]}"
-                return f"encoder.model.{1 + 3 * j}.block.{1 if p[4] == 'conv1' else 3}.conv.conv.{p[5]}"
-            raise AssertionError(n)
-
-        moshi = {moshi_name(n): t for n, t in canon.items()}
+        moshi = {moshi_name(n, ns): t for n, t in canon.items()}
         assert len(moshi) == len(canon)
         back = from_moshi_state_dict(moshi, s)
         assert set(back) == set(canon)

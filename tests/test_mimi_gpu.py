@@ -240,3 +240,23 @@ def test_tts_service_cli_surface_end_to_end_tiny(tiny_codec, tmp_path):
         data = np.frombuffer(f.readframes(n), dtype="<i2")
     assert n >= 2 * int(0.6 * 24000)                         # two sentences, each with 500 ms lead + 100 ms tail silence
     assert int(np.abs(data[:1000]).max()) == 0 and int(np.abs(data).max()) > 1000
+
+
+def test_from_pretrained_reads_a_moshi_format_safetensors_file(tmp_path):
+    """MimiCodec.from_pretrained (reference: moshi's loaders.get_mimi on the hub file, sesameai/generator.py:340-344):
+    a checkpoint written with moshi 0.2.2's tensor names loads through from_moshi_state_dict and decodes / encodes
+    exactly like the codec built from the canonical dict."""
+    from safetensors.torch import save_file
+    from sesameai.mimi import MimiArgs, MimiCodec, synthetic_state_dict
+    from test_host_logic import moshi_name
+    s = MimiArgs()
+    sd = synthetic_state_dict(s, seed=99)
+    f = tmp_path / "tokenizer-test.safetensors"
+    save_file({moshi_name(n, len(s.ratios)): t.contiguous() for n, t in sd.items()}, str(f))
+    a = MimiCodec.from_pretrained(str(f), device="cuda", max_frames=40)
+    b = MimiCodec(s, sd, device="cuda", max_frames=40)
+    g = torch.Generator().manual_seed(2)
+    codes = torch.randint(0, s.codebook_size, (1, s.num_codebooks, 25), generator=g).cuda()
+    assert torch.equal(a.decode(codes), b.decode(codes))
+    wav = (torch.randn(1, 1, 24000, generator=g) * 0.1).cuda()
+    assert torch.equal(a.encode(wav), b.encode(wav))
