@@ -124,6 +124,7 @@ struct DecPersistArgs {
 #define DP_M_SWTOT 42
 #define DP_M_RNG 112     // 4 words: Philox {seed, step} of this frame (read once at kernel start: a global load at sampling time would
                          // wait behind every weight load the wave has in flight)
+#define DP_M_SARG 116    // 4 words: V, temperature (bits), top-k, 1 if a noise tensor was given -- the sampler's scalars, staged once
 #define DP_M_TILE 48     // 4 tiles x 16 floats: the gate | up sums of a tile on their way to the SwiGLU lanes
 
 enum { DP_E_Q = 0, DP_E_H1 = 1, DP_E_P = 2, DP_E_H2 = 3, DP_E_L = 4 };
@@ -374,12 +375,16 @@ __device__ __forceinline__ int dp_sample_step(const DecPersistArgs& a, char* lds
     sc.s_tok = (lds_i32_t*)(misc + DP_M_STOK); sc.s_wtot = (lds_i32_t*)(misc + DP_M_SWTOT);
     DpQuadSync sync{(dp_lvu32*)(misc + DP_M_BAR), ab, a.err, lane, quad_phase, DP_STAMPS(a) != nullptr && cu == 100 && qw == 0 ? DP_STAMPS(a) + 4352 + s * 16 : nullptr};
     const uint64_t seed = (uint64_t)misc[DP_M_RNG] | ((uint64_t)misc[DP_M_RNG + 1] << 32), step = (uint64_t)misc[DP_M_RNG + 2] | ((uint64_t)misc[DP_M_RNG + 3] << 32);
+    // (the sampler's scalars from LDS: as kernel arguments they are re-read from the kernarg segment here, a scalar-cache miss per step)
+    const int sV = (int)misc[DP_M_SARG], sK = (int)misc[DP_M_SARG + 2];
+    const float sT = __uint_as_float(misc[DP_M_SARG + 1]);
+    const bool sN = misc[DP_M_SARG + 3] != 0u;
     int tok = 0;
     const int reps = (a.trickle_sleep & 128) ? 2 : 1;          // experiment: the second pass runs from a warm instruction cache
 #pragma unroll 1
     for (int r = 0; r < reps; ++r) {
         sync.mark(6);
-        tok = sample_body<2>(w, a.V, a.temperature, a.topk, a.noise ? a.noise + (long)cb * a.V : nullptr, seed, step, 0, cb, sc, tid, sync);
+        tok = sample_body<2>(w, sV, sT, sK, sN ? a.noise + (long)cb * sV : nullptr, seed, step, 0, cb, sc, tid, sync);
         sync.mark(7);
     }
     if (DP_STAMPS(a) != nullptr && cu == 100 && tid == 0) DP_STAMPS(a)[s * 32 + 23] = __builtin_amdgcn_s_memrealtime();
@@ -624,6 +629,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
         for (int i = threadIdx.x; i < 128; i += 512) dp_stq((dp_lu4*)(lds + DP_OFF_QB) + i, reinterpret_cast<const uint4*>(a.qd)[i]);
         if (threadIdx.x < 2) misc[DP_M_H0 + threadIdx.x] = reinterpret_cast<const uint32_t*>(a.hdec)[2 * cu + threadIdx.x];
         if (threadIdx.x >= 64 && threadIdx.x < 68) misc[DP_M_RNG + threadIdx.x - 64] = a.rng ? reinterpret_cast<const uint32_t*>(a.rng)[threadIdx.x - 64] : 0u;
+        if (threadIdx.x == 128) { misc[DP_M_SARG] = (uint32_t)a.V; misc[DP_M_SARG + 1] = __float_as_uint(a.temperature); misc[DP_M_SARG + 2] = (uint32_t)a.topk; misc[DP_M_SARG + 3] = a.noise != nullptr; }
     }
     __syncthreads();
     const uint32_t base = *a.epoch;
