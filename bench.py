@@ -304,6 +304,11 @@ def main():
     share0 = os.environ.get("BENCH_SHARE_GPU0") == "1"
     if share0:
         local_rank = 0
+        # two processes on one GPU must not both run launches that need all 256 CUs resident at once (the persistent depth
+        # decoder, the backbone attention block): half-resident twins would wait for each other until their bounded spins
+        # give up.  One process per GPU -- the product setting -- never meets this.
+        os.environ["CSM_PERSIST"] = "0"
+        os.environ["CSM_BB_BLOCK"] = "0"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
