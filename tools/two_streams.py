@@ -2,6 +2,9 @@
 """Experiment: R independent single-utterance models on R HIP streams of one GPU vs one batched model (B = R).
 The B = 1 frame step is a latency-bound chain of ~600 launches, so independent chains may overlap."""
 import os, sys, time
+# (round 2) the experiment is about the LAUNCH CHAIN: the all-CU launches (persistent depth decoder, backbone attention block)
+# of two models must not share a GPU -- see DESIGN.md "constraint that comes with it"
+os.environ.setdefault("CSM_PERSIST", "0"); os.environ.setdefault("CSM_BB_BLOCK", "0")
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sesameai-tts_amd"))
