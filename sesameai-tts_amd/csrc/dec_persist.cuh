@@ -380,7 +380,11 @@ __device__ __forceinline__ int dp_sample_step(const DecPersistArgs& a, char* lds
     const float sT = __uint_as_float(misc[DP_M_SARG + 1]);
     const bool sN = misc[DP_M_SARG + 3] != 0u;
     int tok = 0;
-    const int reps = (a.trickle_sleep & 128) ? 2 : 1;          // experiment: the second pass runs from a warm instruction cache
+#ifdef DP_TIMELINE
+    const int reps = (a.trickle_sleep & 128) ? 2 : 1;          // timeline experiment: a second pass of the sampler on the same logits
+#else
+    constexpr int reps = 1;
+#endif
 #pragma unroll 1
     for (int r = 0; r < reps; ++r) {
         sync.mark(6);
