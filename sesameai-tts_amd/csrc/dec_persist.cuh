@@ -408,7 +408,7 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
     const int ts = a.trickle_sleep & 63;
     const int unit = IS_A ? cu * 3 + (wave - 2) : cu * 2 + (wave - 5);            // q|k|v unit (768) or o-proj unit (512)
     // row blocks (64 rows) of the split down projection: waves 0-3 own {w, w + 4}; 4: {8, 11, 14}; 5: {9, 12, 15}; 6: {10, 13}
-    auto my_block = [&](int b) { return wave < 4 ? wave + 4 * b : (wave + 4) + 3 * b; };
+    auto my_block = [&](int b) { return wave < 4 ? wave + 4 * b : min((wave + 4) + 3 * b, wave == 6 ? 13 : 15); };
     // head rows of this wave: waves 2..5 own unit cu*4 + (wave - 2); wave 6 of CU 0 / 1 owns the tail units 1024 / 1025
     const int hunit = IS_X ? -1 : (wave < 6 ? cu * 4 + (wave - 2) : (cu < 2 ? 1024 + cu : -1));
     const int hrow0 = hunit < 0 ? 0 : 2 * hunit, hrow1 = hunit < 0 ? 0 : min(2 * hunit + 1, a.V - 1);
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
     else if (wave < 4) dp_compute_wave<false, true, false, true, 2>(a, lds, wave, lane, cu, base, ropev);
     else if (wave == 4) dp_compute_wave<false, true, true, false, 3>(a, lds, wave, lane, cu, base, ropev);
     else if (wave == 5) dp_compute_wave<false, false, true, false, 3>(a, lds, wave, lane, cu, base, ropev);
-    else dp_compute_wave<false, false, true, false, 2>(a, lds, wave, lane, cu, base, ropev);
+    else dp_compute_wave<false, false, true, false, 3>(a, lds, wave, lane, cu, base, ropev);   // EXPERIMENT: wave 6 shares wave 5's code (third block = its second again)
 }
 
 // W1, W3 [8192][1024] -> [256 cu][4 tiles][32 k steps][64 lanes] 16-byte operand pieces: tile q of workgroup cu holds the
