@@ -83,8 +83,8 @@ struct CsmModel {
     bool bb_block;
     dp_u64 *bg_q, *bg_a;
     uint32_t* b_state;                  // [0] tag epoch, [1] give-up code
-    uint4* p_w2s[DP_NL];
-    uint4* p_w13p[DP_NL];
+    uint4 *p_w2s, *p_w13p;              // [4 layers] re-tiled W2 / packed W1|W3, constant layer stride
+    bf16_t *p_wsm, *p_norms;            // [4][2560][1024] q|k|v|o rows, [4][2][1024] norm scales
     int p_trickle, p_poll;
     dp_u64* p_stamps;                   // debug timeline (csm_debug_persist_stamps), else nullptr
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
@@ -661,7 +661,7 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             // q / k / v and the decoder caches of positions 0, 1 where the kernel picks them up)
             DecPersistArgs p;
             memset(&p, 0, sizeof p);
-            for (int l = 0; l < DP_NL; ++l) { p.lw[l] = m->dec.lw[l]; p.w2s[l] = m->p_w2s[l]; p.w13p[l] = m->p_w13p[l]; }
+            p.wsm = m->p_wsm; p.norms = m->p_norms; p.w2s = m->p_w2s; p.w13p = m->p_w13p;
             p.dec_norm = (const bf16_t*)m->w.dec_norm; p.head_t = (const bf16_t*)m->w.audio_head_t; p.rope = m->dec.rope;
             p.proj_emb = m->proj_emb; p.qkv0_tab = m->qkv0_tab; p.hdec = m->hdec; p.qd = m->qd;
             p.kc = m->dec.kc; p.vc = m->dec.vc; p.kv_layer_stride = m->dec.layer_stride;
@@ -1056,12 +1056,22 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
             HIPCHK((CsmModel*)nullptr, hipMemset(m->pg_l, 0, (size_t)DP_NREP * DP_LSLOTS * 8));
             HIPCHK((CsmModel*)nullptr, hipMemset(m->pg_p, 0, (size_t)256 * 1024 * 8));
             HIPCHK((CsmModel*)nullptr, hipMemset(m->p_state, 0, 16));
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_w2s, (size_t)DP_NL * DP_W2S_U4 * 16));
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_w13p, (size_t)DP_NL * DP_W13P_U4 * 16));
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_wsm, (size_t)DP_NL * DP_WSM_ROWS * DP_D * 2));
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_norms, (size_t)DP_NL * 2 * DP_D * 2));
             for (int l = 0; l < DP_NL; ++l) {
-                HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_w2s[l], (size_t)DP_D * DP_FFN * 2));
-                hipLaunchKernelGGL(k_dp_retile_w2, dim3(4096), dim3(256), 0, nullptr, (const bf16_t*)m->w.dec[l].w2, m->p_w2s[l]);
-                HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_w13p[l], (size_t)2 * DP_D * DP_FFN * 2));
-                hipLaunchKernelGGL(k_dp_pack_gateup, dim3(256 * 4 * 32 * 64 / 256), dim3(256), 0, nullptr, (const bf16_t*)m->w.dec[l].w1,
-                                   (const bf16_t*)m->w.dec[l].w3, m->p_w13p[l]);
+                const CsmLayerWeights& lw = m->w.dec[l];
+                hipLaunchKernelGGL(k_dp_retile_w2, dim3(4096), dim3(256), 0, nullptr, (const bf16_t*)lw.w2, m->p_w2s + (size_t)l * DP_W2S_U4);
+                hipLaunchKernelGGL(k_dp_pack_gateup, dim3(256 * 4 * 32 * 64 / 256), dim3(256), 0, nullptr, (const bf16_t*)lw.w1,
+                                   (const bf16_t*)lw.w3, m->p_w13p + (size_t)l * DP_W13P_U4);
+                bf16_t* dst = m->p_wsm + (size_t)l * DP_WSM_ROWS * DP_D;
+                HIPCHK((CsmModel*)nullptr, hipMemcpy(dst, lw.wq, (size_t)1024 * DP_D * 2, hipMemcpyDeviceToDevice));
+                HIPCHK((CsmModel*)nullptr, hipMemcpy(dst + (size_t)1024 * DP_D, lw.wk, (size_t)256 * DP_D * 2, hipMemcpyDeviceToDevice));
+                HIPCHK((CsmModel*)nullptr, hipMemcpy(dst + (size_t)1280 * DP_D, lw.wv, (size_t)256 * DP_D * 2, hipMemcpyDeviceToDevice));
+                HIPCHK((CsmModel*)nullptr, hipMemcpy(dst + (size_t)1536 * DP_D, lw.wo, (size_t)1024 * DP_D * 2, hipMemcpyDeviceToDevice));
+                HIPCHK((CsmModel*)nullptr, hipMemcpy(m->p_norms + (size_t)(2 * l) * DP_D, lw.sa_norm, (size_t)DP_D * 2, hipMemcpyDeviceToDevice));
+                HIPCHK((CsmModel*)nullptr, hipMemcpy(m->p_norms + (size_t)(2 * l + 1) * DP_D, lw.mlp_norm, (size_t)DP_D * 2, hipMemcpyDeviceToDevice));
             }
             HIPCHK((CsmModel*)nullptr, hipGetLastError());
             HIPCHK((CsmModel*)nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_persist),
@@ -1108,8 +1118,7 @@ extern "C" void csm_destroy(csm_handle m) {
     for (void* p : m->pk_allocs) (void)hipFree(p);
     if (m->bb_block) { (void)hipFree(m->bg_q); (void)hipFree(m->bg_a); (void)hipFree(m->b_state); }
     if (m->persist) {
-        void* pp[] = {m->pg_q, m->pg_h1, m->pg_h2, m->pg_l, m->pg_p, m->p_state, m->p_w2s[0], m->p_w2s[1], m->p_w2s[2], m->p_w2s[3],
-                      m->p_w13p[0], m->p_w13p[1], m->p_w13p[2], m->p_w13p[3]};
+        void* pp[] = {m->pg_q, m->pg_h1, m->pg_h2, m->pg_l, m->pg_p, m->p_state, m->p_w2s, m->p_w13p, m->p_wsm, m->p_norms};
         for (void* p : pp) (void)hipFree(p);
     }
     delete m;

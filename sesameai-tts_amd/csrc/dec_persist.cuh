@@ -40,6 +40,9 @@ typedef unsigned long long dp_u64;
 #define DP_FFN 8192
 #define DP_HD 128
 #define DP_NQKV 1536
+#define DP_WSM_ROWS 2560              // q|k|v rows + o-proj rows of a layer
+#define DP_W2S_U4 (256L * 4 * 1024)    // 16-byte pieces per layer of the re-tiled W2
+#define DP_W13P_U4 (256L * 4 * 32 * 64)   // ... of the packed W1 | W3
 #define DP_LSLOTS 1088                // logit granules per copy (1026 used)
 
 typedef __attribute__((address_space(3))) uint32_t dp_lu32;
@@ -51,9 +54,12 @@ __device__ __forceinline__ uint4 dp_ldq(const dp_lu4* p) { const u32x4_t v = *p;
 __device__ __forceinline__ void dp_stq(dp_lu4* p, const uint4& v) { u32x4_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *p = t; }
 
 struct DecPersistArgs {
-    CsmLayerWeights lw[DP_NL];
-    const uint4* w2s[DP_NL];          // W2 re-tiled [256 cu][4 k chunks][1024 rows] 16-byte pieces (k_dp_retile_w2)
-    const uint4* w13p[DP_NL];         // W1 | W3 in matrix-core operand order [256 cu][4 tiles][32 k steps][64 lanes] (k_dp_pack_gateup)
+    // Per-layer weights live in FOUR buffers with a constant layer stride, so the kernel addresses them by arithmetic.  (With
+    // per-layer pointers in this struct, a run-time layer index into it made hipcc copy the whole argument block to scratch.)
+    const bf16_t* wsm;                // [4 layers][2560 rows][1024]: rows 0..1535 = wq | wk | wv, 1536..2559 = wo
+    const bf16_t* norms;              // [4][2][1024]: sa_norm | mlp_norm
+    const uint4* w2s;                 // [4] x W2 re-tiled [256 cu][4 k chunks][1024 rows] 16-byte pieces (k_dp_retile_w2)
+    const uint4* w13p;                // [4] x W1 | W3 in matrix-core operand order [256 cu][4 tiles][32 k steps][64 lanes] (k_dp_pack_gateup)
     const bf16_t* dec_norm;
     const bf16_t* head_t;             // [ncb-1][V][1024]
     const bf16_t* rope;               // [max_seq][64][2]
@@ -398,47 +404,61 @@ __device__ __forceinline__ int dp_sample_step(const DecPersistArgs& a, char* lds
 
 typedef __attribute__((ext_vector_type(8))) __bf16 dp_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float dp_f32x4;
-template <bool IS_X, bool IS_A, bool IN_QUAD, bool HAS_TILE, int NBK>
+// Two instantiations only -- <true, 2>: waves 0..3 (a gate/up tile + 2 row blocks), <false, 3>: waves 4..6 (3 row blocks, the
+// sampler) -- with the small-op role a RUNTIME property of the wave (the kernel is instruction-cache bound: five instantiations were
+// 131 KB of code, and sharing one between waves 5 and 6 alone was worth 1.3 % of the frame).  So that hipcc's wait counts stay exact
+// every wave of an instantiation issues the SAME sequence of loads: a role that has no use for a load of the sequence re-reads an
+// address it reads anyway (cache hit, no HBM bytes).
+//   role X (waves 0, 1): no small op;  A (2, 3, 4): q|k|v unit, rows in wsa;  B (5, 6): o-proj unit, rows in wsb.
+#ifndef DP_ROLES
+#define DP_ROLES 4              // instantiations of the compute wave: 4 = every role its own (measured best), 3 / 2 = roles by wave index at run time
+#endif
+template <bool HAS_TILE, int NBK, int TROLE>      // TROLE (tile waves): 0 = role by wave index at run time, 1 = X only, 2 = A only
 __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* lds, const int wave, const unsigned lane, const int cu, const uint32_t base,
                                                 const uint32_t ropev) {
-    constexpr bool IS_B = !IS_X && !IS_A;
-    constexpr int NT = HAS_TILE ? 32 : 0, NCD = NT + NBK * 4;
+    constexpr bool HAS_B = !HAS_TILE;                 // the instantiation carries o-proj waves
+    const bool is_x = HAS_TILE && (TROLE == 1 || (TROLE == 0 && wave < 2)), is_a = HAS_TILE ? !is_x : (TROLE == 1 || (TROLE == 0 && wave == 4)), is_b = HAS_B && !is_a;
+    constexpr int NT = HAS_TILE ? 32 : 0, NCD = NT + NBK * 4, N1 = NCD / 3;
     dp_lu32* misc = (dp_lu32*)(lds + DP_OFF_MISC);
     dp_lvu32* ab = (dp_lvu32*)(misc + DP_M_ABORT);
     const int ts = a.trickle_sleep & 63;
-    const int unit = IS_A ? cu * 3 + (wave - 2) : cu * 2 + (wave - 5);            // q|k|v unit (768) or o-proj unit (512)
-    // row blocks (64 rows) of the split down projection: waves 0-3 own {w, w + 4}; 4: {8, 11, 14}; 5: {9, 12, 15}; 6: {10, 13}
+    const int unit = is_a ? cu * 3 + (wave - 2) : cu * 2 + (wave - 5);            // q|k|v unit (768) or o-proj unit (512); X: unused
+    // row blocks (64 rows) of the split down projection: waves 0-3 own {w, w + 4}; 4: {8, 11, 14}; 5: {9, 12, 15}; 6: {10, 13, 13 again}
     auto my_block = [&](int b) { return wave < 4 ? wave + 4 * b : min((wave + 4) + 3 * b, wave == 6 ? 13 : 15); };
     // head rows of this wave: waves 2..5 own unit cu*4 + (wave - 2); wave 6 of CU 0 / 1 owns the tail units 1024 / 1025
-    const int hunit = IS_X ? -1 : (wave < 6 ? cu * 4 + (wave - 2) : (cu < 2 ? 1024 + cu : -1));
+    const int hunit = is_x ? -1 : (wave < 6 ? cu * 4 + (wave - 2) : (cu < 2 ? 1024 + cu : -1));
     const int hrow0 = hunit < 0 ? 0 : 2 * hunit, hrow1 = hunit < 0 ? 0 : min(2 * hunit + 1, a.V - 1);
-    uint4 ws[2][2];
+    uint4 wsa[2][2], wsb[HAS_B ? 2 : 1][2];
     uint4 wt[HAS_TILE ? 32 : 1];
     uint4 wd[NBK][4];
 
-    // rows of the small op slot `slot`: 0..3 = this wave's layer op, 4 = the head of codebook step cb
-    auto load_ws = [&](int slot, int cb, int k) {
-        const bf16_t* r;
-        if (slot < DP_NL) {
-            if (IS_A) {
+    // rows of the small op slot `slot`: 0..3 = this wave's layer op, 4 = the head of codebook step cb.  (X waves, and a slot
+    // that is not this role's, read the head rows / the role's own rows: a valid address, nothing more.)
+    auto ws_row = [&](int slot, int cb, int k) -> const bf16_t* {
+        if (slot < DP_NL && !is_x) {
+            if (is_a) {
                 const int row = 2 * unit + (k >> 1);
-                r = row < 1024 ? (const bf16_t*)a.lw[slot].wq + (long)row * DP_D
-                  : row < 1280 ? (const bf16_t*)a.lw[slot].wk + (long)(row - 1024) * DP_D
-                               : (const bf16_t*)a.lw[slot].wv + (long)(row - 1280) * DP_D;
-            } else r = (const bf16_t*)a.lw[slot].wo + (long)(2 * unit + (k >> 1)) * DP_D;
-        } else r = a.head_t + ((long)(cb - 1) * a.V + ((k >> 1) ? hrow1 : hrow0)) * DP_D;
-        ws[k >> 1][k & 1] = reinterpret_cast<const uint4*>(r)[(k & 1) * 64 + lane];
+                return a.wsm + ((long)slot * DP_WSM_ROWS + row) * DP_D;
+            }
+            return a.wsm + ((long)slot * DP_WSM_ROWS + DP_NQKV + 2 * unit + (k >> 1)) * DP_D;
+        }
+        return a.head_t + ((long)(cb - 1) * a.V + ((k >> 1) ? hrow1 : hrow0)) * DP_D;
     };
+    auto load_wsa = [&](int slot, int cb, int k) { wsa[k >> 1][k & 1] = reinterpret_cast<const uint4*>(ws_row(slot, cb, k))[(k & 1) * 64 + lane]; };
+    auto load_wsb = [&](int slot, int cb, int k) { wsb[HAS_B ? k >> 1 : 0][k & 1] = reinterpret_cast<const uint4*>(ws_row(slot, cb, k))[(k & 1) * 64 + lane]; };
     auto load_cd = [&](int l, int k) {
-        if (k < NT) wt[HAS_TILE ? k : 0] = a.w13p[l][(((long)cu * 4 + wave) * 32 + k) * 64 + lane];
+        if (k < NT) wt[HAS_TILE ? k : 0] = a.w13p[(long)l * DP_W13P_U4 + (((long)cu * 4 + wave) * 32 + k) * 64 + lane];
         else {
             const int kk = k - NT;
-            wd[kk >> 2][kk & 3] = a.w2s[l][((long)cu * 4 + (kk & 3)) * 1024 + my_block(kk >> 2) * 64 + lane];
+            wd[kk >> 2][kk & 3] = a.w2s[(long)l * DP_W2S_U4 + ((long)cu * 4 + (kk & 3)) * 1024 + my_block(kk >> 2) * 64 + lane];
         }
     };
-    if (!IS_X) {
+    // first uses: A's q|k|v rows of layer 1 (layer 0's q|k|v come from the table), B's o-proj rows of layer 0
 #pragma unroll
-        for (int k = 0; k < 4; ++k) load_ws(IS_A ? 1 : 0, a.cb_first, k);
+    for (int k = 0; k < 4; ++k) load_wsa(1, a.cb_first, k);
+    if (HAS_B) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load_wsb(0, a.cb_first, k);
     }
 #pragma unroll
     for (int k = 0; k < NCD; ++k) load_cd(0, k);
@@ -450,44 +470,42 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
         for (int l = 0; l < DP_NL; ++l) {
             const int it = s * DP_NL + l;
             dp_lu32* att = (dp_lu32*)(lds + DP_OFF_ATT);
-            if (IS_A) {
-                // -- q|k|v unit of layers 1..3 (layer 0's row comes from the table); first third of this layer's MLP weights meanwhile
+            {
+                // -- x of the q|k|v units is ready (layers 1..3; layer 0's row comes from the table): A waves run their unit; first third
+                //    of this layer's MLP weights meanwhile
                 const uint32_t tg = dp_tag(base, s, l - 1, DP_E_H2);
-                if (!dp_wait<NCD / 3, false>((dp_lvu32*)(misc + DP_M_FXA), l > 0 ? tg : *(dp_lvu32*)(misc + DP_M_FXA), ab, a.err, 0x910u, lane, ts,
-                                             [&](int k) { load_cd(l, k); })) return;
-                if (l > 0) {
+                if (!dp_wait<N1, false>((dp_lvu32*)(misc + DP_M_FXA), l > 0 ? tg : *(dp_lvu32*)(misc + DP_M_FXA), ab, a.err, 0x910u, lane, ts,
+                                        [&](int k) { load_cd(l, k); })) return;
+                if (is_a && l > 0) {
                     const dp_lu4* xs = (const dp_lu4*)(lds + DP_OFF_XA);
                     const uint4 x0 = dp_ldq(xs + lane), x1 = dp_ldq(xs + 64 + lane);
-                    float a0 = dot8(ws[0][0], x0, 0.f); a0 = dot8(ws[0][1], x1, a0);
-                    float a1 = dot8(ws[1][0], x0, 0.f); a1 = dot8(ws[1][1], x1, a1);
+                    float a0 = dot8(wsa[0][0], x0, 0.f); a0 = dot8(wsa[0][1], x1, a0);
+                    float a1 = dot8(wsa[1][0], x0, 0.f); a1 = dot8(wsa[1][1], x1, a1);
                     a0 = wave_sum(a0); a1 = wave_sum(a1);
                     const int row = 2 * unit;                              // q rows 0..1023, k 1024..1279, v 1280..1535
-                    const int e = (row < 1024 ? row : row - 1024) % DP_HD;
                     const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)ropev, cb);   // (cos, sin) of this unit's pair at position cb
                     const uint32_t outw = dp_rope_pair(a0, a1, cs, row < 1280);
                     if (lane < DP_NREP) dp_gran_store(a.gQ + lane * 768 + unit, dp_tag(base, s, l, DP_E_Q), outw);
                 }
             }
             {
-                // -- attention: head `wave` over keys 0..cb (the gather wave takes head 7); the A waves' next q|k|v rows and part
-                //    of this layer's MLP weights meanwhile
-                constexpr int N2 = IS_A ? 4 + NCD / 3 : NCD / 2;
-                if (!dp_wait<N2, false>((dp_lvu32*)(misc + DP_M_FQ), dp_tag(base, s, l, DP_E_Q), ab, a.err, 0x920u, lane, ts, [&](int k) {
-                        if (IS_A) { if (k < 4) load_ws(l + 1 < DP_NL ? l + 1 : DP_NL, cb, k); else load_cd(l, NCD / 3 + k - 4); }
-                        else load_cd(l, k);
+                // -- attention: head `wave` over keys 0..cb (the gather wave takes head 7); the A waves' next q|k|v rows (or head rows)
+                //    and the second third of this layer's MLP weights meanwhile
+                if (!dp_wait<4 + N1, false>((dp_lvu32*)(misc + DP_M_FQ), dp_tag(base, s, l, DP_E_Q), ab, a.err, 0x920u, lane, ts, [&](int k) {
+                        if (k < 4) load_wsa(l + 1 < DP_NL ? l + 1 : DP_NL, cb, k); else load_cd(l, N1 + k - 4);
                     })) return;
                 const bool st5 = DP_STAMPS(a) != nullptr && cu == 100 && lane == 0 && wave == 5 && l == 2;
                 if (st5) DP_STAMPS(a)[4096 + s * 8 + 0] = __builtin_amdgcn_s_memrealtime();
                 dp_attention_wave(lds, wave, l, cb, lane);
                 if (st5) DP_STAMPS(a)[4096 + s * 8 + 1] = __builtin_amdgcn_s_memrealtime();
             }
-            if (IS_B) {
-                // -- o-projection unit + residual, once the four attention waves are done
+            if (HAS_B && is_b) {
+                // -- o-projection unit + residual, once the eight attention waves are done
                 if (!dp_wait<1, true>((dp_lvu32*)(misc + DP_M_ATTN), 8u * (uint32_t)(it + 1), ab, a.err, 0x930u, lane, ts, [&](int) {})) return;
                 const dp_lu4* xs = (const dp_lu4*)att;
                 const uint4 x0 = dp_ldq(xs + lane), x1 = dp_ldq(xs + 64 + lane);
-                float a0 = dot8(ws[0][0], x0, 0.f); a0 = dot8(ws[0][1], x1, a0);
-                float a1 = dot8(ws[1][0], x0, 0.f); a1 = dot8(ws[1][1], x1, a1);
+                float a0 = dot8(wsb[0][0], x0, 0.f); a0 = dot8(wsb[0][1], x1, a0);
+                float a1 = dot8(wsb[HAS_B ? 1 : 0][0], x0, 0.f); a1 = dot8(wsb[HAS_B ? 1 : 0][1], x1, a1);
                 a0 = wave_sum(a0); a1 = wave_sum(a1);
                 const uint32_t h0w = *(dp_lvu32*)(misc + DP_M_H0 + (wave - 5));
                 const uint32_t outw = dp_resid_pair(a0, a1, h0w);
@@ -498,11 +516,10 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
             }
             {
                 // -- the MLP: my (gate, up) pairs -> h values -> LDS -> my row blocks of the split down projection
-                constexpr int N4 = IS_X ? NCD - NCD / 2 : IS_A ? NCD - 2 * (NCD / 3) : 4 + NCD - NCD / 2;
+                // (the B waves' next o-proj rows, or head rows, and the last third of the MLP weights meanwhile)
+                constexpr int NB4 = HAS_B ? 4 : 0, N4 = NB4 + NCD - 2 * N1;
                 if (!dp_wait<N4, false>((dp_lvu32*)(misc + DP_M_FXC), dp_tag(base, s, l, DP_E_H1), ab, a.err, 0x940u, lane, ts, [&](int k) {
-                        if (IS_X) load_cd(l, NCD / 2 + k);
-                        else if (IS_A) load_cd(l, 2 * (NCD / 3) + k);
-                        else { if (k < 4) load_ws(l + 1 < DP_NL ? l + 1 : DP_NL, cb, k); else load_cd(l, NCD / 2 + k - 4); }
+                        if (k < NB4) load_wsb(l + 1 < DP_NL ? l + 1 : DP_NL, cb, k); else load_cd(l, 2 * N1 + k - NB4);
                     })) return;
                 const bool st0 = DP_STAMPS(a) != nullptr && cu == 100 && lane == 0 && wave == 0 && l == 2;
                 if (st0) DP_STAMPS(a)[4096 + s * 8 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -571,28 +588,31 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
             }
         }
         // ---- the head of codebook cb: waves 2..6 hold 2 logit rows each (ws slot 4), x = dec_norm(h)
-        if (!IS_X) {
+        {
             if (!dp_wait<1, false>((dp_lvu32*)(misc + DP_M_FXA), dp_tag(base, s, DP_NL - 1, DP_E_H2), ab, a.err, 0x960u, lane, ts, [&](int) {})) return;
             const bool st2 = DP_STAMPS(a) != nullptr && cu == 100 && lane == 0 && wave == 2;
             if (st2) DP_STAMPS(a)[s * 32 + 20] = __builtin_amdgcn_s_memrealtime();
             if (hunit >= 0) {
                 const dp_lu4* xs = (const dp_lu4*)(lds + DP_OFF_XA);
                 const uint4 x0 = dp_ldq(xs + lane), x1 = dp_ldq(xs + 64 + lane);
-                float a0 = dot8(ws[0][0], x0, 0.f); a0 = dot8(ws[0][1], x1, a0);
-                float a1 = dot8(ws[1][0], x0, 0.f); a1 = dot8(ws[1][1], x1, a1);
+                // the head rows sit in the role's own slot (A: wsa, B: wsb)
+                uint4 r00 = wsa[0][0], r01 = wsa[0][1], r10 = wsa[1][0], r11 = wsa[1][1];
+                if (HAS_B && is_b) { r00 = wsb[0][0]; r01 = wsb[0][1]; r10 = wsb[HAS_B ? 1 : 0][0]; r11 = wsb[HAS_B ? 1 : 0][1]; }
+                float a0 = dot8(r00, x0, 0.f); a0 = dot8(r01, x1, a0);
+                float a1 = dot8(r10, x0, 0.f); a1 = dot8(r11, x1, a1);
                 a0 = wave_sum(a0); a1 = wave_sum(a1);
                 if (lane < DP_NREP) dp_gran_store(a.gL + lane * DP_LSLOTS + hunit, dp_tag(base, s, DP_NL - 1, DP_E_L), pack_bf(a0, a1));
             }
             if (st2) DP_STAMPS(a)[s * 32 + 21] = __builtin_amdgcn_s_memrealtime();
             if (DP_STAMPS(a) != nullptr && s == 5 && lane == 0 && hunit >= 0) DP_STAMPS(a)[1024 + cu * 8 + wave] = __builtin_amdgcn_s_memrealtime();
             // next use of the small-op rows: the B waves' layer-0 o-proj of the next step (the A waves reload theirs in layer 0)
-            if (IS_B) {
+            if (HAS_B) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) load_ws(0, cb, k);
+                for (int k = 0; k < 4; ++k) load_wsb(0, cb, k);
             }
         }
         // ---- the sampler (waves 4, 5, 6 and the gather wave), on every CU alike: each CU needs the code for its table rows
-        if (IN_QUAD) {
+        if (!HAS_TILE) {
             if (!dp_wait<1, false>((dp_lvu32*)(misc + DP_M_FLG), dp_tag(base, s, DP_NL - 1, DP_E_L), ab, a.err, 0x970u, lane, ts, [&](int) {})) return;
             (void)dp_sample_step<false>(a, lds, wave - 4, (int)lane, cu, cb, s, &quad_phase);
             if (*ab) return;
@@ -654,7 +674,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
                 if (l > 0) {
                     {   // rows of the previous layer -> sa_norm -> xA
                         uint32_t v[8];
-                        const uint4 g0 = reinterpret_cast<const uint4*>(a.lw[l].sa_norm)[ln], g1 = reinterpret_cast<const uint4*>(a.lw[l].sa_norm)[64 + ln];
+                        const uint4 g0 = reinterpret_cast<const uint4*>(a.norms + (long)(2 * l) * DP_D)[ln], g1 = reinterpret_cast<const uint4*>(a.norms + (long)(2 * l) * DP_D)[64 + ln];
                         if (!dp_sweep<4>(rgH2, 512, dp_tag(base, s, l - 1, DP_E_H2), v, ln, ab, a.err, 0x100u + l, a.poll_sleep)) return;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { ((dp_lu32*)(lds + DP_OFF_XA))[2 * (j * 64 + ln)] = v[2 * j]; ((dp_lu32*)(lds + DP_OFF_XA))[2 * (j * 64 + ln) + 1] = v[2 * j + 1]; }
@@ -680,7 +700,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
                 dp_attention_wave(lds, 7, l, cb, ln);              // (layer 0: q / k / v were placed by the table fetch)
                 {   // rows after the o-projection -> mlp_norm -> xC
                     uint32_t v[8];
-                    const uint4 g0 = reinterpret_cast<const uint4*>(a.lw[l].mlp_norm)[ln], g1 = reinterpret_cast<const uint4*>(a.lw[l].mlp_norm)[64 + ln];
+                    const uint4 g0 = reinterpret_cast<const uint4*>(a.norms + (long)(2 * l + 1) * DP_D)[ln], g1 = reinterpret_cast<const uint4*>(a.norms + (long)(2 * l + 1) * DP_D)[64 + ln];
                     if (!dp_sweep<4>(rgH1, 512, dp_tag(base, s, l, DP_E_H1), v, ln, ab, a.err, 0x300u + l, a.poll_sleep)) return;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { ((dp_lu32*)(lds + DP_OFF_XC))[2 * (j * 64 + ln)] = v[2 * j]; ((dp_lu32*)(lds + DP_OFF_XC))[2 * (j * 64 + ln) + 1] = v[2 * j + 1]; }
@@ -760,11 +780,19 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
         if (cu == 0 && lane == 0) __hip_atomic_store(a.epoch, base + (uint32_t)(n_steps * DP_NL * 5 + 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    if (wave < 2) dp_compute_wave<true, false, false, true, 2>(a, lds, wave, lane, cu, base, ropev);
-    else if (wave < 4) dp_compute_wave<false, true, false, true, 2>(a, lds, wave, lane, cu, base, ropev);
-    else if (wave == 4) dp_compute_wave<false, true, true, false, 3>(a, lds, wave, lane, cu, base, ropev);
-    else if (wave == 5) dp_compute_wave<false, false, true, false, 3>(a, lds, wave, lane, cu, base, ropev);
-    else dp_compute_wave<false, false, true, false, 3>(a, lds, wave, lane, cu, base, ropev);   // EXPERIMENT: wave 6 shares wave 5's code (third block = its second again)
+#if DP_ROLES == 4
+    if (wave < 2) dp_compute_wave<true, 2, 1>(a, lds, wave, lane, cu, base, ropev);
+    else if (wave < 4) dp_compute_wave<true, 2, 2>(a, lds, wave, lane, cu, base, ropev);
+    else if (wave == 4) dp_compute_wave<false, 3, 1>(a, lds, wave, lane, cu, base, ropev);
+    else dp_compute_wave<false, 3, 2>(a, lds, wave, lane, cu, base, ropev);
+#elif DP_ROLES == 3
+    if (wave < 2) dp_compute_wave<true, 2, 1>(a, lds, wave, lane, cu, base, ropev);
+    else if (wave < 4) dp_compute_wave<true, 2, 2>(a, lds, wave, lane, cu, base, ropev);
+    else dp_compute_wave<false, 3, 0>(a, lds, wave, lane, cu, base, ropev);
+#else
+    if (wave < 4) dp_compute_wave<true, 2, 0>(a, lds, wave, lane, cu, base, ropev);
+    else dp_compute_wave<false, 3, 0>(a, lds, wave, lane, cu, base, ropev);
+#endif
 }
 
 // W1, W3 [8192][1024] -> [256 cu][4 tiles][32 k steps][64 lanes] 16-byte operand pieces: tile q of workgroup cu holds the

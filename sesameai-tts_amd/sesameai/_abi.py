@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CSM_HIP_TIMELINE=1: the build with the persistent decoder's debug stamps compiled in (make -C csrc timeline)
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib",
                         "libcsm_hip_timeline.so" if os.environ.get("CSM_HIP_TIMELINE", "0") == "1" else "libcsm_hip.so")
+if os.environ.get("CSM_HIP_LIB"):           # an explicitly named build of the library (A/B runs of kernel variants)
+    LIB_PATH = os.environ["CSM_HIP_LIB"]
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
