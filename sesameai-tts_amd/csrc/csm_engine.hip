@@ -590,7 +590,7 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
             memset(&b, 0, sizeof b);
             b.wq = (const bf16_t*)w.wq; b.wk = (const bf16_t*)w.wk; b.wv = (const bf16_t*)w.wv; b.wo = (const bf16_t*)w.wo;
             b.sa_norm = (const bf16_t*)w.sa_norm; b.rope = S.rope; b.h = h; b.kc = kc; b.vc = vc; b.pos = pos; b.smax = S.cache_len;
-            b.eps = S.d.norm_eps; b.gQ = m->bg_q; b.gA = m->bg_a; b.err = m->b_state + 1; b.epoch = m->b_state; b.poll_sleep = m->p_poll > 0 ? m->p_poll : 2;
+            b.eps = S.d.norm_eps; b.gQ = m->bg_q; b.gA = m->bg_a; b.err = m->b_state + 1; b.epoch = m->b_state; b.poll_sleep = m->persist ? m->p_poll : 1;
             hipLaunchKernelGGL(k_bb_attn_block, dim3(DP_NB), dim3(512), 0, st, b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             block_done = true;
@@ -1077,8 +1077,8 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
             HIPCHK((CsmModel*)nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_persist),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_BYTES));
             HIPCHK((CsmModel*)nullptr, hipDeviceSynchronize());
-            { const char* e2 = getenv("CSM_PERSIST_TRICKLE"); m->p_trickle = e2 ? atoi(e2) : 6; }
-            { const char* e2 = getenv("CSM_PERSIST_POLL"); m->p_poll = e2 ? atoi(e2) : 2; }
+            { const char* e2 = getenv("CSM_PERSIST_TRICKLE"); m->p_trickle = e2 ? atoi(e2) : 8; }       // (swept 4..16 x 0..3 at the final state: 8 / 1)
+            { const char* e2 = getenv("CSM_PERSIST_POLL"); m->p_poll = e2 ? atoi(e2) : 1; }
             m->persist = true;
         }
     }
