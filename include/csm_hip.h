@@ -123,7 +123,12 @@ int csm_depth(csm_handle h, int B, float temperature, int topk, const int32_t* f
  * frame (kept on device) is embedded with mask [1 x32, 0] at the internal position, one
  * backbone step, csm_depth, position += 1, frame appended to the history, EOS flag
  * (all 32 codes == 0, generator.py:285) accumulated per sequence.  No host sync; the whole
- * step is captured once into a hipGraph and replayed.                                       */
+ * step is captured once into a hipGraph and replayed.
+ * Batch 1 on the CSM-1B shapes: codebooks 2..31 and every backbone attention block run as launches of 256 workgroups
+ * that must all be resident at once (csrc/dec_persist.cuh, csrc/bb_block.cuh).  Drive ONE frame loop per GPU (batch, or
+ * one process per GPU); two loops sharing a GPU can starve each other, which ends -- after a bounded 50 ms spin, never a
+ * hang -- in CSM_E_HIP from csm_read_frames; csm_reset makes the handle usable again.  CSM_PERSIST=0 / CSM_BB_BLOCK=0
+ * select the plain launch chain.                                                              */
 int csm_frame_step(csm_handle h, int B, float temperature, int topk, int use_graph, void* stream);
 /* Copies the most recent frame [B][32] i32 to out_frame (dev) on the stream.                 */
 int csm_copy_frame(csm_handle h, int B, int32_t* out_frame, void* stream);
