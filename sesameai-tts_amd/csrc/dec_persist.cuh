@@ -19,6 +19,8 @@
 //               waves 2-4: + one q|k|v unit (2 rows, RoPE) + one head unit
 //               waves 5,6: + one o-proj unit (2 rows, + residual) + head unit (5) / tail rows (6)
 //               all 8 waves: one attention head each over the LDS-resident K/V;  waves 4-7 ("quad"): the sampler.
+//               Every wave of an instantiation issues the same load sequence (dp_compute_wave); the per-layer weights are
+//               four buffers with a constant layer stride (DecPersistArgs), addressed by arithmetic.
 //
 // Arithmetic: every dot product, RoPE, attention, RMSNorm, residual and the sampler use the chain path's code or its
 // exact lane/k mapping (k_gemv, stage_attn, stage_x, sample_body), so those values are bit-identical to the launch
