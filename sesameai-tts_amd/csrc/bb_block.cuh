@@ -11,8 +11,9 @@
 //   * attention: CU h < 32 = head h, keys 0..p-1 from the cache (prefetched at entry: they do not depend on this step),
 //     key p from the granules; 8 waves x 8 key slots, fp32 online softmax (k_attn's arithmetic), merged through LDS,
 //   * the 2048 attention outputs travel as granules to every CU; wave w of CU c owns output row 8c + w.
-// Bounded spins (dp_give_up) -> *err.  Any position: keys beyond the BB_KMAX prefetched at entry are walked in further
-// rounds loaded on the spot.  Batches and the fp8 decode stream use the chain.
+// Bounded spins (dp_give_up) -> *err.  Any position: from BB_KMAX keys on a head's key range is split over 8 CUs (all 256
+// CUs attend) and the head's CU folds their (o, m, l) partials in order -- one more hand-off, taken only where it pays.
+// Batches and the fp8 decode stream use the chain.
 #pragma once
 #include "dec_persist.cuh"
 
@@ -32,6 +33,7 @@ struct BbBlockArgs {
     int smax;
     float eps;
     dp_u64 *gQ, *gA;                      // [8][1536], [8][1024] granules
+    dp_u64* gS;                           // [32 heads][8 key ranges][72]: (o[64], m, l) partials of the long-context mode (fp32 payloads)
     uint32_t *err, *epoch;
     int poll_sleep;
 };
@@ -95,24 +97,29 @@ __global__ __launch_bounds__(512) void k_bb_attn_block(const BbBlockArgs a) {
     const uint32_t cs = reinterpret_cast<const uint32_t*>(a.rope)[(long)p * (BB_HD / 2) + e0 / 2];
     // attention CUs: K / V rows of keys 0..p-1 of this head's KV group.  Load j of wave w: keys 64 j + 8 w + (lane >> 3),
     // 16-byte piece lane & 7 of each 128-byte row (8 rows = one contiguous 1 KB per wave load)
-    const bool attn_cu = cu < BB_NH;
+    // Short contexts: head h = CU h walks all its keys (one hand-off less).  From BB_KMAX keys on the range is split over 8 CUs
+    // per head (CU h + 32 r: keys [r chunk, (r + 1) chunk)), their (o, m, l) partials go to CU h, which folds them in order.
+    const int nsplit = p >= BB_KMAX ? 8 : 1;
+    const bool attn_cu = cu < BB_NH * nsplit;
+    const int head = cu % BB_NH, split = cu / BB_NH;
+    const int chunk = (p + nsplit - 1) / nsplit, k_lo = split * chunk, k_hi = min(p, k_lo + chunk);
     const int slot = lane >> 3, e8 = lane & 7;
     uint4 kr[BB_KMAX / 64], vr[BB_KMAX / 64];
     if (attn_cu) {
-        const int kvh = cu / (BB_NH / BB_NKV);
+        const int kvh = head / (BB_NH / BB_NKV);
         const bf16_t* kb = a.kc + (long)kvh * a.smax * BB_HD;
         const bf16_t* vb = a.vc + (long)kvh * a.smax * BB_HD;
 #pragma unroll
         for (int j = 0; j < BB_KMAX / 64; ++j) {
-            // (slots past the last key re-read key p - 1: finite values, weight 0; with p == 0 the round loop does not run)
-            const int key = min(64 * j + 8 * wave + slot, max(p - 1, 0));
+            // (slots past the last key re-read the last one: finite values, weight 0; with no key in range the round loop does not run)
+            const int key = min(k_lo + 64 * j + 8 * wave + slot, max(k_hi - 1, 0));
             kr[j] = *reinterpret_cast<const uint4*>(kb + (long)key * BB_HD + e8 * 8);
             vr[j] = *reinterpret_cast<const uint4*>(vb + (long)key * BB_HD + e8 * 8);
         }
     }
     // (misc zeroed.  A bare s_barrier: __syncthreads() would also wait for every load issued above)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const uint32_t tagQ = base + 1u, tagA = base + 2u;
+    const uint32_t tagQ = base + 1u, tagA = base + 2u, tagS = base + 3u;
 
     // ---- RMSNorm of the whole row, per wave, in registers (chunk i * 64 + lane = elements 8 (i * 64 + lane) ..) ---------
     uint4 xn[4];
@@ -141,12 +148,12 @@ __global__ __launch_bounds__(512) void k_bb_attn_block(const BbBlockArgs a) {
     }
     // ---- attention (CUs 0..31) -----------------------------------------------------------------------------------------
     if (attn_cu) {
-        const int kvh = cu / (BB_NH / BB_NKV);
+        const int kvh = head / (BB_NH / BB_NKV);
         dp_lf32* part = (dp_lf32*)(lds + BB_L_PART);
         if (wave == 7) {
-            // q of head cu (pairs 32 cu ..), k_new / v_new of KV head kvh (pairs 1024 + 32 kvh .., 1280 + 32 kvh ..)
+            // q of this head (pairs 32 head ..), k_new / v_new of KV head kvh (pairs 1024 + 32 kvh .., 1280 + 32 kvh ..)
             const dp_u64* rg = a.gQ + (cu % DP_NREP) * BB_NQKV_PAIRS;
-            const int i0 = lane < 32 ? 32 * cu + lane : 1024 + 32 * kvh + (lane - 32);
+            const int i0 = lane < 32 ? 32 * head + lane : 1024 + 32 * kvh + (lane - 32);
             const int i1 = 1280 + 32 * kvh + (lane & 31);
             const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
             uint32_t v0, v1;
@@ -165,21 +172,21 @@ __global__ __launch_bounds__(512) void k_bb_attn_block(const BbBlockArgs a) {
         float mx = -INFINITY, l = 0.f, o[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = 0.f;
-        // keys 0..p-1 in rounds of BB_KMAX: round 0 is the set prefetched at entry, later rounds (p > BB_KMAX) load here
-        for (int k0 = 0; k0 < p; k0 += BB_KMAX) {
-            if (k0 > 0) {
+        // this CU's keys in rounds of BB_KMAX: round 0 is the set prefetched at entry (with the 8-way split it is the only one)
+        for (int k0 = k_lo; k0 < k_hi; k0 += BB_KMAX) {
+            if (k0 > k_lo) {
                 const bf16_t* kb = a.kc + (long)kvh * a.smax * BB_HD;
                 const bf16_t* vb = a.vc + (long)kvh * a.smax * BB_HD;
 #pragma unroll
                 for (int j = 0; j < BB_KMAX / 64; ++j) {
-                    const int key = min(k0 + 64 * j + 8 * wave + slot, p - 1);
+                    const int key = min(k0 + 64 * j + 8 * wave + slot, k_hi - 1);
                     kr[j] = *reinterpret_cast<const uint4*>(kb + (long)key * BB_HD + e8 * 8);
                     vr[j] = *reinterpret_cast<const uint4*>(vb + (long)key * BB_HD + e8 * 8);
                 }
             }
 #pragma unroll
             for (int j = 0; j < BB_KMAX / 64; ++j) {
-                const bool live = k0 + 64 * j + 8 * wave + slot < p;
+                const bool live = k0 + 64 * j + 8 * wave + slot < k_hi;
                 float s = bb_sum8(dot8(qv, kr[j], 0.f)) * 0.125f;
                 s = live ? s : -INFINITY;
                 const float mn = fmaxf(mx, s);
@@ -213,12 +220,12 @@ __global__ __launch_bounds__(512) void k_bb_attn_block(const BbBlockArgs a) {
             // the step's own key (position p): one more partial with a single key
             const uint4 kn = dp_ldq((const dp_lu4*)(lds + BB_L_Q + 128) + e8), vn = dp_ldq((const dp_lu4*)(lds + BB_L_Q + 256) + e8);
             const float s = bb_sum8(dot8(qv, kn, 0.f)) * 0.125f;
-            if (slot == 1) {
+            if (slot == 1) {                                             // (key range 0 carries it; the others add an empty partial)
             part[8 * 66 + e8 * 8 + 0] = lo2f(vn.x); part[8 * 66 + e8 * 8 + 1] = hi2f(vn.x);
             part[8 * 66 + e8 * 8 + 2] = lo2f(vn.y); part[8 * 66 + e8 * 8 + 3] = hi2f(vn.y);
             part[8 * 66 + e8 * 8 + 4] = lo2f(vn.z); part[8 * 66 + e8 * 8 + 5] = hi2f(vn.z);
             part[8 * 66 + e8 * 8 + 6] = lo2f(vn.w); part[8 * 66 + e8 * 8 + 7] = hi2f(vn.w);
-            if (e8 == 0) { part[8 * 66 + 64] = s; part[8 * 66 + 65] = 1.0f; }
+            if (e8 == 0) { part[8 * 66 + 64] = split == 0 ? s : -INFINITY; part[8 * 66 + 65] = split == 0 ? 1.0f : 0.f; }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -239,12 +246,40 @@ __global__ __launch_bounds__(512) void k_bb_attn_block(const BbBlockArgs a) {
                 const float c0 = (M == -INFINITY) ? 0.f : __expf(M - mn), c1 = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
                 L = L * c0 + lw * c1; O = O * c0 + ow * c1; M = mn;
             }
-            const float y = O / L;
-            const float yn = __shfl_xor(y, 1, WAVE);
-            if ((lane & 1) == 0) {
-                const uint32_t pw = pack_bf(y, yn);
+            if (nsplit > 1) {
+                dp_u64* mine = a.gS + ((long)head * 8 + split) * 72;
+                if (split > 0) {
+                    // a later key range: hand (o, m, l) to the head's CU
+                    dp_gran_store(mine + lane, tagS, __float_as_uint(O));
+                    if (lane == 0) dp_gran_store(mine + 64, tagS, __float_as_uint(M));
+                    if (lane == 1) dp_gran_store(mine + 65, tagS, __float_as_uint(L));
+                } else {
+                    // the head's CU: fold ranges 1..7 in order
+                    for (int r = 1; r < 8; ++r) {
+                        const dp_u64* src = a.gS + ((long)head * 8 + r) * 72;
+                        const dp_u64 t1 = __builtin_amdgcn_s_memrealtime();
+                        dp_u64 xo, xm, xl;
+                        for (;;) {
+                            xo = dp_gran_load(src + lane); xm = dp_gran_load(src + 64); xl = dp_gran_load(src + 65);
+                            if (__all((uint32_t)(xo >> 32) == tagS && (uint32_t)(xm >> 32) == tagS && (uint32_t)(xl >> 32) == tagS)) break;
+                            if (dp_give_up(t1, ab, a.err, 0xC06u, lane)) return;
+                            for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+                        }
+                        const float mw = __uint_as_float((uint32_t)xm), lw = __uint_as_float((uint32_t)xl), ow = __uint_as_float((uint32_t)xo);
+                        const float mn = fmaxf(M, mw);
+                        const float c0 = (M == -INFINITY) ? 0.f : __expf(M - mn), c1 = (mw == -INFINITY) ? 0.f : __expf(mw - mn);
+                        L = L * c0 + lw * c1; O = O * c0 + ow * c1; M = mn;
+                    }
+                }
+            }
+            if (split == 0) {
+                const float y = O / L;
+                const float yn = __shfl_xor(y, 1, WAVE);
+                if ((lane & 1) == 0) {
+                    const uint32_t pw = pack_bf(y, yn);
 #pragma unroll
-                for (int rep = 0; rep < DP_NREP; ++rep) dp_gran_store(a.gA + rep * 1024 + 32 * cu + (lane >> 1), tagA, pw);
+                    for (int rep = 0; rep < DP_NREP; ++rep) dp_gran_store(a.gA + rep * 1024 + 32 * head + (lane >> 1), tagA, pw);
+                }
             }
         }
     }

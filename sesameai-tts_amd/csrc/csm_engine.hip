@@ -81,7 +81,7 @@ struct CsmModel {
     uint32_t* p_state;                  // [0] tag epoch, [1] give-up code of the last launch (0 = ok)
     // backbone attention block of a batch-1 decode step as one launch per layer (bb_block.cuh)
     bool bb_block;
-    dp_u64 *bg_q, *bg_a;
+    dp_u64 *bg_q, *bg_a, *bg_s;
     uint32_t* b_state;                  // [0] tag epoch, [1] give-up code
     uint4 *p_w2s, *p_w13p;              // [4 layers] re-tiled W2 / packed W1|W3, constant layer stride
     bf16_t *p_wsm, *p_norms;            // [4][2560][1024] q|k|v|o rows, [4][2][1024] norm scales
@@ -590,7 +590,7 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
             memset(&b, 0, sizeof b);
             b.wq = (const bf16_t*)w.wq; b.wk = (const bf16_t*)w.wk; b.wv = (const bf16_t*)w.wv; b.wo = (const bf16_t*)w.wo;
             b.sa_norm = (const bf16_t*)w.sa_norm; b.rope = S.rope; b.h = h; b.kc = kc; b.vc = vc; b.pos = pos; b.smax = S.cache_len;
-            b.eps = S.d.norm_eps; b.gQ = m->bg_q; b.gA = m->bg_a; b.err = m->b_state + 1; b.epoch = m->b_state; b.poll_sleep = m->persist ? m->p_poll : 1;
+            b.eps = S.d.norm_eps; b.gQ = m->bg_q; b.gA = m->bg_a; b.gS = m->bg_s; b.err = m->b_state + 1; b.epoch = m->b_state; b.poll_sleep = m->persist ? m->p_poll : 1;
             hipLaunchKernelGGL(k_bb_attn_block, dim3(DP_NB), dim3(512), 0, st, b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             block_done = true;
@@ -1095,6 +1095,8 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
             HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->bg_q, (size_t)DP_NREP * BB_NQKV_PAIRS * 8));
             HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->bg_a, (size_t)DP_NREP * 1024 * 8));
             HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->b_state, 16));
+            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->bg_s, (size_t)BB_NH * 8 * 72 * 8));
+            HIPCHK((CsmModel*)nullptr, hipMemset(m->bg_s, 0, (size_t)BB_NH * 8 * 72 * 8));
             HIPCHK((CsmModel*)nullptr, hipMemset(m->bg_q, 0, (size_t)DP_NREP * BB_NQKV_PAIRS * 8));
             HIPCHK((CsmModel*)nullptr, hipMemset(m->bg_a, 0, (size_t)DP_NREP * 1024 * 8));
             HIPCHK((CsmModel*)nullptr, hipMemset(m->b_state, 0, 16));
@@ -1116,7 +1118,7 @@ extern "C" void csm_destroy(csm_handle m) {
                     m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos, m->qkv0_tab};
     for (void* p : ptrs) (void)hipFree(p);
     for (void* p : m->pk_allocs) (void)hipFree(p);
-    if (m->bb_block) { (void)hipFree(m->bg_q); (void)hipFree(m->bg_a); (void)hipFree(m->b_state); }
+    if (m->bb_block) { (void)hipFree(m->bg_q); (void)hipFree(m->bg_a); (void)hipFree(m->bg_s); (void)hipFree(m->b_state); }
     if (m->persist) {
         void* pp[] = {m->pg_q, m->pg_h1, m->pg_h2, m->pg_l, m->pg_p, m->p_state, m->p_w2s, m->p_w13p, m->p_wsm, m->p_norms};
         for (void* p : pp) (void)hipFree(p);
