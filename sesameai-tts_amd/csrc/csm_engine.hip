@@ -82,6 +82,9 @@ struct CsmModel {
     // backbone attention block of a batch-1 decode step as one launch per layer (bb_block.cuh)
     bool bb_block;
     dp_u64 *bg_q, *bg_a, *bg_s;
+    bool bb_layer;                      // ... and the MLP in the same launch (k_bb_layer)
+    dp_u64 *bg_h, *bg_p;
+    uint4* b_w2t;                       // [layers] W2 re-tiled, 256 * 4 * 2048 pieces each
     uint32_t* b_state;                  // [0] tag epoch, [1] give-up code
     uint4 *p_w2s, *p_w13p;              // [4 layers] re-tiled W2 / packed W1|W3, constant layer stride
     bf16_t *p_wsm, *p_norms;            // [4][2560][1024] q|k|v|o rows, [4][2][1024] norm scales
@@ -591,6 +594,18 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
             b.wq = (const bf16_t*)w.wq; b.wk = (const bf16_t*)w.wk; b.wv = (const bf16_t*)w.wv; b.wo = (const bf16_t*)w.wo;
             b.sa_norm = (const bf16_t*)w.sa_norm; b.rope = S.rope; b.h = h; b.kc = kc; b.vc = vc; b.pos = pos; b.smax = S.cache_len;
             b.eps = S.d.norm_eps; b.gQ = m->bg_q; b.gA = m->bg_a; b.gS = m->bg_s; b.err = m->b_state + 1; b.epoch = m->b_state; b.poll_sleep = m->persist ? m->p_poll : 1;
+            if (m->bb_layer) {
+                // ... and the MLP: the whole layer in one launch
+                BbLayerArgs L;
+                memset(&L, 0, sizeof L);
+                L.wq = b.wq; L.wk = b.wk; L.wv = b.wv; L.wo = b.wo; L.sa_norm = b.sa_norm; L.rope = b.rope; L.h = b.h; L.kc = b.kc; L.vc = b.vc;
+                L.pos = b.pos; L.smax = b.smax; L.eps = b.eps; L.gQ = b.gQ; L.gA = b.gA; L.gS = b.gS; L.err = b.err; L.epoch = b.epoch; L.poll_sleep = b.poll_sleep;
+                L.w1 = (const bf16_t*)w.w1; L.w3 = (const bf16_t*)w.w3; L.mlp_norm = (const bf16_t*)w.mlp_norm;
+                L.w2t = m->b_w2t + (size_t)l * 256 * 4 * BB_D; L.gH = m->bg_h; L.gP = m->bg_p;
+                hipLaunchKernelGGL(k_bb_layer, dim3(DP_NB), dim3(512), BL_LDS_BYTES, st, L);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                continue;
+            }
             hipLaunchKernelGGL(k_bb_attn_block, dim3(DP_NB), dim3(512), 0, st, b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             block_done = true;
@@ -1084,7 +1099,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     }
     m->p_stamps = nullptr;
     // ---- backbone attention block: the CSM-1B backbone shape on a 256-CU device, bf16 weight stream ----
-    m->bb_block = false;
+    m->bb_block = false; m->bb_layer = false;
     {
         const char* ev = getenv("CSM_BB_BLOCK");
         const CsmLlamaDims& bc = cfg->backbone;
@@ -1102,6 +1117,23 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
             HIPCHK((CsmModel*)nullptr, hipMemset(m->b_state, 0, 16));
             HIPCHK((CsmModel*)nullptr, hipDeviceSynchronize());
             m->bb_block = true;
+            const char* ev2 = getenv("CSM_BB_LAYER");
+            m->bb_layer = false;
+            if (!(ev2 && ev2[0] == '0') && bc.ffn == 8192) {
+                const size_t per_layer = (size_t)256 * 4 * BB_D;
+                HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->bg_h, (size_t)DP_NREP * 1024 * 8));
+                HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->bg_p, (size_t)256 * 256 * 8 * 8));
+                HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->b_w2t, per_layer * 16 * bc.n_layers));
+                HIPCHK((CsmModel*)nullptr, hipMemset(m->bg_h, 0, (size_t)DP_NREP * 1024 * 8));
+                HIPCHK((CsmModel*)nullptr, hipMemset(m->bg_p, 0, (size_t)256 * 256 * 8 * 8));
+                for (int l = 0; l < bc.n_layers; ++l)
+                    hipLaunchKernelGGL(k_bb_retile_w2, dim3((unsigned)((per_layer + 255) / 256)), dim3(256), 0, nullptr, (const bf16_t*)w->bb[l].w2,
+                                       m->b_w2t + (size_t)l * per_layer);
+                HIPCHK((CsmModel*)nullptr, hipGetLastError());
+                HIPCHK((CsmModel*)nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bb_layer), hipFuncAttributeMaxDynamicSharedMemorySize, BL_LDS_BYTES));
+                HIPCHK((CsmModel*)nullptr, hipDeviceSynchronize());
+                m->bb_layer = true;
+            }
         }
     }
     *out = m;
@@ -1119,6 +1151,7 @@ extern "C" void csm_destroy(csm_handle m) {
     for (void* p : ptrs) (void)hipFree(p);
     for (void* p : m->pk_allocs) (void)hipFree(p);
     if (m->bb_block) { (void)hipFree(m->bg_q); (void)hipFree(m->bg_a); (void)hipFree(m->bg_s); (void)hipFree(m->b_state); }
+    if (m->bb_block && m->bb_layer) { (void)hipFree(m->bg_h); (void)hipFree(m->bg_p); (void)hipFree(m->b_w2t); }
     if (m->persist) {
         void* pp[] = {m->pg_q, m->pg_h1, m->pg_h2, m->pg_l, m->pg_p, m->p_state, m->p_w2s, m->p_w13p, m->p_wsm, m->p_norms};
         for (void* p : pp) (void)hipFree(p);
