@@ -330,7 +330,13 @@ struct BbLayerArgs {
     const bf16_t *w1, *w3, *mlp_norm;     // gate / up [8192][2048] row-major
     const uint4* w2t;                     // W2 re-tiled [256 cu][4 k chunks][2048 rows] 16-byte pieces (k_bb_retile_w2)
     dp_u64 *gH, *gP;                      // [8][1024] h1 granules; [256 owners][256 producers][8 rows] fp32 partials
+    dp_u64* stamps;                       // timeline build: 16 s_memrealtime stamps of workgroup 100 (layer 8)
 };
+#ifdef DP_TIMELINE
+#define BL_STAMP(i_, cond_) do { if (a.stamps != nullptr && cu == 100 && lane == 0 && (cond_)) a.stamps[i_] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BL_STAMP(i_, cond_) do { } while (0)
+#endif
 #define BL_L_H1 7232                      // 4096: h1 (the residual stream after the attention block)
 #define BL_L_HL 11328                     // 64: this CU's 32 h values
 #define BL_L_G2 11392                     // 4096: mlp_norm's scale
@@ -353,6 +359,7 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
     dp_lu32* misc = (dp_lu32*)(lds + BB_L_MISC);
     dp_lvu32* ab = (dp_lvu32*)(misc + BB_M_ABORT);
     if (threadIdx.x < 16) misc[threadIdx.x] = 0;
+    BL_STAMP(0, wave == 0);
     // ---- everything that does not depend on the step's position: issued now, in the order it is consumed ---------------
     uint4 hv[4], g[4];
 #pragma unroll
@@ -368,6 +375,11 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
     if (wave < 6) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { w0[i] = ldg16<true>(reinterpret_cast<const uint4*>(wr) + i * 64 + lane); w1[i] = ldg16<true>(reinterpret_cast<const uint4*>(wr + BB_D) + i * 64 + lane); }
+    }
+    if (wave < 4) {                                     // o-projection rows: BEFORE the MLP weights in the queue (issued after them these 32 KB
+                                                        // arrived last, ~16 us in, and held the whole layer up)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { wo[i] = ldg16<true>(reinterpret_cast<const uint4*>(a.wo + (long)orow * BB_D) + i * 64 + lane); wo1[i] = ldg16<true>(reinterpret_cast<const uint4*>(a.wo + (long)(orow + 1) * BB_D) + i * 64 + lane); }
     }
     const uint32_t base = *a.epoch;
     const int p = min(max(*a.pos, 0), a.smax - 1);
@@ -427,6 +439,7 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
         a0 = wave_sum(a0); a1 = wave_sum(a1);
         const uint32_t outw = dp_rope_pair(a0, a1, cs, R0 < 2560);
         if (lane < DP_NREP) dp_gran_store(a.gQ + lane * BB_NQKV_PAIRS + pair, tagQ, outw);
+        BL_STAMP(1, wave == 0);
         if (R0 >= 2048 && lane == 0) {
             const int rk = R0 < 2560 ? R0 - 2048 : R0 - 2560;            // row inside k or v: KV head rk / 64, element rk % 64
             bf16_t* dst = (R0 < 2560 ? a.kc : a.vc) + ((long)(rk / BB_HD) * a.smax + p) * BB_HD + rk % BB_HD;
@@ -591,10 +604,6 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
             }
         }
     }
-    if (wave < 4) {                                     // the two o-projection rows of this wave (3 us ahead of their use)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { wo[i] = ldg16<true>(reinterpret_cast<const uint4*>(a.wo + (long)orow * BB_D) + i * 64 + lane); wo1[i] = ldg16<true>(reinterpret_cast<const uint4*>(a.wo + (long)(orow + 1) * BB_D) + i * 64 + lane); }
-    }
     if (attn_cu && wave == 0) {                         // (wave 0 had the fold and the publishing to do first)
 #pragma unroll
         for (int q = 0; q < 24; ++q) buf[q] = load_gu(q >> 3, (q >> 2) & 1, q & 3);
@@ -606,6 +615,7 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { ((dp_lu32*)(lds + BB_L_ATT))[2 * (j * 64 + lane)] = v[2 * j]; ((dp_lu32*)(lds + BB_L_ATT))[2 * (j * 64 + lane) + 1] = v[2 * j + 1]; }
         dp_flag((dp_lvu32*)(misc + BB_M_FATT), tagA);
+        BL_STAMP(2, true);
         // the gather wave's own share of the MLP weights: only now -- its sweeps wait on vmcnt(0), and loads issued at entry
         // would have put the whole 100 MB stream of the chip in front of the attention hand-off
 #pragma unroll
@@ -622,6 +632,7 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
         a0 = wave_sum(a0); a1 = wave_sum(a1);
         const uint32_t outw = dp_resid_pair(a0, a1, hres);
         if (lane < DP_NREP) dp_gran_store(a.gH + lane * 1024 + 4 * cu + wave, tagH, outw);
+        BL_STAMP(3, wave == 0);
     }
     // ---- the MLP: h1 -> mlp_norm -> this CU's 32 (gate, up) pairs -> 32 h values -> its 32-column slice of W2 -> partials ----
     if (wave == 7) {
@@ -634,6 +645,7 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
             for (int j = 0; j < 4; ++j) { ((dp_lu32*)(lds + BL_L_H1))[2 * ((hf * 4 + j) * 64 + lane)] = v[2 * j]; ((dp_lu32*)(lds + BL_L_H1))[2 * ((hf * 4 + j) * 64 + lane) + 1] = v[2 * j + 1]; }
         }
         dp_flag((dp_lvu32*)(misc + BL_M_FH), tagH);
+        BL_STAMP(4, true);
     } else if (!bb_wait_flag((dp_lvu32*)(misc + BL_M_FH), tagH, ab, a.err, 0xC08u, lane)) return;
     {
         const dp_lu4* hs = (const dp_lu4*)(lds + BL_L_H1);
@@ -658,6 +670,7 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
             const uint32_t hv1 = dp_swiglu(ag, au);
             if (lane == 0) ((dp_lu16*)(lds + BL_L_HL))[4 * wave + i] = (unsigned short)hv1;
         }
+        BL_STAMP(5, wave == 0); BL_STAMP(6, wave == 7);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(misc + BL_M_CD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         {
@@ -669,7 +682,9 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
         uint4 hk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) hk[q] = dp_ldq((const dp_lu4*)(lds + BL_L_HL) + q);
+        BL_STAMP(7, wave == 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the W2 pieces are in LDS (they were issued ~10 us ago)
+        BL_STAMP(8, wave == 0); BL_STAMP(9, wave == 7);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             const int row = 256 * wave + 64 * rb + lane;
@@ -681,6 +696,7 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
             dp_gran_store(a.gP + ((long)(row >> 3) * 256 + cu) * 8 + (row & 7), tagP, __float_as_uint(pacc));
         }
     }
+    BL_STAMP(10, wave == 0); BL_STAMP(11, wave == 7);
     // ---- the rows' owner (gather wave): 256 partials per row in fixed order + residual -> h ------------------------------------
     if (wave == 7) {
         // load j of lane l: granules 2 (64 j + l), + 1 = producer 16 j + (l >> 2), rows 2 (l & 3), 2 (l & 3) + 1 of this CU's eight;
@@ -703,5 +719,6 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
             *reinterpret_cast<uint32_t*>(a.h + 8 * cu + 2 * lane) = dp_resid_pair(s0, s1, h1w);
         }
     }
+    BL_STAMP(12, wave == 7);
     if (cu == 0 && threadIdx.x == 0) *a.epoch = base + 8u;
 }

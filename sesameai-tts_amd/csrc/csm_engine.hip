@@ -602,6 +602,7 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
                 L.pos = b.pos; L.smax = b.smax; L.eps = b.eps; L.gQ = b.gQ; L.gA = b.gA; L.gS = b.gS; L.err = b.err; L.epoch = b.epoch; L.poll_sleep = b.poll_sleep;
                 L.w1 = (const bf16_t*)w.w1; L.w3 = (const bf16_t*)w.w3; L.mlp_norm = (const bf16_t*)w.mlp_norm;
                 L.w2t = m->b_w2t + (size_t)l * 256 * 4 * BB_D; L.gH = m->bg_h; L.gP = m->bg_p;
+                L.stamps = (m->p_stamps != nullptr && l == 8) ? m->p_stamps + 5312 : nullptr;        // (timeline build only)
                 hipLaunchKernelGGL(k_bb_layer, dim3(DP_NB), dim3(512), BL_LDS_BYTES, st, L);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
                 continue;

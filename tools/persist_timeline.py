@@ -100,6 +100,14 @@ def main():
     print(f"      {'argmax over the wave, last barrier':58s} {sum(vals) / max(len(vals), 1):6.2f}")
     vals = [float(sm[s_, 7] - sm[s_, 6]) for s_ in range(3, 29) if sm[s_, 7] > 0]
     print(f"      {'sampler body alone, last pass (CSM_PERSIST_TRICKLE=134 runs it twice: warm instruction cache)':58s} {sum(vals) / max(len(vals), 1):6.2f}")
+    bl = allw[5312:5312 + 16] * 0.01
+    if float(bl[12]) > 0:
+        nm = ["entry (wave 0)", "q|k|v pair published (wave 0)", "attention vector in LDS (gather wave)", "o-proj rows published (wave 0)", "h1 in LDS (gather wave)",
+              "gate/up done (wave 0)", "gate/up done (gather wave)", "h values exchanged (wave 0)", "W2 slice in LDS (wave 0)", "W2 slice in LDS (gather wave)",
+              "partials published (wave 0)", "partials published (gather wave)", "rows written (gather wave)"]
+        print("   whole-backbone-layer launch (k_bb_layer), workgroup 100, layer 8, us after entry:")
+        for i, n_ in enumerate(nm):
+            print(f"      {n_:44s} {float(bl[i] - bl[0]):6.2f}")
     whole = float(t[n_steps - 2, 19] - t[2, 19]) / (n_steps - 4)
     print(f"   step period measured directly: {whole:.2f} us")
 
