@@ -21,6 +21,7 @@
 #include "attn_flash.cuh"
 #include "sampler.cuh"
 #include "dec_persist.cuh"
+#include "dec_persist_m.cuh"
 #include "bb_block.cuh"
 
 #define BB_NSPLIT_MAX 8
@@ -89,7 +90,13 @@ struct CsmModel {
     uint4 *p_w2s, *p_w13p;              // [4 layers] re-tiled W2 / packed W1|W3, constant layer stride
     bf16_t *p_wsm, *p_norms;            // [4][2560][1024] q|k|v|o rows, [4][2][1024] norm scales
     int p_trickle, p_poll;
+    // the same for 2..32 batched utterances (dec_persist_m.cuh; env CSM_PERSIST_M=0 disables)
+    bool persist_m;
+    uint4 *pm_w13, *pm_w2;              // [4 layers] A-operand packed W1 | W3 / W2
+    char* pm_xchg;                      // exchange buffers (DM_XCHG_BYTES), 0xFF-filled in front of every launch
+    int pm_max_rows;                    // rows up to which the launch is used (env CSM_PERSIST_M_MAX, default 32)
     dp_u64* p_stamps;                   // debug timeline (csm_debug_persist_stamps), else nullptr
+    std::vector<void*> persist_allocs, bb_allocs;   // device memory of the optional all-CU launches
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
     int last_S;                         // rows per sequence of the h buffer feeding csm_depth
     // graph
@@ -691,6 +698,22 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             hipLaunchKernelGGL(k_dec_persist, dim3(DP_NB), dim3(512), DP_LDS_BYTES, st, p);
             return hipGetLastError();
         }
+        if (cb == 2 && B >= 2 && B <= m->pm_max_rows && m->persist_m) {
+            // codebooks 2..ncb-1 of a batch: one persistent launch (dec_persist_m.cuh)
+            DecPersistMArgs p;
+            memset(&p, 0, sizeof p);
+            p.wsm = m->p_wsm; p.norms = m->p_norms; p.w2m = m->pm_w2; p.w13m = m->pm_w13;
+            p.dec_norm = (const bf16_t*)m->w.dec_norm; p.head_t = (const bf16_t*)m->w.audio_head_t; p.rope = m->dec.rope;
+            p.proj_emb = m->proj_emb; p.qkv0_tab = m->qkv0_tab; p.hdec = m->hdec; p.qd = m->qd;
+            p.kc = m->dec.kc; p.vc = m->dec.vc; p.kv_layer_stride = m->dec.layer_stride;
+            p.temperature = temperature; p.topk = topk; p.noise = (const bf16_t*)noise; p.rng = m->rng; p.forced = forced;
+            p.V = V; p.ncb = ncb; p.M = B; p.frame = m->frame; p.logits_out = (bf16_t*)logits_out; p.cb_first = 2; p.cb_last = ncb - 1;
+            p.xchg = m->pm_xchg; p.err = m->p_state + 1; p.eps = c.decoder.norm_eps; p.trickle_sleep = m->p_trickle; p.poll_sleep = m->p_poll;
+            if ((e = hipMemsetAsync(m->pm_xchg, 0xFF, DM_XCHG_BYTES, st)) != hipSuccess) return e;
+            if (B <= 16) hipLaunchKernelGGL(k_dec_persist_m<1>, dim3(DP_NB), dim3(512), DM_LDS_BYTES, st, p);
+            else hipLaunchKernelGGL(k_dec_persist_m<2>, dim3(DP_NB), dim3(512), DM_LDS_BYTES, st, p);
+            return hipGetLastError();
+        }
         if (cb >= 1) {
             const int rows = cb == 1 ? 2 * B : B;
             if (cb == 1) {
@@ -920,6 +943,124 @@ static hipError_t build_qkv0_table(CsmModel* m) {
     return e;
 }
 
+// ---------------------------------------------------------------------------------------
+// optional all-CU launches: set-up that may fail without failing csm_create
+// ---------------------------------------------------------------------------------------
+struct OptAllocs {                                   // allocations of one optional block: freed together when the block is abandoned
+    std::vector<void*> ptrs;
+    bool ok = true;
+    template <class T> void get(T** p, size_t bytes, int fill = 0) {
+        *p = nullptr;
+        if (!ok) return;
+        void* v = nullptr;
+        if (hipMalloc(&v, bytes) != hipSuccess || hipMemset(v, fill, bytes) != hipSuccess) { (void)hipGetLastError(); if (v) (void)hipFree(v); ok = false; return; }
+        ptrs.push_back(v); *p = (T*)v;
+    }
+    void drop() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }
+};
+static void note_fallback(const char* what, const char* why) {
+    if (getenv("CSM_QUIET") == nullptr) fprintf(stderr, "libcsm_hip: %s disabled (%s): the launch chain runs instead\n", what, why);
+}
+// A launch of DP_NB workgroups whose waves wait for each other is only correct if all of them are resident at once: ask
+// the runtime whether one workgroup of this kernel (512 threads, `lds` bytes) fits a CU, and whether the device has DP_NB CUs.
+template <class K>
+static bool all_cu_launch_fits(K kernel, size_t lds, const char* what) {
+    int ncu = 0, dev_ = 0, per_cu = 0;
+    (void)hipGetDevice(&dev_);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev_);
+    if (ncu < DP_NB) { note_fallback(what, "fewer than 256 compute units"); return false; }
+    if (lds > 0 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError(); note_fallback(what, "dynamic LDS size refused"); return false;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 512, lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError(); note_fallback(what, "occupancy query: no workgroup fits a compute unit"); return false;
+    }
+    return true;
+}
+
+static void setup_persist(CsmModel* m) {
+    const CsmConfig* cfg = &m->cfg;
+    const char* ev = getenv("CSM_PERSIST");
+    const CsmLlamaDims& dc = cfg->decoder;
+    // the in-kernel sampler's candidate lists hold DP_CAND_SLOTS entries each
+    const bool shape_ok = dc.n_layers == DP_NL && dc.dim == DP_D && dc.ffn == DP_FFN && dc.n_heads == 8 && dc.n_kv_heads == 2 &&
+                          cfg->n_codebooks >= 3 && cfg->n_codebooks <= 32 && cfg->audio_vocab <= DP_CAND_SLOTS && cfg->audio_vocab <= 2 * DP_LSLOTS;
+    // (fp8 mode too: the launch streams the bf16 weights, which there ARE the dequantised e4m3 values -- byte * scale is
+    //  exactly a bf16 -- so it computes what the fp8 chain computes; the decoder is bound by its hand-offs, not by bytes)
+    if ((ev && ev[0] == '0') || !shape_ok || m->qkv0_tab == nullptr) return;
+    if (!all_cu_launch_fits(k_dec_persist, DP_LDS_BYTES, "persistent depth decoder")) return;
+    OptAllocs A;
+    A.get(&m->pg_q, (size_t)DP_NREP * 768 * 8); A.get(&m->pg_h1, (size_t)DP_NREP * 512 * 8); A.get(&m->pg_h2, (size_t)DP_NREP * 512 * 8);
+    A.get(&m->pg_l, (size_t)DP_NREP * DP_LSLOTS * 8); A.get(&m->pg_p, (size_t)256 * 1024 * 8); A.get(&m->p_state, 16);
+    A.get(&m->p_w2s, (size_t)DP_NL * DP_W2S_U4 * 16); A.get(&m->p_w13p, (size_t)DP_NL * DP_W13P_U4 * 16);
+    A.get(&m->p_wsm, (size_t)DP_NL * DP_WSM_ROWS * DP_D * 2); A.get(&m->p_norms, (size_t)DP_NL * 2 * DP_D * 2);
+    if (!A.ok) { A.drop(); m->p_state = nullptr; note_fallback("persistent depth decoder", "allocation failed"); return; }
+    bool ok = true;
+    for (int l = 0; l < DP_NL && ok; ++l) {
+        const CsmLayerWeights& lw = m->w.dec[l];
+        hipLaunchKernelGGL(k_dp_retile_w2, dim3(4096), dim3(256), 0, nullptr, (const bf16_t*)lw.w2, m->p_w2s + (size_t)l * DP_W2S_U4);
+        hipLaunchKernelGGL(k_dp_pack_gateup, dim3(256 * 4 * 32 * 64 / 256), dim3(256), 0, nullptr, (const bf16_t*)lw.w1,
+                           (const bf16_t*)lw.w3, m->p_w13p + (size_t)l * DP_W13P_U4);
+        bf16_t* dst = m->p_wsm + (size_t)l * DP_WSM_ROWS * DP_D;
+        ok = ok && hipMemcpy(dst, lw.wq, (size_t)1024 * DP_D * 2, hipMemcpyDeviceToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(dst + (size_t)1024 * DP_D, lw.wk, (size_t)256 * DP_D * 2, hipMemcpyDeviceToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(dst + (size_t)1280 * DP_D, lw.wv, (size_t)256 * DP_D * 2, hipMemcpyDeviceToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(dst + (size_t)1536 * DP_D, lw.wo, (size_t)1024 * DP_D * 2, hipMemcpyDeviceToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(m->p_norms + (size_t)(2 * l) * DP_D, lw.sa_norm, (size_t)DP_D * 2, hipMemcpyDeviceToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(m->p_norms + (size_t)(2 * l + 1) * DP_D, lw.mlp_norm, (size_t)DP_D * 2, hipMemcpyDeviceToDevice) == hipSuccess;
+    }
+    ok = ok && hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); A.drop(); m->p_state = nullptr; note_fallback("persistent depth decoder", "weight re-tiling failed"); return; }
+    { const char* e2 = getenv("CSM_PERSIST_TRICKLE"); m->p_trickle = e2 ? atoi(e2) : 8; }       // (swept 4..16 x 0..3 at the final state: 8 / 1)
+    { const char* e2 = getenv("CSM_PERSIST_POLL"); m->p_poll = e2 ? atoi(e2) : 1; }
+    m->persist = true;
+    m->persist_allocs = A.ptrs;
+    // ---- the batched form (2..32 rows): shares the q|k|v|o rows and the norms, own packed MLP weights and exchange buffers ----
+    const char* evm = getenv("CSM_PERSIST_M");
+    { const char* e2 = getenv("CSM_PERSIST_M_MAX"); m->pm_max_rows = e2 ? atoi(e2) : 32; if (m->pm_max_rows > 32) m->pm_max_rows = 32; }
+    if ((evm && evm[0] == '0') || m->max_batch < 2 || cfg->audio_vocab <= 2048 || cfg->audio_vocab > 2056) return;
+    if (!all_cu_launch_fits(k_dec_persist_m<1>, DM_LDS_BYTES, "batched persistent depth decoder") ||
+        !all_cu_launch_fits(k_dec_persist_m<2>, DM_LDS_BYTES, "batched persistent depth decoder")) return;
+    OptAllocs Bm;
+    Bm.get(&m->pm_w13, (size_t)DP_NL * DM_W13M_U4 * 16); Bm.get(&m->pm_w2, (size_t)DP_NL * DM_W2M_U4 * 16); Bm.get(&m->pm_xchg, (size_t)DM_XCHG_BYTES, 0xFF);
+    if (!Bm.ok) { Bm.drop(); note_fallback("batched persistent depth decoder", "allocation failed"); return; }
+    for (int l = 0; l < DP_NL; ++l) {
+        const CsmLayerWeights& lw = m->w.dec[l];
+        hipLaunchKernelGGL(k_dm_pack_gateup, dim3((unsigned)(DM_W13M_U4 / 256)), dim3(256), 0, nullptr, (const bf16_t*)lw.w1, (const bf16_t*)lw.w3,
+                           m->pm_w13 + (size_t)l * DM_W13M_U4);
+        hipLaunchKernelGGL(k_dm_pack_down, dim3((unsigned)(DM_W2M_U4 / 256)), dim3(256), 0, nullptr, (const bf16_t*)lw.w2, m->pm_w2 + (size_t)l * DM_W2M_U4);
+    }
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); Bm.drop(); note_fallback("batched persistent depth decoder", "weight packing failed"); return; }
+    m->persist_m = true;
+    m->persist_allocs.insert(m->persist_allocs.end(), Bm.ptrs.begin(), Bm.ptrs.end());
+}
+
+static void setup_bb_block(CsmModel* m) {
+    const char* ev = getenv("CSM_BB_BLOCK");
+    const CsmLlamaDims& bc = m->cfg.backbone;
+    if ((ev && ev[0] == '0') || bc.dim != BB_D || bc.n_heads != BB_NH || bc.n_kv_heads != BB_NKV || m->w.fp8) return;
+    if (!all_cu_launch_fits(k_bb_attn_block, 0, "one-launch backbone attention block")) return;
+    OptAllocs A;
+    A.get(&m->bg_q, (size_t)DP_NREP * BB_NQKV_PAIRS * 8); A.get(&m->bg_a, (size_t)DP_NREP * 1024 * 8); A.get(&m->b_state, 16);
+    A.get(&m->bg_s, (size_t)BB_NH * 8 * 72 * 8);
+    if (!A.ok || hipDeviceSynchronize() != hipSuccess) { A.drop(); m->b_state = nullptr; note_fallback("one-launch backbone attention block", "allocation failed"); return; }
+    m->bb_block = true;
+    m->bb_allocs = A.ptrs;
+    const char* ev2 = getenv("CSM_BB_LAYER");
+    if ((ev2 && ev2[0] == '0') || bc.ffn != 8192) return;
+    if (!all_cu_launch_fits(k_bb_layer, BL_LDS_BYTES, "one-launch backbone layer")) return;
+    const size_t per_layer = (size_t)256 * 4 * BB_D;
+    OptAllocs L;
+    L.get(&m->bg_h, (size_t)DP_NREP * 1024 * 8); L.get(&m->bg_p, (size_t)256 * 256 * 8 * 8); L.get(&m->b_w2t, per_layer * 16 * bc.n_layers);
+    if (!L.ok) { L.drop(); note_fallback("one-launch backbone layer", "allocation failed"); return; }
+    for (int l = 0; l < bc.n_layers; ++l)
+        hipLaunchKernelGGL(k_bb_retile_w2, dim3((unsigned)((per_layer + 255) / 256)), dim3(256), 0, nullptr, (const bf16_t*)m->w.bb[l].w2,
+                           m->b_w2t + (size_t)l * per_layer);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); L.drop(); note_fallback("one-launch backbone layer", "weight re-tiling failed"); return; }
+    m->bb_layer = true;
+    m->bb_allocs.insert(m->bb_allocs.end(), L.ptrs.begin(), L.ptrs.end());
+}
+
 extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_batch, int max_rows, int max_frames,
                           csm_handle* out) {
     if (!cfg || !w || !out || max_batch < 1 || max_frames < 1) return fail(nullptr, CSM_E_INVALID, "csm_create: null/invalid argument");
@@ -1047,96 +1188,12 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
         const char* ev = getenv("CSM_QKV0_TABLE");
         if (!(ev && ev[0] == '0') && ncb > 2) HIPCHK((CsmModel*)nullptr, build_qkv0_table(m));
     }
-    // ---- persistent depth decoder: the production decoder shape on a 256-CU device, bf16 weight stream ----
-    m->persist = false;
-    {
-        const char* ev = getenv("CSM_PERSIST");
-        const CsmLlamaDims& dc = cfg->decoder;
-        int ncu = 0, dev_ = 0;
-        (void)hipGetDevice(&dev_);
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev_);
-        const bool shape_ok = dc.n_layers == DP_NL && dc.dim == DP_D && dc.ffn == DP_FFN && dc.n_heads == 8 && dc.n_kv_heads == 2 &&
-                              cfg->n_codebooks >= 3 && cfg->n_codebooks <= 32 && cfg->audio_vocab <= 2 * DP_LSLOTS && cfg->audio_vocab <= 2560;
-        // (fp8 mode too: the launch streams the bf16 weights, which there ARE the dequantised e4m3 values -- byte * scale is
-        //  exactly a bf16 -- so it computes what the fp8 chain computes; the decoder is bound by its hand-offs, not by bytes)
-        if (!(ev && ev[0] == '0') && shape_ok && ncu >= DP_NB && m->qkv0_tab != nullptr) {
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pg_q, (size_t)DP_NREP * 768 * 8));
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pg_h1, (size_t)DP_NREP * 512 * 8));
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pg_h2, (size_t)DP_NREP * 512 * 8));
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pg_l, (size_t)DP_NREP * DP_LSLOTS * 8));
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->pg_p, (size_t)256 * 1024 * 8));
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_state, 16));
-            HIPCHK((CsmModel*)nullptr, hipMemset(m->pg_q, 0, (size_t)DP_NREP * 768 * 8));
-            HIPCHK((CsmModel*)nullptr, hipMemset(m->pg_h1, 0, (size_t)DP_NREP * 512 * 8));
-            HIPCHK((CsmModel*)nullptr, hipMemset(m->pg_h2, 0, (size_t)DP_NREP * 512 * 8));
-            HIPCHK((CsmModel*)nullptr, hipMemset(m->pg_l, 0, (size_t)DP_NREP * DP_LSLOTS * 8));
-            HIPCHK((CsmModel*)nullptr, hipMemset(m->pg_p, 0, (size_t)256 * 1024 * 8));
-            HIPCHK((CsmModel*)nullptr, hipMemset(m->p_state, 0, 16));
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_w2s, (size_t)DP_NL * DP_W2S_U4 * 16));
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_w13p, (size_t)DP_NL * DP_W13P_U4 * 16));
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_wsm, (size_t)DP_NL * DP_WSM_ROWS * DP_D * 2));
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->p_norms, (size_t)DP_NL * 2 * DP_D * 2));
-            for (int l = 0; l < DP_NL; ++l) {
-                const CsmLayerWeights& lw = m->w.dec[l];
-                hipLaunchKernelGGL(k_dp_retile_w2, dim3(4096), dim3(256), 0, nullptr, (const bf16_t*)lw.w2, m->p_w2s + (size_t)l * DP_W2S_U4);
-                hipLaunchKernelGGL(k_dp_pack_gateup, dim3(256 * 4 * 32 * 64 / 256), dim3(256), 0, nullptr, (const bf16_t*)lw.w1,
-                                   (const bf16_t*)lw.w3, m->p_w13p + (size_t)l * DP_W13P_U4);
-                bf16_t* dst = m->p_wsm + (size_t)l * DP_WSM_ROWS * DP_D;
-                HIPCHK((CsmModel*)nullptr, hipMemcpy(dst, lw.wq, (size_t)1024 * DP_D * 2, hipMemcpyDeviceToDevice));
-                HIPCHK((CsmModel*)nullptr, hipMemcpy(dst + (size_t)1024 * DP_D, lw.wk, (size_t)256 * DP_D * 2, hipMemcpyDeviceToDevice));
-                HIPCHK((CsmModel*)nullptr, hipMemcpy(dst + (size_t)1280 * DP_D, lw.wv, (size_t)256 * DP_D * 2, hipMemcpyDeviceToDevice));
-                HIPCHK((CsmModel*)nullptr, hipMemcpy(dst + (size_t)1536 * DP_D, lw.wo, (size_t)1024 * DP_D * 2, hipMemcpyDeviceToDevice));
-                HIPCHK((CsmModel*)nullptr, hipMemcpy(m->p_norms + (size_t)(2 * l) * DP_D, lw.sa_norm, (size_t)DP_D * 2, hipMemcpyDeviceToDevice));
-                HIPCHK((CsmModel*)nullptr, hipMemcpy(m->p_norms + (size_t)(2 * l + 1) * DP_D, lw.mlp_norm, (size_t)DP_D * 2, hipMemcpyDeviceToDevice));
-            }
-            HIPCHK((CsmModel*)nullptr, hipGetLastError());
-            HIPCHK((CsmModel*)nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dec_persist),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_BYTES));
-            HIPCHK((CsmModel*)nullptr, hipDeviceSynchronize());
-            { const char* e2 = getenv("CSM_PERSIST_TRICKLE"); m->p_trickle = e2 ? atoi(e2) : 8; }       // (swept 4..16 x 0..3 at the final state: 8 / 1)
-            { const char* e2 = getenv("CSM_PERSIST_POLL"); m->p_poll = e2 ? atoi(e2) : 1; }
-            m->persist = true;
-        }
-    }
-    m->p_stamps = nullptr;
-    // ---- backbone attention block: the CSM-1B backbone shape on a 256-CU device, bf16 weight stream ----
-    m->bb_block = false; m->bb_layer = false;
-    {
-        const char* ev = getenv("CSM_BB_BLOCK");
-        const CsmLlamaDims& bc = cfg->backbone;
-        int ncu = 0, dev_ = 0;
-        (void)hipGetDevice(&dev_);
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev_);
-        if (!(ev && ev[0] == '0') && bc.dim == BB_D && bc.n_heads == BB_NH && bc.n_kv_heads == BB_NKV && ncu >= DP_NB && !w->fp8) {
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->bg_q, (size_t)DP_NREP * BB_NQKV_PAIRS * 8));
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->bg_a, (size_t)DP_NREP * 1024 * 8));
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->b_state, 16));
-            HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->bg_s, (size_t)BB_NH * 8 * 72 * 8));
-            HIPCHK((CsmModel*)nullptr, hipMemset(m->bg_s, 0, (size_t)BB_NH * 8 * 72 * 8));
-            HIPCHK((CsmModel*)nullptr, hipMemset(m->bg_q, 0, (size_t)DP_NREP * BB_NQKV_PAIRS * 8));
-            HIPCHK((CsmModel*)nullptr, hipMemset(m->bg_a, 0, (size_t)DP_NREP * 1024 * 8));
-            HIPCHK((CsmModel*)nullptr, hipMemset(m->b_state, 0, 16));
-            HIPCHK((CsmModel*)nullptr, hipDeviceSynchronize());
-            m->bb_block = true;
-            const char* ev2 = getenv("CSM_BB_LAYER");
-            m->bb_layer = false;
-            if (!(ev2 && ev2[0] == '0') && bc.ffn == 8192) {
-                const size_t per_layer = (size_t)256 * 4 * BB_D;
-                HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->bg_h, (size_t)DP_NREP * 1024 * 8));
-                HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->bg_p, (size_t)256 * 256 * 8 * 8));
-                HIPCHK((CsmModel*)nullptr, hipMalloc((void**)&m->b_w2t, per_layer * 16 * bc.n_layers));
-                HIPCHK((CsmModel*)nullptr, hipMemset(m->bg_h, 0, (size_t)DP_NREP * 1024 * 8));
-                HIPCHK((CsmModel*)nullptr, hipMemset(m->bg_p, 0, (size_t)256 * 256 * 8 * 8));
-                for (int l = 0; l < bc.n_layers; ++l)
-                    hipLaunchKernelGGL(k_bb_retile_w2, dim3((unsigned)((per_layer + 255) / 256)), dim3(256), 0, nullptr, (const bf16_t*)w->bb[l].w2,
-                                       m->b_w2t + (size_t)l * per_layer);
-                HIPCHK((CsmModel*)nullptr, hipGetLastError());
-                HIPCHK((CsmModel*)nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bb_layer), hipFuncAttributeMaxDynamicSharedMemorySize, BL_LDS_BYTES));
-                HIPCHK((CsmModel*)nullptr, hipDeviceSynchronize());
-                m->bb_layer = true;
-            }
-        }
-    }
+    // ---- all-CU launches (persistent depth decoders, one-launch backbone layers): optional fast paths.  Anything that
+    //      fails here (shape, device, occupancy, allocation) leaves the flag off and the launch chain in charge.
+    m->persist = false; m->persist_m = false; m->p_stamps = nullptr; m->bb_block = false; m->bb_layer = false;
+    m->p_state = nullptr; m->b_state = nullptr;
+    setup_persist(m);
+    setup_bb_block(m);
     *out = m;
     return CSM_OK;
 }
@@ -1151,12 +1208,9 @@ extern "C" void csm_destroy(csm_handle m) {
                     m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos, m->qkv0_tab};
     for (void* p : ptrs) (void)hipFree(p);
     for (void* p : m->pk_allocs) (void)hipFree(p);
-    if (m->bb_block) { (void)hipFree(m->bg_q); (void)hipFree(m->bg_a); (void)hipFree(m->bg_s); (void)hipFree(m->b_state); }
-    if (m->bb_block && m->bb_layer) { (void)hipFree(m->bg_h); (void)hipFree(m->bg_p); (void)hipFree(m->b_w2t); }
-    if (m->persist) {
-        void* pp[] = {m->pg_q, m->pg_h1, m->pg_h2, m->pg_l, m->pg_p, m->p_state, m->p_w2s, m->p_w13p, m->p_wsm, m->p_norms};
-        for (void* p : pp) (void)hipFree(p);
-    }
+    for (void* p : m->persist_allocs) (void)hipFree(p);
+    for (void* p : m->bb_allocs) (void)hipFree(p);
+    if (m->p_stamps) (void)hipFree(m->p_stamps);
     delete m;
 }
 

@@ -104,13 +104,15 @@ struct DecPersistArgs {
 #define DP_OFF_XC (DP_OFF_U + 2048)
 #define DP_OFF_QB (DP_OFF_U + 4096)
 #define DP_OFF_ATT (DP_OFF_U + 6144)
+#define DP_CAND_SLOTS 2112                           // entries of each sampler candidate list (csm_create admits audio_vocab <= this)
 #define DP_OFF_CANDT (DP_OFF_U)
-#define DP_OFF_CANDI (DP_OFF_U + 8448)
+#define DP_OFF_CANDI (DP_OFF_U + DP_CAND_SLOTS * 4)
 #define DP_OFF_LOGITS (DP_OFF_U + 16896)             // 2560 bf16
 #define DP_OFF_SMAX (DP_OFF_LOGITS + 5120)           // 256 u32
 #define DP_OFF_PS (DP_OFF_SMAX + 1024)               // attention P rows: 8 waves x 32 floats
 #define DP_OFF_MISC (DP_OFF_PS + 1024)
 #define DP_LDS_BYTES (DP_OFF_MISC + 512)
+static_assert(DP_OFF_CANDI + DP_CAND_SLOTS * 4 <= DP_OFF_LOGITS, "sampler candidate lists overrun the LDS logits");
 // misc words
 #define DP_M_HL 0        // 16 words: this CU's 32 h values
 #define DP_M_H0 16       // 2 words: residual rows 4cu..4cu+3 entering the layer

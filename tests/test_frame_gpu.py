@@ -957,6 +957,60 @@ def test_persistent_decoder_vs_launch_chain_and_golden(csm1b, monkeypatch):
     #  the sampler INSIDE the launch is the reference's: next test)
 
 
+@pytest.mark.parametrize("B", [2, 5, 16, 17, 32])
+def test_batched_persistent_decoder_vs_launch_chain(csm1b, monkeypatch, B):
+    """The M-row persistent launch (csrc/dec_persist_m.cuh, codebooks 2..31 of B = 2..32 utterances) against the chain of
+    launches it replaces, same weights, DIFFERENT prompts per utterance, teacher-forced on random codes: codebooks 0 and 1
+    never enter the launch (bit-identical), codebooks 2..31 differ only in fp32 summation order (16 x 16 x 32 matrix ops,
+    the MLP's 16-way split) -- logits within the oracle's own bf16-vs-fp32 gap, greedy indices equal away from ties.  Then a
+    sampled free run through the captured graph: every frame must be a valid code block and the launch must not give up."""
+    import bench
+    from oracle import csm_ref as C
+    from sesameai.models import Model, csm_1b_args
+    gold, sd = csm1b
+    noise = float(gold["bf16_vs_fp32_gap"].max())
+    tok, msk = bench.synthetic_prompt(_bench_args(), B, C.csm_1b().text_vocab_size, seed0=7000)
+    tok, msk = tok[:, :48], msk[:, :48]                          # short prompts: the decoder is what is compared
+    S = tok.shape[1]
+    g = torch.Generator().manual_seed(B)
+    forced = torch.randint(0, 2048, (3, B, 32), generator=g)
+    outs = {}
+    for name, env in (("persistent", "1"), ("chain", "0")):
+        monkeypatch.setenv("CSM_PERSIST_M", env)
+        m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S)
+        m.setup_caches(B)
+        m.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+        per_frame = []
+        for f in range(3):
+            out, logits = m.depth(B, 1.0, 1, forced=forced[f], want_logits=True, commit=False)
+            per_frame.append((out.cpu(), logits.float().cpu()))
+            row = torch.zeros(B, 1, 33, dtype=torch.long); row[:, 0, :32] = forced[f]
+            rmask = torch.ones(B, 1, 33, dtype=torch.bool); rmask[:, 0, 32] = False
+            m.prefill(row, rmask, torch.full((B, 1), S + f))
+        m.reset_caches(); m.seed(99)
+        m.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+        m.depth(B, 0.9, 50, commit=True)
+        for _ in range(5):
+            m.step(B, 0.9, 50)
+        frames, eos = m.read_frames(B)                           # raises if a launch gave up
+        assert frames.shape == (6, B, 32) and int(frames.min()) >= 0 and int(frames.max()) < 2051
+        outs[name] = (per_frame, frames)
+        del m
+    worst, n_idx = 0.0, 0
+    for f in range(3):
+        (op, lp), (oc, lc) = outs["persistent"][0][f], outs["chain"][0][f]
+        assert torch.equal(lp[:2], lc[:2]) and torch.equal(op[:, :2], oc[:, :2]), "codebooks 0, 1 do not run in the persistent launch"
+        worst = max(worst, (lp - lc).abs().max().item())
+        top2 = torch.topk(lc, 2, dim=-1)[0]                      # [32][B][2]
+        for b, cb in (op != oc).nonzero().tolist():
+            n_idx += 1
+            assert float(top2[cb, b, 0] - top2[cb, b, 1]) <= 2 * noise, f"frame {f} utterance {b} codebook {cb}: greedy index differs away from a tie"
+    same = (outs["persistent"][1] == outs["chain"][1]).all(dim=2).all(dim=1)
+    print(f"batched persistent vs chain, B={B}: max|dlogit| = {worst:.4f} (oracle noise floor {noise:.4f}); {n_idx} of {3 * 32 * B} greedy indices differ; "
+          f"sampled free run: first {int(same.float().cumprod(0).sum())} of {same.numel()} frames identical")
+    assert worst <= noise, "the two decoder paths differ by more than the oracle's own bf16-vs-fp32 gap"
+
+
 _FAULT_SCRIPT = r"""
 import os, sys, time
 os.environ["CSM_HIP_TIMELINE"] = "1"          # the library build that carries the fault-injection hook
