@@ -708,7 +708,7 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             p.kc = m->dec.kc; p.vc = m->dec.vc; p.kv_layer_stride = m->dec.layer_stride;
             p.temperature = temperature; p.topk = topk; p.noise = (const bf16_t*)noise; p.rng = m->rng; p.forced = forced;
             p.V = V; p.ncb = ncb; p.M = B; p.frame = m->frame; p.logits_out = (bf16_t*)logits_out; p.cb_first = 2; p.cb_last = ncb - 1;
-            p.xchg = m->pm_xchg; p.err = m->p_state + 1; p.eps = c.decoder.norm_eps; p.trickle_sleep = m->p_trickle; p.poll_sleep = m->p_poll;
+            p.xchg = m->pm_xchg; p.stamps = m->p_stamps; p.err = m->p_state + 1; p.eps = c.decoder.norm_eps; p.trickle_sleep = m->p_trickle; p.poll_sleep = m->p_poll;
             if ((e = hipMemsetAsync(m->pm_xchg, 0xFF, DM_XCHG_BYTES, st)) != hipSuccess) return e;
             if (B <= 16) hipLaunchKernelGGL(k_dec_persist_m<1>, dim3(DP_NB), dim3(512), DM_LDS_BYTES, st, p);
             else hipLaunchKernelGGL(k_dec_persist_m<2>, dim3(DP_NB), dim3(512), DM_LDS_BYTES, st, p);

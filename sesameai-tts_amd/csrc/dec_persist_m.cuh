@@ -28,12 +28,11 @@
 #include "dec_persist.cuh"
 
 #define DM_R 3
-#define DM_LROW 2112                              // logits row pitch (elements)
 #define DM_X_BYTES (32 * 1024 * 2)
 #define DM_Q_BYTES (32 * 1536 * 2)
 #define DM_HG_BYTES (16 * 32 * 512 * 2)
 #define DM_P_BYTES (16 * 16 * 32 * 64 * 4)
-#define DM_L_BYTES (32 * DM_LROW * 2)
+#define DM_L_BYTES (257 * 512)                    // logits: [256 workgroups + the tail block][32 rows][8] bf16
 #define DM_T_BYTES 128
 #define DM_OFF_X 0
 #define DM_OFF_A (DM_OFF_X + DM_R * DM_X_BYTES)
@@ -104,7 +103,9 @@ struct DecPersistMArgs {
     uint32_t* err;
     float eps;
     int trickle_sleep, poll_sleep;
+    dp_u64* stamps;                   // optional debug timeline (timeline build only): workgroup 100, [step][128]
 };
+#define DM_STAMP(i_) do { if (DP_STAMPS(a) != nullptr && cu == 100 && lane == 0) DP_STAMPS(a)[s * 128 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 __device__ __forceinline__ bool dm_valid(const u32x4_t& v) { return v.x != 0xffffffffu && v.y != 0xffffffffu && v.z != 0xffffffffu && v.w != 0xffffffffu; }
 // saddr + 32-bit voffset forms: the buffer base is wave-uniform (an SGPR pair), a lane carries ONE 32-bit offset per access
@@ -122,7 +123,10 @@ __device__ __forceinline__ void dm_sst8(char* sbase, uint32_t voff, uint32_t a, 
 __device__ __forceinline__ void dm_sst16(char* sbase, uint32_t voff, const u32x4_t& v) { asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory"); }
 template <int J, int NL, int STRIDE> struct DmIssue {
     static __device__ __forceinline__ void go(u32x4_t (&x)[NL], const char* sbase, uint32_t voff, uint32_t done) {
-        if (!((done >> J) & 1u)) dm_lds16<J * STRIDE>(x[J], sbase, voff);
+        if (!((done >> J) & 1u)) {
+            if constexpr (J * STRIDE < 4096) dm_lds16<J * STRIDE>(x[J], sbase, voff);
+            else dm_lds16<0>(x[J], sbase + (long)J * STRIDE, voff);
+        }
         if constexpr (J + 1 < NL) DmIssue<J + 1, NL, STRIDE>::go(x, sbase, voff, done);
     }
 };
@@ -205,35 +209,62 @@ __device__ __forceinline__ void dm_arrive(dp_lu32* ctr, int lane) {
     if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// All-gather of a [rows][NP * 8] bf16 matrix into the activation buffer (B-operand order), by the four gather waves:
-// wave gw takes rows gw*RW .. + RW (RW = 4 MT), lane = (row, piece group).  NORM: RMSNorm with the scale row `norm` of
-// the LDS copy (fp32 normalise -> bf16 -> * bf16 scale, torchtune's rounding points).
-template <int MT, int NP, bool NORM>
-__device__ __forceinline__ bool dm_sweep_mat(const char* buf, int row_bytes, int M, int norm, float eps, char* lds, int gw, int lane, dp_lvu32* ab,
-                                             uint32_t* err, uint32_t code, int poll_sleep) {
+// All-gather of an M x (NP * 8) bf16 matrix into the activation buffer (B-operand order), by the four gather waves: wave gw takes
+// rows gw*RW .. + RW (RW = 4 MT), lane = (row, piece group pg), load j = piece j * PG + pg of the row.  The caller gives the lane's
+// byte offset of piece pg of its row and the byte stride between a lane's pieces (buffer layouts differ per edge).
+template <int MT, int NP, int STRIDE>
+__device__ __forceinline__ bool dm_sweep_mat(const char* buf, uint32_t voff, char* lds, int gw, int lane, dp_lvu32* ab, uint32_t* err, uint32_t code, int poll_sleep) {
     constexpr int RW = 4 * MT, PG = 64 / RW, NL = NP / PG;
     const int rl = lane & (RW - 1), pg = lane / RW;
-    const int row = gw * RW + rl, rowc = min(row, M - 1);
+    const int row = gw * RW + rl;
     u32x4_t x[NL];
-    if (!dm_poll_s<NL, PG * 16>(buf, (uint32_t)(rowc * row_bytes + pg * 16), x, lane, ab, err, code, poll_sleep)) return false;
-    if (NORM) {
-        float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < NL; ++j) ss += dp_chunk_ss(make_uint4(x[j].x, x[j].y, x[j].z, x[j].w));
-#pragma unroll
-        for (int o = RW; o < 64; o <<= 1) ss += __shfl_xor(ss, o, 64);
-        const float r = 1.0f / sqrtf(ss / (float)(NP * 8) + eps);
-        const dp_lu4* g = (const dp_lu4*)(lds + DM_L_NORM + norm * 2048);
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            asm volatile("" : "+v"(x[j]));        // unpack again here: kept from the sum-of-squares pass, the 8 NL fp32 values of a lane spill
-            const uint4 o = dp_chunk_norm(make_uint4(x[j].x, x[j].y, x[j].z, x[j].w), dp_ldq(g + j * PG + pg), r);
-            x[j].x = o.x; x[j].y = o.y; x[j].z = o.z; x[j].w = o.w;
-        }
-    }
+    if (!dm_poll_s<NL, STRIDE>(buf, voff, x, lane, ab, err, code, poll_sleep)) return false;
     dp_lu4* xb = (dp_lu4*)(lds + DM_L_XB + (row >> 4) * (NP * 256));
 #pragma unroll
     for (int j = 0; j < NL; ++j) xb[(j * PG + pg) * 16 + (row & 15)] = x[j];
+    return true;
+}
+
+// All-gather of the residual stream, published as [256 workgroups][32 rows][4 columns] (a producer's 256 bytes are two whole
+// cache lines: with a row-major matrix 16 workgroups write 8 bytes each into every line, and the edge took 10-15 us instead
+// of 4), + RMSNorm with scale row `norm` of the LDS copy (fp32 normalise -> bf16 -> * bf16 scale, torchtune's rounding points).
+// Wave gw takes row pairs gw*RP .. + RP (RP = 2 MT); lane = (row pair, workgroup group cg); load j = workgroup j * CG + cg: 16 bytes =
+// its 4 columns of rows 2 rp and 2 rp + 1.
+template <int MT>
+__device__ __forceinline__ bool dm_sweep_cols(const char* buf, int M, int norm, float eps, char* lds, int gw, int lane, dp_lvu32* ab, uint32_t* err,
+                                              uint32_t code, int poll_sleep) {
+    constexpr int RP = 2 * MT, CG = 64 / RP, NL = 256 / CG;
+    const int rpl = lane & (RP - 1), cg = lane / RP;
+    const int rp = gw * RP + rpl, rpc = min(rp, (M - 1) >> 1);
+    u32x4_t x[NL];
+    if (!dm_poll_s<NL, CG * 256>(buf, (uint32_t)(cg * 256 + rpc * 16), x, lane, ab, err, code, poll_sleep)) return false;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        float f;
+        f = lo2f(x[j].x); s0 += f * f; f = hi2f(x[j].x); s0 += f * f; f = lo2f(x[j].y); s0 += f * f; f = hi2f(x[j].y); s0 += f * f;
+        f = lo2f(x[j].z); s1 += f * f; f = hi2f(x[j].z); s1 += f * f; f = lo2f(x[j].w); s1 += f * f; f = hi2f(x[j].w); s1 += f * f;
+    }
+#pragma unroll
+    for (int o = RP; o < 64; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    const float r0 = 1.0f / sqrtf(s0 / 1024.0f + eps), r1 = 1.0f / sqrtf(s1 / 1024.0f + eps);
+    const dp_lu32* g = (const dp_lu32*)(lds + DM_L_NORM + norm * 2048);
+    typedef __attribute__((address_space(3))) unsigned long long dm_lu64;
+    const int ra = 2 * rp, rb = 2 * rp + 1;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        asm volatile("" : "+v"(x[j]));            // unpack again here (see the register note in dm_sweep_mat's history: fp32 copies kept across passes spill)
+        const int c = j * CG + cg;
+        const uint32_t g0 = g[2 * c], g1 = g[2 * c + 1];
+        const uint32_t a0 = pack_bf(round_bf(lo2f(x[j].x) * r0) * lo2f(g0), round_bf(hi2f(x[j].x) * r0) * hi2f(g0));
+        const uint32_t a1 = pack_bf(round_bf(lo2f(x[j].y) * r0) * lo2f(g1), round_bf(hi2f(x[j].y) * r0) * hi2f(g1));
+        const uint32_t b0 = pack_bf(round_bf(lo2f(x[j].z) * r1) * lo2f(g0), round_bf(hi2f(x[j].z) * r1) * hi2f(g0));
+        const uint32_t b1 = pack_bf(round_bf(lo2f(x[j].w) * r1) * lo2f(g1), round_bf(hi2f(x[j].w) * r1) * hi2f(g1));
+        // columns 4c..4c+3 = half (c & 1) of piece c >> 1
+        *(dm_lu64*)(lds + DM_L_XB + (ra >> 4) * 32768 + (((c >> 1) * 16 + (ra & 15)) * 16 + (c & 1) * 8)) = ((unsigned long long)a1 << 32) | a0;
+        *(dm_lu64*)(lds + DM_L_XB + (rb >> 4) * 32768 + (((c >> 1) * 16 + (rb & 15)) * 16 + (c & 1) * 8)) = ((unsigned long long)b1 << 32) | b0;
+        if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // (bounds the temporaries the scheduler keeps live across pieces)
+    }
     return true;
 }
 
@@ -242,23 +273,36 @@ typedef __attribute__((ext_vector_type(4))) float dm_f32x4;
 // one K range of a 16-row weight tile against MT row tiles of the activation buffer
 template <int MT, int NP, int NT>
 __device__ __forceinline__ void dm_mma(const uint4 (&wf)[NT], const char* lds, int t0, int lane, dm_f32x4 (&acc)[MT]) {
-    // B fragments four k steps at a time (a bounded number of registers: left alone, the scheduler hoists every read of the
-    // phase in front of the first matrix op and spills)
+    // B fragments G k steps at a time, the next group's reads in flight behind the current group's matrix ops (a bounded number of
+    // registers: left alone, the scheduler hoists every read of the phase in front of the first matrix op and spills)
+    constexpr int G = 4 / MT;
     const dp_lu4* xb = (const dp_lu4*)(lds + DM_L_XB) + (t0 * 4 + (lane >> 4)) * 16 + (lane & 15);
+    uint4 xa[G][MT], xn[G][MT];
 #pragma unroll
-    for (int kb = 0; kb < NT; kb += 4) {
-        uint4 xv[4][MT];
+    for (int k = 0; k < G; ++k)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int m = 0; m < MT; ++m) xa[k][m] = dp_ldq(xb + m * (NP * 16) + k * 64);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) xv[k][m] = dp_ldq(xb + m * (NP * 16) + (kb + k) * 64);
+    for (int kb = 0; kb < NT; kb += G) {
+        if (kb + G < NT) {
+#pragma unroll
+            for (int k = 0; k < G; ++k)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xn[k][m] = dp_ldq(xb + m * (NP * 16) + (kb + G + k) * 64);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < G; ++k)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dp_bf16x8, wf[kb + k]), __builtin_bit_cast(dp_bf16x8, xv[k][m]), acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dp_bf16x8, wf[kb + k]), __builtin_bit_cast(dp_bf16x8, xa[k][m]), acc[m], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (kb + G < NT) {
+#pragma unroll
+            for (int k = 0; k < G; ++k)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xa[k][m] = xn[k][m];
+        }
     }
 }
 
@@ -356,6 +400,7 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
     };
     uint32_t kp = 0;
     const int n_steps = a.cb_last - a.cb_first + 1;
+    const int mpad = (a.M + 1) & ~1;          // the residual stream travels in row pairs: an odd M publishes one (finite, unused) row more
     for (int s = 0; s < n_steps; ++s) {
         const int cb = a.cb_first + s;
         for (int l = 0; l < DP_NL; ++l) {
@@ -368,6 +413,7 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
             {   // ---- q|k|v of my 6 columns (layers 1..3; layer 0's come from the table) ----
                 if (l > 0) ++kp;
                 if (!dp_wait<8, true>(fill, l > 0 ? 4u * kp : 0u, ab, a.err, 0xA10u, lane, ts, [&](int k) { load_s(l, cb, k); })) return;
+                if (w == 0) DM_STAMP(64 + l * 8 + 0);
                 if (l > 0) {
                     dm_f32x4 acc[MT];
 #pragma unroll
@@ -396,9 +442,11 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                     }
                 }
             }
+            if (w == 0) DM_STAMP(64 + l * 8 + 1);
             {   // ---- o-projection of my 4 columns + residual ----
                 ++kp;
                 if (!dp_wait<24, true>(fill, 4u * kp, ab, a.err, 0xA20u, lane, ts, [&](int k) { if (k < 8) load_s(4 + l, cb, k); else load_gu(l, k - 8); })) return;
+                if (w == 0) DM_STAMP(64 + l * 8 + 2);
                 dm_f32x4 acc[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[m] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -410,20 +458,22 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const int b = 16 * m + bl;
-                        if (g4 == 0 && b < a.M) {
+                        if (g4 == 0 && b < mpad) {
                             const dp_lu32* hr = (const dp_lu32*)(lds + DM_L_HRES) + 2 * b;
                             const uint32_t p0 = dp_resid_pair(v[m][0], v[m][1], hr[0]), p1 = dp_resid_pair(v[m][2], v[m][3], hr[1]);
                             dp_lu32* h1 = (dp_lu32*)(lds + DM_L_HRES1) + 2 * b;
                             h1[0] = p0; h1[1] = p1;
-                            dm_sst8(xh, (uint32_t)(b * 2048 + 8 * cu), p0, p1);
-                            dm_sst8(xh2, (uint32_t)(b * 2048 + 8 * cu), 0xffffffffu, 0xffffffffu);
+                            dm_sst8(xh, (uint32_t)(cu * 256 + b * 8), p0, p1);
+                            dm_sst8(xh2, (uint32_t)(cu * 256 + b * 8), 0xffffffffu, 0xffffffffu);
                         }
                     }
                 }
             }
+            if (w == 0) DM_STAMP(64 + l * 8 + 3);
             {   // ---- gate / up of my 32 pairs: tile w = pairs 8w..8w+7 as rows (g, u, g, u, ...) ----
                 ++kp;
                 if (!dp_wait<24, true>(fill, 4u * kp, ab, a.err, 0xA30u, lane, ts, [&](int k) { if (k < 16) load_gu(l, 16 + k); else load_dn(l, k - 16); })) return;
+                if (w == 0) DM_STAMP(64 + l * 8 + 4);
                 dm_f32x4 acc[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[m] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -434,15 +484,17 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                     const int b = 16 * m + bl;
                     if (b < a.M) {
                         const uint32_t hv = dp_swiglu(acc[m][0], acc[m][1]) | (dp_swiglu(acc[m][2], acc[m][3]) << 16);
-                        const uint32_t off = (uint32_t)(((gg * 32 + b) * 512 + 32 * gj + 8 * w + 2 * g4) * 2);
+                        const uint32_t off = (uint32_t)(gg * 32768 + gj * 2048 + b * 64 + (8 * w + 2 * g4) * 2);
                         dm_sst4(xg, off, hv);
                         dm_sst4(xg2, off, 0xffffffffu);
                     }
                 }
             }
+            if (w == 0) DM_STAMP(64 + l * 8 + 5);
             {   // ---- down projection: my 64 output columns over my group's 512 ffn columns; tile w = columns 16w..16w+15 ----
                 ++kp;
                 if (!dp_wait<8, true>(fill, 4u * kp, ab, a.err, 0xA40u, lane, ts, [&](int k) { load_dn(l, 8 + k); })) return;
+                if (w == 0) DM_STAMP(64 + l * 8 + 6);
                 dm_f32x4 acc[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[m] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -466,10 +518,12 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                     }
                 }
             }
+            if (w == 0) DM_STAMP(64 + l * 8 + 7);
         }
         {   // ---- head of codebook cb: my 8 logit rows (+ the tail rows on workgroup 0) ----
             ++kp;
             if (!dp_wait<8, true>(fill, 4u * kp, ab, a.err, 0xA50u, lane, ts, [&](int k) { load_s(8, cb, k); })) return;
+            if (w == 0) DM_STAMP(96);
             dm_f32x4 acc[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -482,12 +536,13 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                 for (int m = 0; m < MT; ++m) {
                     const int b = 16 * m + bl;
                     if (b < a.M && (g4 < 2 || cu == 0)) {
-                        const int col = g4 < 2 ? 8 * cu + 4 * g4 : 2048 + 4 * (g4 - 2);
-                        dm_sst8(xl, (uint32_t)((b * DM_LROW + col) * 2), pack_bf(v[m][0], v[m][1]), pack_bf(v[m][2], v[m][3]));
-                        dm_sst8(xl2, (uint32_t)((b * DM_LROW + col) * 2), 0xffffffffu, 0xffffffffu);
+                        const uint32_t off = (uint32_t)((g4 < 2 ? cu : 256) * 512 + b * 16 + (g4 & 1) * 8);
+                        dm_sst8(xl, off, pack_bf(v[m][0], v[m][1]), pack_bf(v[m][2], v[m][3]));
+                        dm_sst8(xl2, off, 0xffffffffu, 0xffffffffu);
                     }
                 }
             }
+            if (w == 0) DM_STAMP(97);
         }
     }
 }
@@ -506,6 +561,15 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
     const int ps = a.poll_sleep;
     uint32_t kf = 0, quad_phase = 0;
     const int n_steps = a.cb_last - a.cb_first + 1;
+    const int mpad = (a.M + 1) & ~1;
+    // my lane's piece offsets in the row-major attention matrix and in my group's h blocks [16 j][32 rows][32 columns]
+    uint32_t voff_a, voff_g;
+    {
+        constexpr int RW = 4 * MT;
+        const int rowc = min(gw * RW + (lane & (RW - 1)), a.M - 1), pg = lane / RW;
+        voff_a = (uint32_t)(rowc * 2048 + pg * 16);
+        voff_g = (uint32_t)((pg >> 2) * 2048 + rowc * 64 + (pg & 3) * 16);
+    }
     // fill k of the activation buffer may start once phase k - 1 has read it
 #define DM_FILL_BEGIN(code_) do { ++kf; if (!dm_wait_ge(cdone, 4u * (kf - 1), ab, a.err, (code_), lane)) return; } while (0)
 #define DM_FILL_END() dm_arrive(misc + DM_M_FILL, lane)
@@ -515,8 +579,9 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
             const int n = s * DP_NL + l;
             if (l > 0) {
                 DM_FILL_BEGIN(0xB10u);
-                if (!dm_sweep_mat<MT, 128, true>(a.xchg + DM_OFF_X + ((n - 1) % DM_R) * DM_X_BYTES, 2048, a.M, 2 * l, a.eps, lds, gw, lane, ab, a.err, 0x110u + l, ps)) return;
+                if (!dm_sweep_cols<MT>(a.xchg + DM_OFF_X + ((n - 1) % DM_R) * DM_X_BYTES, a.M, 2 * l, a.eps, lds, gw, lane, ab, a.err, 0x110u + l, ps)) return;
                 DM_FILL_END();
+                if (gw == 0) DM_STAMP(l * 8 + 0);
                 if (owner && gw == 0) {
                     // q of my head, k / v of my kv head, this step's position
                     const int nq = s * (DP_NL - 1) + l - 1;
@@ -529,6 +594,7 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
                     else if (lane < 32) ((dp_lu4*)(lds + DM_L_K + (l * 32 + cb) * 256))[lane - 16] = x[0];
                     else if (lane < 48) ((dp_lu4*)(lds + DM_L_V + (l * 32 + cb) * 256))[lane - 32] = x[0];
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    DM_STAMP(l * 8 + 1);
                 }
             }
             if (owner && gw == 0) {
@@ -536,16 +602,20 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
                 const long off = (long)ob * 2048 + oh * 256 + lane * 4;
                 dm_st4(a.xchg + DM_OFF_A + (n % DM_R) * DM_X_BYTES + off, o);
                 dm_st4(a.xchg + DM_OFF_A + ((n + 2) % DM_R) * DM_X_BYTES + off, 0xffffffffu);
+                DM_STAMP(l * 8 + 2);
             }
             DM_FILL_BEGIN(0xB20u);
-            if (!dm_sweep_mat<MT, 128, false>(a.xchg + DM_OFF_A + (n % DM_R) * DM_X_BYTES, 2048, a.M, 0, a.eps, lds, gw, lane, ab, a.err, 0x310u + l, ps)) return;
+            if (!dm_sweep_mat<MT, 128, (64 / (4 * MT)) * 16>(a.xchg + DM_OFF_A + (n % DM_R) * DM_X_BYTES, voff_a, lds, gw, lane, ab, a.err, 0x310u + l, ps)) return;
             DM_FILL_END();
+            if (gw == 0) DM_STAMP(l * 8 + 3);
             DM_FILL_BEGIN(0xB30u);
-            if (!dm_sweep_mat<MT, 128, true>(a.xchg + DM_OFF_H1 + (n % DM_R) * DM_X_BYTES, 2048, a.M, 2 * l + 1, a.eps, lds, gw, lane, ab, a.err, 0x410u + l, ps)) return;
+            if (!dm_sweep_cols<MT>(a.xchg + DM_OFF_H1 + (n % DM_R) * DM_X_BYTES, a.M, 2 * l + 1, a.eps, lds, gw, lane, ab, a.err, 0x410u + l, ps)) return;
             DM_FILL_END();
+            if (gw == 0) DM_STAMP(l * 8 + 4);
             DM_FILL_BEGIN(0xB40u);
-            if (!dm_sweep_mat<MT, 64, false>(a.xchg + DM_OFF_HG + (n % DM_R) * DM_HG_BYTES + (long)gg * 32768, 1024, a.M, 0, a.eps, lds, gw, lane, ab, a.err, 0x510u + l, ps)) return;
+            if (!dm_sweep_mat<MT, 64, ((64 / (4 * MT)) / 4) * 2048>(a.xchg + DM_OFF_HG + (n % DM_R) * DM_HG_BYTES + (long)gg * 32768, voff_g, lds, gw, lane, ab, a.err, 0x510u + l, ps)) return;
             DM_FILL_END();
+            if (gw == 0) DM_STAMP(l * 8 + 5);
             if (gw == 1) {
                 // the 16 partial sums of my 4 columns, every row: lane = (row b = lane & 31, half of the groups); fixed order
                 const int b = lane & 31, bc = min(b, a.M - 1), half = lane >> 5;
@@ -563,30 +633,33 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
                     const float o = __shfl_xor(t[i], 32, 64);
                     t[i] = half == 0 ? t[i] + o : o + t[i];
                 }
-                if (lane < 32 && b < a.M) {
+                if (lane < 32 && b < mpad) {
                     const dp_lu32* h1 = (const dp_lu32*)(lds + DM_L_HRES1) + 2 * b;
                     const uint32_t p0 = dp_resid_pair(t[0], t[1], h1[0]), p1 = dp_resid_pair(t[2], t[3], h1[1]);
                     dp_lu32* hr = (dp_lu32*)(lds + DM_L_HRES) + 2 * b;
                     hr[0] = p0; hr[1] = p1;
-                    dm_st8(a.xchg + DM_OFF_X + (n % DM_R) * DM_X_BYTES + (long)b * 2048 + 8 * cu, p0, p1);
-                    dm_st8(a.xchg + DM_OFF_X + ((n + 2) % DM_R) * DM_X_BYTES + (long)b * 2048 + 8 * cu, 0xffffffffu, 0xffffffffu);
+                    dm_st8(a.xchg + DM_OFF_X + (n % DM_R) * DM_X_BYTES + cu * 256 + b * 8, p0, p1);
+                    dm_st8(a.xchg + DM_OFF_X + ((n + 2) % DM_R) * DM_X_BYTES + cu * 256 + b * 8, 0xffffffffu, 0xffffffffu);
                 }
+                DM_STAMP(l * 8 + 6);
             }
         }
         {   // the stack's output rows -> final norm -> x of the head
             const int n = s * DP_NL + DP_NL - 1;
             DM_FILL_BEGIN(0xB50u);
-            if (!dm_sweep_mat<MT, 128, true>(a.xchg + DM_OFF_X + (n % DM_R) * DM_X_BYTES, 2048, a.M, 8, a.eps, lds, gw, lane, ab, a.err, 0x710u, ps)) return;
+            if (!dm_sweep_cols<MT>(a.xchg + DM_OFF_X + (n % DM_R) * DM_X_BYTES, a.M, 8, a.eps, lds, gw, lane, ab, a.err, 0x710u, ps)) return;
             DM_FILL_END();
+            if (gw == 0) DM_STAMP(32);
         }
         int fed = 0;
         if (owner) {
             // logits of my row -> registers (thread tid of the quad owns logits 8 tid .. + 7, tid 0 also the tail piece), sample
             const int tid = gw * 64 + lane;
-            const char* lrow = a.xchg + DM_OFF_L + (s % DM_R) * DM_L_BYTES + (long)ob * (DM_LROW * 2);
-            const char* p[2] = {lrow + tid * 16, lrow + (tid == 0 ? 256 : tid) * 16};
+            const char* lrow = a.xchg + DM_OFF_L + (s % DM_R) * DM_L_BYTES + ob * 16;
+            const char* p[2] = {lrow + tid * 512, lrow + (tid == 0 ? 256 : tid) * 512};
             u32x4_t x[2];
             if (!dm_poll<2>(p, x, lane, ab, a.err, 0x810u, ps)) return;
+            if (gw == 0) DM_STAMP(33);
             uint32_t wv[2][4] = {{x[0].x, x[0].y, x[0].z, x[0].w}, {0u, 0u, 0u, 0u}};
             if (tid == 0) { wv[1][0] = x[1].x; wv[1][1] = x[1].y; wv[1][2] = x[1].z; wv[1][3] = x[1].w; }
             if (a.logits_out != nullptr && oh == 0) {
@@ -616,6 +689,7 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
             const int tok = sample_body<2>(wv, sV, sT, sK, sN ? a.noise + ((long)cb * a.M + ob) * sV : nullptr, seed, step, ob, cb, sc, tid, sync);
 #endif
             if (*ab) return;
+            if (gw == 0) DM_STAMP(34);
             fed = a.forced ? a.forced[(long)ob * a.ncb + cb] : tok;
             fed = min(max(fed, 0), a.V - 1);
             if (gw == 0) {
@@ -634,6 +708,7 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
                     else if (lane < 32) dp_stq((dp_lu4*)(lds + DM_L_K + (cb + 1) * 256) + lane - 16, v);
                     else if (lane < 48) dp_stq((dp_lu4*)(lds + DM_L_V + (cb + 1) * 256) + lane - 32, v);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    DM_STAMP(35);
                 }
             }
         }
@@ -648,6 +723,7 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
             if (lane < a.M) { dp_lu32* hr = (dp_lu32*)(lds + DM_L_HRES) + 2 * lane; hr[0] = hv.x; hr[1] = hv.y; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) misc[DM_M_FT] = (uint32_t)(s + 2);
+            DM_STAMP(36);
         }
     }
 #undef DM_FILL_BEGIN
@@ -661,7 +737,7 @@ __global__ __launch_bounds__(512) void k_dec_persist_m(const DecPersistMArgs a) 
     const int lane = threadIdx.x & 63;
     dp_lu32* misc = (dp_lu32*)(lds + DM_L_MISC);
     const int ob = cu >> 3, oh = cu & 7, kvh = oh >> 2;
-    for (int i = threadIdx.x; i < 256; i += 512) misc[i] = 0;
+    for (int i = threadIdx.x; i < 256 + 128; i += 512) misc[i] = 0;      // misc words, HRES, HRES1 (rows >= M must be finite)
     for (int i = threadIdx.x; i < 65536 / 16; i += 512) dp_stq((dp_lu4*)lds + i, make_uint4(0, 0, 0, 0));     // K / V: dead slots must be finite
     __syncthreads();
     {
