@@ -24,6 +24,12 @@
 // Waves 0..3 compute (weights trickled into VGPRs while they wait on LDS counters, dec_persist.cuh's dp_wait), waves
 // 4..7 gather (no weight loads in flight, so their polls never queue behind the stream), run the attention, the
 // owner-side sums and the sampler.  Every spin is bounded (s_memrealtime) and ends in *err.
+//
+// More than 16 rows run as TWO independent halves (rows 0..15, 16..31) whose phases interleave in every wave's program
+// order: A's phase k, B's phase k, A's phase k + 1, ...  A step is a chain of ~26 cross-workgroup exchanges of 3-4 us each
+// with ~1.5 us of work between them; handled as one 32-row problem the work doubles and the waits stay (measured: 181 us per
+// step against 88 us at 16 rows), interleaved, one half's exchange is in flight while the other half's rows are normalised,
+// multiplied and published.  The halves share the weights in registers and nothing else (own counters, own buffer rows).
 #pragma once
 #include "dec_persist.cuh"
 
@@ -49,8 +55,8 @@
 // LDS image (bytes)
 #define DM_L_K 0                                  // [4 layers][32 pos][128] bf16 of this workgroup's (row, kv head)
 #define DM_L_V 32768
-#define DM_L_XB 65536                             // activations in B-operand order: piece (tile, p, row) at tile * NP*256 + (p*16 + row) * 16
-#define DM_L_RED 131072                           // small-op partial sums [4 waves][2 tiles][4][64] f32
+#define DM_L_XB 65536                             // activations in B-operand order, 32 KB per half: piece (p, row) at (p*16 + row) * 16
+#define DM_L_RED 131072                           // small-op partial sums [2 halves][4 waves][4][64] f32
 #define DM_L_MISC 139264
 #define DM_L_HRES (DM_L_MISC + 1024)              // [32][4] bf16: my residual columns entering the layer
 #define DM_L_HRES1 (DM_L_HRES + 256)              // ... after the o-projection
@@ -60,16 +66,16 @@
 #define DM_L_SMAX (DM_L_ROPE + 384)               // sampler: 256 u32
 #define DM_L_NORM (DM_L_SMAX + 1024)              // [9][1024] bf16: sa/mlp norms of the 4 layers, final norm
 #define DM_LDS_BYTES (DM_L_NORM + 9 * 2048)
-#define DM_L_CANDT DM_L_XB                        // sampler scratch aliases the activation buffer (8448 B each)
-#define DM_L_CANDI (DM_L_XB + DP_CAND_SLOTS * 4)
+#define DM_L_CANDT 0                              // sampler scratch: offsets into the owner's half of the activation buffer
+#define DM_L_CANDI (DP_CAND_SLOTS * 4)
 static_assert(DM_LDS_BYTES <= 163840, "LDS image exceeds 160 KB");
 // misc words
-#define DM_M_FILL 0      // gather waves: +1 each per fill of the activation buffer
-#define DM_M_CDONE 1     // compute waves: +1 each once a phase has read the activation buffer
-#define DM_M_RED 2       // small-op arrivals
-#define DM_M_FT 3        // residual rows of step s are in HRES when >= s + 1
-#define DM_M_ABORT 4
-#define DM_M_BAR 5       // sampler quad barrier
+#define DM_M_FILL 0      // [2 halves] gather waves: +1 each per fill of the half's activation buffer
+#define DM_M_CDONE 2     // [2] compute waves: +1 each once a phase has read it
+#define DM_M_RED 4       // [2] small-op arrivals
+#define DM_M_FT 6        // [2] residual rows of step s are in HRES when >= s + 1
+#define DM_M_ABORT 22
+#define DM_M_BAR 23      // sampler quad barrier
 #define DM_M_SBV 8
 #define DM_M_SBI 12
 #define DM_M_SN 16
@@ -209,99 +215,87 @@ __device__ __forceinline__ void dm_arrive(dp_lu32* ctr, int lane) {
     if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// All-gather of an M x (NP * 8) bf16 matrix into the activation buffer (B-operand order), by the four gather waves: wave gw takes
-// rows gw*RW .. + RW (RW = 4 MT), lane = (row, piece group pg), load j = piece j * PG + pg of the row.  The caller gives the lane's
-// byte offset of piece pg of its row and the byte stride between a lane's pieces (buffer layouts differ per edge).
-template <int MT, int NP, int STRIDE>
-__device__ __forceinline__ bool dm_sweep_mat(const char* buf, uint32_t voff, char* lds, int gw, int lane, dp_lvu32* ab, uint32_t* err, uint32_t code, int poll_sleep) {
-    constexpr int RW = 4 * MT, PG = 64 / RW, NL = NP / PG;
-    const int rl = lane & (RW - 1), pg = lane / RW;
-    const int row = gw * RW + rl;
+// All-gather of 16 rows x (NP * 8) columns of one half into its activation buffer (B-operand order), by the four gather waves: wave gw
+// takes rows 4 gw .. + 3 of the half, lane = (row, piece group pg of 16), load j = piece 16 j + pg of the row.  The caller gives the
+// lane's byte offset of piece pg of its row and the byte stride between a lane's pieces (buffer layouts differ per edge).
+template <int NP, int STRIDE>
+__device__ __forceinline__ bool dm_sweep_mat(const char* buf, uint32_t voff, char* xb_half, int gw, int lane, dp_lvu32* ab, uint32_t* err, uint32_t code, int poll_sleep) {
+    constexpr int NL = NP / 16;
+    const int row = gw * 4 + (lane & 3), pg = lane >> 2;
     u32x4_t x[NL];
     if (!dm_poll_s<NL, STRIDE>(buf, voff, x, lane, ab, err, code, poll_sleep)) return false;
-    dp_lu4* xb = (dp_lu4*)(lds + DM_L_XB + (row >> 4) * (NP * 256));
+    dp_lu4* xb = (dp_lu4*)xb_half;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) xb[(j * PG + pg) * 16 + (row & 15)] = x[j];
+    for (int j = 0; j < NL; ++j) xb[(j * 16 + pg) * 16 + row] = x[j];
     return true;
 }
 
-// All-gather of the residual stream, published as [256 workgroups][32 rows][4 columns] (a producer's 256 bytes are two whole
-// cache lines: with a row-major matrix 16 workgroups write 8 bytes each into every line, and the edge took 10-15 us instead
-// of 4), + RMSNorm with scale row `norm` of the LDS copy (fp32 normalise -> bf16 -> * bf16 scale, torchtune's rounding points).
-// Wave gw takes row pairs gw*RP .. + RP (RP = 2 MT); lane = (row pair, workgroup group cg); load j = workgroup j * CG + cg: 16 bytes =
-// its 4 columns of rows 2 rp and 2 rp + 1.
-template <int MT>
-__device__ __forceinline__ bool dm_sweep_cols(const char* buf, int M, int norm, float eps, char* lds, int gw, int lane, dp_lvu32* ab, uint32_t* err,
+// All-gather of a half's rows of the residual stream, published as [256 workgroups][32 rows][4 columns] (a producer's 256 bytes are two
+// whole cache lines: with a row-major matrix 16 workgroups write 8 bytes each into every line, and the edge took 10-15 us instead of
+// 4), + RMSNorm with scale row `norm` of the LDS copy (fp32 normalise -> bf16 -> * bf16 scale, torchtune's rounding points).  Wave gw
+// takes row pairs 2 gw, 2 gw + 1 of the half; lane = (row pair, workgroup group cg of 32); load j = workgroup 32 j + cg: 16 bytes = its
+// 4 columns of the pair's two rows.
+__device__ __forceinline__ bool dm_sweep_cols(const char* buf, int hf, int M, int norm, float eps, char* lds, int gw, int lane, dp_lvu32* ab, uint32_t* err,
                                               uint32_t code, int poll_sleep) {
-    constexpr int RP = 2 * MT, CG = 64 / RP, NL = 256 / CG;
-    const int rpl = lane & (RP - 1), cg = lane / RP;
-    const int rp = gw * RP + rpl, rpc = min(rp, (M - 1) >> 1);
-    u32x4_t x[NL];
-    if (!dm_poll_s<NL, CG * 256>(buf, (uint32_t)(cg * 256 + rpc * 16), x, lane, ab, err, code, poll_sleep)) return false;
+    const int rpl = lane & 1, cg = lane >> 1;
+    const int rp = gw * 2 + rpl, rpc = min(8 * hf + rp, (M - 1) >> 1);
+    u32x4_t x[8];
+    if (!dm_poll_s<8, 32 * 256>(buf, (uint32_t)(cg * 256 + rpc * 16), x, lane, ab, err, code, poll_sleep)) return false;
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
+    for (int j = 0; j < 8; ++j) {
         float f;
         f = lo2f(x[j].x); s0 += f * f; f = hi2f(x[j].x); s0 += f * f; f = lo2f(x[j].y); s0 += f * f; f = hi2f(x[j].y); s0 += f * f;
         f = lo2f(x[j].z); s1 += f * f; f = hi2f(x[j].z); s1 += f * f; f = lo2f(x[j].w); s1 += f * f; f = hi2f(x[j].w); s1 += f * f;
     }
 #pragma unroll
-    for (int o = RP; o < 64; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    for (int o = 2; o < 64; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
     const float r0 = 1.0f / sqrtf(s0 / 1024.0f + eps), r1 = 1.0f / sqrtf(s1 / 1024.0f + eps);
     const dp_lu32* g = (const dp_lu32*)(lds + DM_L_NORM + norm * 2048);
     typedef __attribute__((address_space(3))) unsigned long long dm_lu64;
+    char* xb = lds + DM_L_XB + hf * 32768;
     const int ra = 2 * rp, rb = 2 * rp + 1;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-        asm volatile("" : "+v"(x[j]));            // unpack again here (see the register note in dm_sweep_mat's history: fp32 copies kept across passes spill)
-        const int c = j * CG + cg;
+    for (int j = 0; j < 8; ++j) {
+        asm volatile("" : "+v"(x[j]));            // unpack again here: fp32 copies kept from the sum-of-squares pass spill
+        const int c = j * 32 + cg;
         const uint32_t g0 = g[2 * c], g1 = g[2 * c + 1];
         const uint32_t a0 = pack_bf(round_bf(lo2f(x[j].x) * r0) * lo2f(g0), round_bf(hi2f(x[j].x) * r0) * hi2f(g0));
         const uint32_t a1 = pack_bf(round_bf(lo2f(x[j].y) * r0) * lo2f(g1), round_bf(hi2f(x[j].y) * r0) * hi2f(g1));
         const uint32_t b0 = pack_bf(round_bf(lo2f(x[j].z) * r1) * lo2f(g0), round_bf(hi2f(x[j].z) * r1) * hi2f(g0));
         const uint32_t b1 = pack_bf(round_bf(lo2f(x[j].w) * r1) * lo2f(g1), round_bf(hi2f(x[j].w) * r1) * hi2f(g1));
         // columns 4c..4c+3 = half (c & 1) of piece c >> 1
-        *(dm_lu64*)(lds + DM_L_XB + (ra >> 4) * 32768 + (((c >> 1) * 16 + (ra & 15)) * 16 + (c & 1) * 8)) = ((unsigned long long)a1 << 32) | a0;
-        *(dm_lu64*)(lds + DM_L_XB + (rb >> 4) * 32768 + (((c >> 1) * 16 + (rb & 15)) * 16 + (c & 1) * 8)) = ((unsigned long long)b1 << 32) | b0;
-        if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // (bounds the temporaries the scheduler keeps live across pieces)
+        *(dm_lu64*)(xb + (((c >> 1) * 16 + ra) * 16 + (c & 1) * 8)) = ((unsigned long long)a1 << 32) | a0;
+        *(dm_lu64*)(xb + (((c >> 1) * 16 + rb) * 16 + (c & 1) * 8)) = ((unsigned long long)b1 << 32) | b0;
     }
     return true;
 }
 
 typedef __attribute__((ext_vector_type(4))) float dm_f32x4;
 
-// one K range of a 16-row weight tile against MT row tiles of the activation buffer
-template <int MT, int NP, int NT>
-__device__ __forceinline__ void dm_mma(const uint4 (&wf)[NT], const char* lds, int t0, int lane, dm_f32x4 (&acc)[MT]) {
-    // B fragments G k steps at a time, the next group's reads in flight behind the current group's matrix ops (a bounded number of
-    // registers: left alone, the scheduler hoists every read of the phase in front of the first matrix op and spills)
-    constexpr int G = 4 / MT;
-    const dp_lu4* xb = (const dp_lu4*)(lds + DM_L_XB) + (t0 * 4 + (lane >> 4)) * 16 + (lane & 15);
-    uint4 xa[G][MT], xn[G][MT];
+// NT k steps of a 16-row weight tile (A operand) against one half's 16 rows in its activation buffer (B operand)
+template <int NT>
+__device__ __forceinline__ void dm_mma(const uint4 (&wf)[NT], const char* xb_half, int t0, int lane, dm_f32x4& acc) {
+    // B fragments four k steps at a time, the next four reads in flight behind the current four matrix ops (left alone, the scheduler
+    // hoists every read of the phase in front of the first matrix op)
+    const dp_lu4* xb = (const dp_lu4*)xb_half + (t0 * 4 + (lane >> 4)) * 16 + (lane & 15);
+    uint4 xa[4], xn[4];
 #pragma unroll
-    for (int k = 0; k < G; ++k)
+    for (int k = 0; k < 4; ++k) xa[k] = dp_ldq(xb + k * 64);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) xa[k][m] = dp_ldq(xb + m * (NP * 16) + k * 64);
+    for (int kb = 0; kb < NT; kb += 4) {
+        if (kb + 4 < NT) {
 #pragma unroll
-    for (int kb = 0; kb < NT; kb += G) {
-        if (kb + G < NT) {
-#pragma unroll
-            for (int k = 0; k < G; ++k)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) xn[k][m] = dp_ldq(xb + m * (NP * 16) + (kb + G + k) * 64);
+            for (int k = 0; k < 4; ++k) xn[k] = dp_ldq(xb + (kb + 4 + k) * 64);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < G; ++k)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dp_bf16x8, wf[kb + k]), __builtin_bit_cast(dp_bf16x8, xa[k][m]), acc[m], 0, 0, 0);
+        for (int k = 0; k < 4; ++k)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dp_bf16x8, wf[kb + k]), __builtin_bit_cast(dp_bf16x8, xa[k]), acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (kb + G < NT) {
+        if (kb + 4 < NT) {
 #pragma unroll
-            for (int k = 0; k < G; ++k)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) xa[k][m] = xn[k][m];
+            for (int k = 0; k < 4; ++k) xa[k] = xn[k];
         }
     }
 }
@@ -351,9 +345,9 @@ __device__ __forceinline__ uint32_t dm_attention(char* lds, int l, int nk, int l
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// compute wave w (0..3)
+// compute wave w (0..3); NH = halves (1: up to 16 rows, 2: up to 32)
 // ---------------------------------------------------------------------------------------------------------------
-template <int MT>
+template <int NH>
 __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* lds, const int w, const int lane, const int cu) {
     dp_lu32* misc = (dp_lu32*)(lds + DM_L_MISC);
     dp_lvu32* ab = (dp_lvu32*)(misc + DM_M_ABORT);
@@ -361,6 +355,7 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
     const int ts = a.trickle_sleep & 63;
     const int g4 = lane >> 4, bl = lane & 15, r16 = lane & 15;
     const int gj = cu >> 4, gg = cu & 15;
+    const int mpad = (a.M + 1) & ~1;          // the residual stream travels in row pairs: an odd M publishes one (finite, unused) row more
     uint4 S[8], W[32], D[8];
     // A-operand fragments of the small ops: lane = (weight row r16 of the 16-row tile, k quarter g4); wave w takes k steps 8w..8w+7
     auto small_row = [&](int slot, int cb) -> const bf16_t* {      // slot 0..3: q|k|v of layer slot; 4..7: o-proj of layer slot-4; 8: head of cb
@@ -375,32 +370,29 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
         const uint4 v = a.w2m[(long)l * DM_W2M_U4 + (((long)cu * 4 + w) * 16 + k) * 64 + lane];
         if (k < 8) D[k & 7] = v; else W[(k - 8) & 31] = v;
     };
-    // last-arriver fold of the four waves' K-quarter partial tiles; returns true in the wave that arrived last with the sums in v
-    auto fold = [&](dm_f32x4 (&acc)[MT], float (&v)[MT][4]) -> bool {
-        dp_lf32* red = (dp_lf32*)(lds + DM_L_RED);
+    // last-arriver fold of the four waves' K-quarter partial tiles of one half; true in the wave that arrived last, with the sums in v
+    auto fold = [&](int hf, const dm_f32x4& acc, float (&v)[4]) -> bool {
+        dp_lf32* red = (dp_lf32*)(lds + DM_L_RED) + hf * 1024;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) red[((w * 2 + m) * 4 + i) * 64 + lane] = acc[m][i];
+        for (int i = 0; i < 4; ++i) red[(w * 4 + i) * 64 + lane] = acc[i];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         uint32_t old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(misc + DM_M_RED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) old = __hip_atomic_fetch_add(misc + DM_M_RED + hf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);
         if ((old & 3u) != 3u) return false;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int i = 0; i < 4; ++i) {
+            float s = red[i * 64 + lane];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float s = red[((0 * 2 + m) * 4 + i) * 64 + lane];
-#pragma unroll
-                for (int ww = 1; ww < 4; ++ww) s += red[((ww * 2 + m) * 4 + i) * 64 + lane];
-                v[m][i] = s;
-            }
+            for (int ww = 1; ww < 4; ++ww) s += red[(ww * 4 + i) * 64 + lane];
+            v[i] = s;
+        }
         return true;
     };
+    // the second half's wait: plain poll of its fill counter (the phase's weights are in registers already)
+    auto wait_half = [&](int hf, uint32_t want, uint32_t code) -> bool { return dm_wait_ge(fill + hf, want, ab, a.err, code, lane); };
     uint32_t kp = 0;
     const int n_steps = a.cb_last - a.cb_first + 1;
-    const int mpad = (a.M + 1) & ~1;          // the residual stream travels in row pairs: an odd M publishes one (finite, unused) row more
     for (int s = 0; s < n_steps; ++s) {
         const int cb = a.cb_first + s;
         for (int l = 0; l < DP_NL; ++l) {
@@ -415,25 +407,24 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                 if (!dp_wait<8, true>(fill, l > 0 ? 4u * kp : 0u, ab, a.err, 0xA10u, lane, ts, [&](int k) { load_s(l, cb, k); })) return;
                 if (w == 0) DM_STAMP(64 + l * 8 + 0);
                 if (l > 0) {
-                    dm_f32x4 acc[MT];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
-                    dm_mma<MT, 128, 8>(S, lds, 8 * w, lane, acc);
-                    dm_arrive(misc + DM_M_CDONE, lane);
-                    float v[MT][4];
-                    if (fold(acc, v)) {
-                        // lane (g4, b): rows 4 g4 .. + 3 of my 6: g4 = 0 -> pairs 0, 1; g4 = 1 -> pair 2
-                        const dp_lu32* rp = (const dp_lu32*)(lds + DM_L_ROPE) + cb * 3;
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            const int b = 16 * m + bl;
+#pragma unroll 1
+                    for (int hf = 0; hf < NH; ++hf) {
+                        if (hf > 0 && !wait_half(hf, 4u * kp, 0xA11u)) return;
+                        dm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        dm_mma<8>(S, lds + DM_L_XB + hf * 32768, 8 * w, lane, acc);
+                        dm_arrive(misc + DM_M_CDONE + hf, lane);
+                        float v[4];
+                        if (fold(hf, acc, v)) {
+                            // lane (g4, b): rows 4 g4 .. + 3 of my 6: g4 = 0 -> pairs 0, 1; g4 = 1 -> pair 2
+                            const dp_lu32* rp = (const dp_lu32*)(lds + DM_L_ROPE) + cb * 3;
+                            const int b = 16 * hf + bl;
                             if (g4 < 2 && b < a.M) {
                                 const int u0 = 2 * g4;
-                                const uint32_t o0 = dp_rope_pair(v[m][0], v[m][1], rp[u0], 2 * (3 * cu + u0) < 1280);
+                                const uint32_t o0 = dp_rope_pair(v[0], v[1], rp[u0], 2 * (3 * cu + u0) < 1280);
                                 dm_sst4(xq, (uint32_t)(b * 3072 + (6 * cu + 2 * u0) * 2), o0);
                                 dm_sst4(xq2, (uint32_t)(b * 3072 + (6 * cu + 2 * u0) * 2), 0xffffffffu);
                                 if (g4 == 0) {
-                                    const uint32_t o1 = dp_rope_pair(v[m][2], v[m][3], rp[1], 2 * (3 * cu + 1) < 1280);
+                                    const uint32_t o1 = dp_rope_pair(v[2], v[3], rp[1], 2 * (3 * cu + 1) < 1280);
                                     dm_sst4(xq, (uint32_t)(b * 3072 + (6 * cu + 2) * 2), o1);
                                     dm_sst4(xq2, (uint32_t)(b * 3072 + (6 * cu + 2) * 2), 0xffffffffu);
                                 }
@@ -447,20 +438,19 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                 ++kp;
                 if (!dp_wait<24, true>(fill, 4u * kp, ab, a.err, 0xA20u, lane, ts, [&](int k) { if (k < 8) load_s(4 + l, cb, k); else load_gu(l, k - 8); })) return;
                 if (w == 0) DM_STAMP(64 + l * 8 + 2);
-                dm_f32x4 acc[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
-                dm_mma<MT, 128, 8>(S, lds, 8 * w, lane, acc);
-                dm_arrive(misc + DM_M_CDONE, lane);
-                float v[MT][4];
-                if (fold(acc, v)) {
-                    if (l == 0 && !dm_wait_ge((dp_lvu32*)(misc + DM_M_FT), (uint32_t)(s + 1), ab, a.err, 0xA25u, lane)) return;
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const int b = 16 * m + bl;
+#pragma unroll 1
+                for (int hf = 0; hf < NH; ++hf) {
+                    if (hf > 0 && !wait_half(hf, 4u * kp, 0xA21u)) return;
+                    dm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    dm_mma<8>(S, lds + DM_L_XB + hf * 32768, 8 * w, lane, acc);
+                    dm_arrive(misc + DM_M_CDONE + hf, lane);
+                    float v[4];
+                    if (fold(hf, acc, v)) {
+                        if (l == 0 && !dm_wait_ge((dp_lvu32*)(misc + DM_M_FT + hf), (uint32_t)(s + 1), ab, a.err, 0xA25u, lane)) return;
+                        const int b = 16 * hf + bl;
                         if (g4 == 0 && b < mpad) {
                             const dp_lu32* hr = (const dp_lu32*)(lds + DM_L_HRES) + 2 * b;
-                            const uint32_t p0 = dp_resid_pair(v[m][0], v[m][1], hr[0]), p1 = dp_resid_pair(v[m][2], v[m][3], hr[1]);
+                            const uint32_t p0 = dp_resid_pair(v[0], v[1], hr[0]), p1 = dp_resid_pair(v[2], v[3], hr[1]);
                             dp_lu32* h1 = (dp_lu32*)(lds + DM_L_HRES1) + 2 * b;
                             h1[0] = p0; h1[1] = p1;
                             dm_sst8(xh, (uint32_t)(cu * 256 + b * 8), p0, p1);
@@ -474,16 +464,15 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                 ++kp;
                 if (!dp_wait<24, true>(fill, 4u * kp, ab, a.err, 0xA30u, lane, ts, [&](int k) { if (k < 16) load_gu(l, 16 + k); else load_dn(l, k - 16); })) return;
                 if (w == 0) DM_STAMP(64 + l * 8 + 4);
-                dm_f32x4 acc[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
-                dm_mma<MT, 128, 32>(W, lds, 0, lane, acc);
-                dm_arrive(misc + DM_M_CDONE, lane);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int b = 16 * m + bl;
+#pragma unroll 1
+                for (int hf = 0; hf < NH; ++hf) {
+                    if (hf > 0 && !wait_half(hf, 4u * kp, 0xA31u)) return;
+                    dm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    dm_mma<32>(W, lds + DM_L_XB + hf * 32768, 0, lane, acc);
+                    dm_arrive(misc + DM_M_CDONE + hf, lane);
+                    const int b = 16 * hf + bl;
                     if (b < a.M) {
-                        const uint32_t hv = dp_swiglu(acc[m][0], acc[m][1]) | (dp_swiglu(acc[m][2], acc[m][3]) << 16);
+                        const uint32_t hv = dp_swiglu(acc[0], acc[1]) | (dp_swiglu(acc[2], acc[3]) << 16);
                         const uint32_t off = (uint32_t)(gg * 32768 + gj * 2048 + b * 64 + (8 * w + 2 * g4) * 2);
                         dm_sst4(xg, off, hv);
                         dm_sst4(xg2, off, 0xffffffffu);
@@ -495,23 +484,22 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                 ++kp;
                 if (!dp_wait<8, true>(fill, 4u * kp, ab, a.err, 0xA40u, lane, ts, [&](int k) { load_dn(l, 8 + k); })) return;
                 if (w == 0) DM_STAMP(64 + l * 8 + 6);
-                dm_f32x4 acc[MT];
+#pragma unroll 1
+                for (int hf = 0; hf < NH; ++hf) {
+                    if (hf > 0 && !wait_half(hf, 4u * kp, 0xA41u)) return;
+                    dm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    dm_mma<8>(D, lds + DM_L_XB + hf * 32768, 0, lane, acc);
+                    {
+                        uint4 W8[8];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
-                dm_mma<MT, 64, 8>(D, lds, 0, lane, acc);
-                {
-                    uint4 W8[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) W8[k] = W[k];
-                    dm_mma<MT, 64, 8>(W8, lds, 8, lane, acc);
-                }
-                dm_arrive(misc + DM_M_CDONE, lane);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int b = 16 * m + bl;
+                        for (int k = 0; k < 8; ++k) W8[k] = W[k];
+                        dm_mma<8>(W8, lds + DM_L_XB + hf * 32768, 8, lane, acc);
+                    }
+                    dm_arrive(misc + DM_M_CDONE + hf, lane);
+                    const int b = 16 * hf + bl;
                     if (b < a.M) {
                         const uint32_t off = (uint32_t)((((gj * 16 + gg) * 32 + b) * 64 + 16 * w + 4 * g4) * 4);
-                        u32x4_t o; o.x = __float_as_uint(acc[m][0]); o.y = __float_as_uint(acc[m][1]); o.z = __float_as_uint(acc[m][2]); o.w = __float_as_uint(acc[m][3]);
+                        u32x4_t o; o.x = __float_as_uint(acc[0]); o.y = __float_as_uint(acc[1]); o.z = __float_as_uint(acc[2]); o.w = __float_as_uint(acc[3]);
                         u32x4_t ff; ff.x = ff.y = ff.z = ff.w = 0xffffffffu;
                         dm_sst16(xp, off, o);
                         dm_sst16(xp2, off, ff);
@@ -524,20 +512,19 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
             ++kp;
             if (!dp_wait<8, true>(fill, 4u * kp, ab, a.err, 0xA50u, lane, ts, [&](int k) { load_s(8, cb, k); })) return;
             if (w == 0) DM_STAMP(96);
-            dm_f32x4 acc[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = dm_f32x4{0.f, 0.f, 0.f, 0.f};
-            dm_mma<MT, 128, 8>(S, lds, 8 * w, lane, acc);
-            dm_arrive(misc + DM_M_CDONE, lane);
-            float v[MT][4];
-            if (fold(acc, v)) {
-                char* const xl = a.xchg + DM_OFF_L + (s % DM_R) * DM_L_BYTES, *const xl2 = a.xchg + DM_OFF_L + ((s + 2) % DM_R) * DM_L_BYTES;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int b = 16 * m + bl;
+            char* const xl = a.xchg + DM_OFF_L + (s % DM_R) * DM_L_BYTES, *const xl2 = a.xchg + DM_OFF_L + ((s + 2) % DM_R) * DM_L_BYTES;
+#pragma unroll 1
+            for (int hf = 0; hf < NH; ++hf) {
+                if (hf > 0 && !wait_half(hf, 4u * kp, 0xA51u)) return;
+                dm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                dm_mma<8>(S, lds + DM_L_XB + hf * 32768, 8 * w, lane, acc);
+                dm_arrive(misc + DM_M_CDONE + hf, lane);
+                float v[4];
+                if (fold(hf, acc, v)) {
+                    const int b = 16 * hf + bl;
                     if (b < a.M && (g4 < 2 || cu == 0)) {
                         const uint32_t off = (uint32_t)((g4 < 2 ? cu : 256) * 512 + b * 16 + (g4 & 1) * 8);
-                        dm_sst8(xl, off, pack_bf(v[m][0], v[m][1]), pack_bf(v[m][2], v[m][3]));
+                        dm_sst8(xl, off, pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
                         dm_sst8(xl2, off, 0xffffffffu, 0xffffffffu);
                     }
                 }
@@ -550,39 +537,43 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
 // ---------------------------------------------------------------------------------------------------------------
 // gather wave gw (0..3)
 // ---------------------------------------------------------------------------------------------------------------
-template <int MT>
+template <int NH>
 __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* lds, const int gw, const int lane, const int cu) {
     dp_lu32* misc = (dp_lu32*)(lds + DM_L_MISC);
     dp_lvu32* ab = (dp_lvu32*)(misc + DM_M_ABORT);
     dp_lvu32* cdone = (dp_lvu32*)(misc + DM_M_CDONE);
     const int ob = cu >> 3, oh = cu & 7, kvh = oh >> 2;      // the (row, head) this workgroup owns
-    const bool owner = ob < a.M;
+    const int ohf = ob < a.M ? (ob >> 4) : -1;                 // ... in which half (-1: no row of this batch)
     const int gj = cu >> 4, gg = cu & 15;
     const int ps = a.poll_sleep;
+    const int mpad = (a.M + 1) & ~1;
     uint32_t kf = 0, quad_phase = 0;
     const int n_steps = a.cb_last - a.cb_first + 1;
-    const int mpad = (a.M + 1) & ~1;
-    // my lane's piece offsets in the row-major attention matrix and in my group's h blocks [16 j][32 rows][32 columns]
-    uint32_t voff_a, voff_g;
-    {
-        constexpr int RW = 4 * MT;
-        const int rowc = min(gw * RW + (lane & (RW - 1)), a.M - 1), pg = lane / RW;
-        voff_a = (uint32_t)(rowc * 2048 + pg * 16);
-        voff_g = (uint32_t)((pg >> 2) * 2048 + rowc * 64 + (pg & 3) * 16);
+    // my lane's piece offsets in the row-major attention matrix and in my group's h blocks [16 j][32 rows][32 columns], per half
+    uint32_t voff_a[NH], voff_g[NH];
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {
+        const int rowc = min(16 * hf + gw * 4 + (lane & 3), a.M - 1), pg = lane >> 2;
+        voff_a[hf] = (uint32_t)(rowc * 2048 + pg * 16);
+        voff_g[hf] = (uint32_t)((pg >> 2) * 2048 + rowc * 64 + (pg & 3) * 16);
     }
-    // fill k of the activation buffer may start once phase k - 1 has read it
-#define DM_FILL_BEGIN(code_) do { ++kf; if (!dm_wait_ge(cdone, 4u * (kf - 1), ab, a.err, (code_), lane)) return; } while (0)
-#define DM_FILL_END() dm_arrive(misc + DM_M_FILL, lane)
+    // fill k of a half's activation buffer may start once that half's phase k - 1 has read it
+#define DM_FILL_BEGIN(hf_, code_) do { if (!dm_wait_ge(cdone + (hf_), 4u * (kf - 1), ab, a.err, (code_), lane)) return; } while (0)
+#define DM_FILL_END(hf_) dm_arrive(misc + DM_M_FILL + (hf_), lane)
     for (int s = 0; s < n_steps; ++s) {
         const int cb = a.cb_first + s;
         for (int l = 0; l < DP_NL; ++l) {
             const int n = s * DP_NL + l;
             if (l > 0) {
-                DM_FILL_BEGIN(0xB10u);
-                if (!dm_sweep_cols<MT>(a.xchg + DM_OFF_X + ((n - 1) % DM_R) * DM_X_BYTES, a.M, 2 * l, a.eps, lds, gw, lane, ab, a.err, 0x110u + l, ps)) return;
-                DM_FILL_END();
+                ++kf;
+#pragma unroll 1
+                for (int hf = 0; hf < NH; ++hf) {
+                    DM_FILL_BEGIN(hf, 0xB10u);
+                    if (!dm_sweep_cols(a.xchg + DM_OFF_X + ((n - 1) % DM_R) * DM_X_BYTES, hf, a.M, 2 * l, a.eps, lds, gw, lane, ab, a.err, 0x110u + l, ps)) return;
+                    DM_FILL_END(hf);
+                }
                 if (gw == 0) DM_STAMP(l * 8 + 0);
-                if (owner && gw == 0) {
+                if (ohf >= 0 && gw == 0) {
                     // q of my head, k / v of my kv head, this step's position
                     const int nq = s * (DP_NL - 1) + l - 1;
                     const char* q = a.xchg + DM_OFF_Q + (nq % DM_R) * DM_Q_BYTES + (long)ob * 3072;
@@ -597,62 +588,82 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
                     DM_STAMP(l * 8 + 1);
                 }
             }
-            if (owner && gw == 0) {
+            if (ohf >= 0 && gw == 0) {
                 const uint32_t o = dm_attention(lds, l, cb + 1, lane);
                 const long off = (long)ob * 2048 + oh * 256 + lane * 4;
                 dm_st4(a.xchg + DM_OFF_A + (n % DM_R) * DM_X_BYTES + off, o);
                 dm_st4(a.xchg + DM_OFF_A + ((n + 2) % DM_R) * DM_X_BYTES + off, 0xffffffffu);
                 DM_STAMP(l * 8 + 2);
             }
-            DM_FILL_BEGIN(0xB20u);
-            if (!dm_sweep_mat<MT, 128, (64 / (4 * MT)) * 16>(a.xchg + DM_OFF_A + (n % DM_R) * DM_X_BYTES, voff_a, lds, gw, lane, ab, a.err, 0x310u + l, ps)) return;
-            DM_FILL_END();
+            ++kf;
+#pragma unroll 1
+            for (int hf = 0; hf < NH; ++hf) {
+                DM_FILL_BEGIN(hf, 0xB20u);
+                if (!dm_sweep_mat<128, 256>(a.xchg + DM_OFF_A + (n % DM_R) * DM_X_BYTES, voff_a[hf], lds + DM_L_XB + hf * 32768, gw, lane, ab, a.err, 0x310u + l, ps)) return;
+                DM_FILL_END(hf);
+            }
             if (gw == 0) DM_STAMP(l * 8 + 3);
-            DM_FILL_BEGIN(0xB30u);
-            if (!dm_sweep_cols<MT>(a.xchg + DM_OFF_H1 + (n % DM_R) * DM_X_BYTES, a.M, 2 * l + 1, a.eps, lds, gw, lane, ab, a.err, 0x410u + l, ps)) return;
-            DM_FILL_END();
+            ++kf;
+#pragma unroll 1
+            for (int hf = 0; hf < NH; ++hf) {
+                DM_FILL_BEGIN(hf, 0xB30u);
+                if (!dm_sweep_cols(a.xchg + DM_OFF_H1 + (n % DM_R) * DM_X_BYTES, hf, a.M, 2 * l + 1, a.eps, lds, gw, lane, ab, a.err, 0x410u + l, ps)) return;
+                DM_FILL_END(hf);
+            }
             if (gw == 0) DM_STAMP(l * 8 + 4);
-            DM_FILL_BEGIN(0xB40u);
-            if (!dm_sweep_mat<MT, 64, ((64 / (4 * MT)) / 4) * 2048>(a.xchg + DM_OFF_HG + (n % DM_R) * DM_HG_BYTES + (long)gg * 32768, voff_g, lds, gw, lane, ab, a.err, 0x510u + l, ps)) return;
-            DM_FILL_END();
+            ++kf;
+#pragma unroll 1
+            for (int hf = 0; hf < NH; ++hf) {
+                DM_FILL_BEGIN(hf, 0xB40u);
+                if (!dm_sweep_mat<64, 8192>(a.xchg + DM_OFF_HG + (n % DM_R) * DM_HG_BYTES + (long)gg * 32768, voff_g[hf], lds + DM_L_XB + hf * 32768, gw, lane, ab, a.err, 0x510u + l, ps)) return;
+                DM_FILL_END(hf);
+            }
             if (gw == 0) DM_STAMP(l * 8 + 5);
             if (gw == 1) {
-                // the 16 partial sums of my 4 columns, every row: lane = (row b = lane & 31, half of the groups); fixed order
-                const int b = lane & 31, bc = min(b, a.M - 1), half = lane >> 5;
-                const char* pb = a.xchg + DM_OFF_P + (n % DM_R) * DM_P_BYTES;
-                const char* p[8];
-                u32x4_t x[8];
+#pragma unroll 1
+                for (int hf = 0; hf < NH; ++hf) {
+                    // the 16 partial sums of my 4 columns, every row of the half: lane = (row, quarter of the groups); fixed order
+                    const int b = 16 * hf + (lane & 15), bc = min(b, a.M - 1), qt = lane >> 4;
+                    const char* pb = a.xchg + DM_OFF_P + (n % DM_R) * DM_P_BYTES;
+                    const char* p[4];
+                    u32x4_t x[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) p[i] = pb + ((((long)gj * 16 + (half * 8 + i)) * 32 + bc) * 64 + 4 * gg) * 4;
-                if (!dm_poll<8>(p, x, lane, ab, a.err, 0x610u + l, ps)) return;
-                float t[4] = {__uint_as_float(x[0].x), __uint_as_float(x[0].y), __uint_as_float(x[0].z), __uint_as_float(x[0].w)};
+                    for (int i = 0; i < 4; ++i) p[i] = pb + ((((long)gj * 16 + (qt * 4 + i)) * 32 + bc) * 64 + 4 * gg) * 4;
+                    if (!dm_poll<4>(p, x, lane, ab, a.err, 0x610u + l, ps)) return;
+                    float t[4] = {__uint_as_float(x[0].x), __uint_as_float(x[0].y), __uint_as_float(x[0].z), __uint_as_float(x[0].w)};
 #pragma unroll
-                for (int i = 1; i < 8; ++i) { t[0] += __uint_as_float(x[i].x); t[1] += __uint_as_float(x[i].y); t[2] += __uint_as_float(x[i].z); t[3] += __uint_as_float(x[i].w); }
+                    for (int i = 1; i < 4; ++i) { t[0] += __uint_as_float(x[i].x); t[1] += __uint_as_float(x[i].y); t[2] += __uint_as_float(x[i].z); t[3] += __uint_as_float(x[i].w); }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float o = __shfl_xor(t[i], 32, 64);
-                    t[i] = half == 0 ? t[i] + o : o + t[i];
-                }
-                if (lane < 32 && b < mpad) {
-                    const dp_lu32* h1 = (const dp_lu32*)(lds + DM_L_HRES1) + 2 * b;
-                    const uint32_t p0 = dp_resid_pair(t[0], t[1], h1[0]), p1 = dp_resid_pair(t[2], t[3], h1[1]);
-                    dp_lu32* hr = (dp_lu32*)(lds + DM_L_HRES) + 2 * b;
-                    hr[0] = p0; hr[1] = p1;
-                    dm_st8(a.xchg + DM_OFF_X + (n % DM_R) * DM_X_BYTES + cu * 256 + b * 8, p0, p1);
-                    dm_st8(a.xchg + DM_OFF_X + ((n + 2) % DM_R) * DM_X_BYTES + cu * 256 + b * 8, 0xffffffffu, 0xffffffffu);
+                    for (int i = 0; i < 4; ++i) {
+                        const float o1 = __shfl_xor(t[i], 16, 64);
+                        const float u = (qt & 1) == 0 ? t[i] + o1 : o1 + t[i];        // (q0 + q1) or (q2 + q3), the same bits in both lanes
+                        const float o2 = __shfl_xor(u, 32, 64);
+                        t[i] = qt < 2 ? u + o2 : o2 + u;
+                    }
+                    if (lane < 16 && b < mpad) {
+                        const dp_lu32* h1 = (const dp_lu32*)(lds + DM_L_HRES1) + 2 * b;
+                        const uint32_t p0 = dp_resid_pair(t[0], t[1], h1[0]), p1 = dp_resid_pair(t[2], t[3], h1[1]);
+                        dp_lu32* hr = (dp_lu32*)(lds + DM_L_HRES) + 2 * b;
+                        hr[0] = p0; hr[1] = p1;
+                        dm_st8(a.xchg + DM_OFF_X + (n % DM_R) * DM_X_BYTES + cu * 256 + b * 8, p0, p1);
+                        dm_st8(a.xchg + DM_OFF_X + ((n + 2) % DM_R) * DM_X_BYTES + cu * 256 + b * 8, 0xffffffffu, 0xffffffffu);
+                    }
                 }
                 DM_STAMP(l * 8 + 6);
             }
         }
         {   // the stack's output rows -> final norm -> x of the head
             const int n = s * DP_NL + DP_NL - 1;
-            DM_FILL_BEGIN(0xB50u);
-            if (!dm_sweep_cols<MT>(a.xchg + DM_OFF_X + (n % DM_R) * DM_X_BYTES, a.M, 8, a.eps, lds, gw, lane, ab, a.err, 0x710u, ps)) return;
-            DM_FILL_END();
+            ++kf;
+#pragma unroll 1
+            for (int hf = 0; hf < NH; ++hf) {
+                DM_FILL_BEGIN(hf, 0xB50u);
+                if (!dm_sweep_cols(a.xchg + DM_OFF_X + (n % DM_R) * DM_X_BYTES, hf, a.M, 8, a.eps, lds, gw, lane, ab, a.err, 0x710u, ps)) return;
+                DM_FILL_END(hf);
+            }
             if (gw == 0) DM_STAMP(32);
         }
-        int fed = 0;
-        if (owner) {
+        if (ohf >= 0) {
             // logits of my row -> registers (thread tid of the quad owns logits 8 tid .. + 7, tid 0 also the tail piece), sample
             const int tid = gw * 64 + lane;
             const char* lrow = a.xchg + DM_OFF_L + (s % DM_R) * DM_L_BYTES + ob * 16;
@@ -672,10 +683,11 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
                     if (tid == 0 && i1 < a.V) dst[i1] = (bf16_t)((j & 1) ? (wv[1][j >> 1] >> 16) : (wv[1][j >> 1] & 0xffffu));
                 }
             }
-            // the sampler's scratch aliases the activation buffer: every phase of this step must have read it
-            if (!dm_wait_ge(cdone, 4u * kf, ab, a.err, 0xB60u, lane)) return;
+            // the sampler's scratch aliases my half's activation buffer: every phase of this step must have read it
+            if (!dm_wait_ge(cdone + ohf, 4u * kf, ab, a.err, 0xB60u, lane)) return;
+            char* scr = lds + DM_L_XB + ohf * 32768;
             SampleScratch sc;
-            sc.cand_t = (lds_f32_t*)(lds + DM_L_CANDT); sc.cand_i = (lds_i32_t*)(lds + DM_L_CANDI); sc.s_max = (lds_u32_t*)(lds + DM_L_SMAX); sc.cand_q = (lds_f32_t*)(lds + DM_L_SMAX);
+            sc.cand_t = (lds_f32_t*)(scr + DM_L_CANDT); sc.cand_i = (lds_i32_t*)(scr + DM_L_CANDI); sc.s_max = (lds_u32_t*)(lds + DM_L_SMAX); sc.cand_q = (lds_f32_t*)(lds + DM_L_SMAX);
             sc.s_bv = (lds_f32_t*)(misc + DM_M_SBV); sc.s_bi = (lds_i32_t*)(misc + DM_M_SBI); sc.s_n = (lds_i32_t*)(misc + DM_M_SN);
             sc.s_tok = (lds_i32_t*)(misc + DM_M_STOK); sc.s_wtot = (lds_i32_t*)(misc + DM_M_SWTOT);
             DpQuadSync sync{(dp_lvu32*)(misc + DM_M_BAR), ab, a.err, lane, &quad_phase, nullptr};
@@ -683,14 +695,10 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
             const int sV = (int)misc[DM_M_SARG], sK = (int)misc[DM_M_SARG + 2];
             const float sT = __uint_as_float(misc[DM_M_SARG + 1]);
             const bool sN = misc[DM_M_SARG + 3] != 0u;
-#ifdef DM_NO_SAMPLE
-            const int tok = (int)wv[0][0] & 1023; (void)sc; (void)sync; (void)seed; (void)step; (void)sV; (void)sK; (void)sT; (void)sN;
-#else
             const int tok = sample_body<2>(wv, sV, sT, sK, sN ? a.noise + ((long)cb * a.M + ob) * sV : nullptr, seed, step, ob, cb, sc, tid, sync);
-#endif
             if (*ab) return;
             if (gw == 0) DM_STAMP(34);
-            fed = a.forced ? a.forced[(long)ob * a.ncb + cb] : tok;
+            int fed = a.forced ? a.forced[(long)ob * a.ncb + cb] : tok;
             fed = min(max(fed, 0), a.V - 1);
             if (gw == 0) {
                 if (oh == 0 && lane == 0) {
@@ -713,16 +721,19 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
             }
         }
         if (cb + 1 < a.ncb && gw == 2) {
-            // every row's fed token -> my 4 residual columns of the next step's input rows
-            const int bc = min(lane, a.M - 1);
-            uint32_t tw;
-            if (!dm_poll4(a.xchg + DM_OFF_T + (s % DM_R) * DM_T_BYTES + bc * 4, tw, lane, ab, a.err, 0x910u, ps)) return;
-            const int tk = min(max((int)tw, 0), a.V - 1);
-            typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
-            const u32x2v hv = *reinterpret_cast<const u32x2v*>(a.proj_emb + ((long)cb * a.V + tk) * DP_D + 4 * cu);
-            if (lane < a.M) { dp_lu32* hr = (dp_lu32*)(lds + DM_L_HRES) + 2 * lane; hr[0] = hv.x; hr[1] = hv.y; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) misc[DM_M_FT] = (uint32_t)(s + 2);
+            // every row's fed token -> my 4 residual columns of the next step's input rows, half by half
+#pragma unroll 1
+            for (int hf = 0; hf < NH; ++hf) {
+                const int b = 16 * hf + (lane & 15), bc = min(b, a.M - 1);
+                uint32_t tw;
+                if (!dm_poll4(a.xchg + DM_OFF_T + (s % DM_R) * DM_T_BYTES + bc * 4, tw, lane, ab, a.err, 0x910u, ps)) return;
+                const int tk = min(max((int)tw, 0), a.V - 1);
+                typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+                const u32x2v hv = *reinterpret_cast<const u32x2v*>(a.proj_emb + ((long)cb * a.V + tk) * DP_D + 4 * cu);
+                if (lane < 16 && b < a.M) { dp_lu32* hr = (dp_lu32*)(lds + DM_L_HRES) + 2 * b; hr[0] = hv.x; hr[1] = hv.y; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) misc[DM_M_FT + hf] = (uint32_t)(s + 2);
+            }
             DM_STAMP(36);
         }
     }
@@ -730,7 +741,7 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
 #undef DM_FILL_END
 }
 
-template <int MT>
+template <int NH>
 __global__ __launch_bounds__(512) void k_dec_persist_m(const DecPersistMArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cu = blockIdx.x;
@@ -761,7 +772,10 @@ __global__ __launch_bounds__(512) void k_dec_persist_m(const DecPersistMArgs a) 
             ((dp_lu32*)(lds + DM_L_ROPE))[i] = reinterpret_cast<const uint32_t*>(a.rope)[pos * (DP_HD / 2) + e / 2];
         }
         if (threadIdx.x >= 256 && threadIdx.x < 260) misc[DM_M_RNG + threadIdx.x - 256] = a.rng ? reinterpret_cast<const uint32_t*>(a.rng)[threadIdx.x - 256] : 0u;
-        if (threadIdx.x == 320) { misc[DM_M_SARG] = (uint32_t)a.V; misc[DM_M_SARG + 1] = __float_as_uint(a.temperature); misc[DM_M_SARG + 2] = (uint32_t)a.topk; misc[DM_M_SARG + 3] = a.noise != nullptr; misc[DM_M_FT] = 1u; }
+        if (threadIdx.x == 320) {
+            misc[DM_M_SARG] = (uint32_t)a.V; misc[DM_M_SARG + 1] = __float_as_uint(a.temperature); misc[DM_M_SARG + 2] = (uint32_t)a.topk; misc[DM_M_SARG + 3] = a.noise != nullptr;
+            misc[DM_M_FT] = 1u; misc[DM_M_FT + 1] = 1u;
+        }
         for (int i = threadIdx.x; i < 9 * 128; i += 512) {
             const int nrm = i >> 7, c = i & 127;
             const bf16_t* src = nrm < 8 ? a.norms + (long)nrm * DP_D : a.dec_norm;
@@ -772,10 +786,10 @@ __global__ __launch_bounds__(512) void k_dec_persist_m(const DecPersistMArgs a) 
 #ifndef DM_ONLY_ROLE
 #define DM_ONLY_ROLE 0            // (register-pressure probes: 1 = compute waves only, 2 = gather waves only)
 #endif
-    if (wave < 4) { if (DM_ONLY_ROLE != 2) dm_compute_wave<MT>(a, lds, wave, lane, cu); }
+    if (wave < 4) { if (DM_ONLY_ROLE != 2) dm_compute_wave<NH>(a, lds, wave, lane, cu); }
     else if (DM_ONLY_ROLE != 1) {
         __builtin_amdgcn_s_setprio(2);
-        dm_gather_wave<MT>(a, lds, wave - 4, lane, cu);
+        dm_gather_wave<NH>(a, lds, wave - 4, lane, cu);
     }
 }
 
