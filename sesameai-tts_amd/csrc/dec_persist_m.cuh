@@ -65,7 +65,8 @@
 #define DM_L_ROPE (DM_L_PS + 128)                 // [32 pos][3 pairs] (cos, sin) of my q|k|v pairs
 #define DM_L_SMAX (DM_L_ROPE + 384)               // sampler: 256 u32
 #define DM_L_NORM (DM_L_SMAX + 1024)              // [9][1024] bf16: sa/mlp norms of the 4 layers, final norm
-#define DM_LDS_BYTES (DM_L_NORM + 9 * 2048)
+#define DM_L_SSQ (DM_L_NORM + 9 * 2048)           // [2 sweep parities][2 halves][4 gather waves][16 rows] f32 partial sums of squares
+#define DM_LDS_BYTES (DM_L_SSQ + 1024)
 #define DM_L_CANDT 0                              // sampler scratch: offsets into the owner's half of the activation buffer
 #define DM_L_CANDI (DP_CAND_SLOTS * 4)
 static_assert(DM_LDS_BYTES <= 163840, "LDS image exceeds 160 KB");
@@ -233,14 +234,17 @@ __device__ __forceinline__ bool dm_sweep_mat(const char* buf, uint32_t voff, cha
 // All-gather of a half's rows of the residual stream, published as [256 workgroups][32 rows][4 columns] (a producer's 256 bytes are two
 // whole cache lines: with a row-major matrix 16 workgroups write 8 bytes each into every line, and the edge took 10-15 us instead of
 // 4), + RMSNorm with scale row `norm` of the LDS copy (fp32 normalise -> bf16 -> * bf16 scale, torchtune's rounding points).  Wave gw
-// takes row pairs 2 gw, 2 gw + 1 of the half; lane = (row pair, workgroup group cg of 32); load j = workgroup 32 j + cg: 16 bytes = its
-// 4 columns of the pair's two rows.
+// takes the 64 workgroups 64 gw .. + 63 (columns 256 gw .. + 255) of ALL 16 rows: lane = (row pair of the half, workgroup lane >> 3),
+// load j = workgroup 64 gw + 8 j + (lane >> 3) -- 8 lanes read one whole 128-byte line, a line is read once per workgroup (with the rows
+// split over the waves instead, every wave touched every line for 32 bytes and the sweep was request-bound: 6.5 us against 2.7 for the
+// same bytes row-major).  The rows' sums of squares meet in LDS: per-wave partials, the four gather waves' barrier, fixed-order sum.
+template <class Sync>
 __device__ __forceinline__ bool dm_sweep_cols(const char* buf, int hf, int M, int norm, float eps, char* lds, int gw, int lane, dp_lvu32* ab, uint32_t* err,
-                                              uint32_t code, int poll_sleep) {
-    const int rpl = lane & 1, cg = lane >> 1;
-    const int rp = gw * 2 + rpl, rpc = min(8 * hf + rp, (M - 1) >> 1);
+                                              uint32_t code, int poll_sleep, const Sync& sync, int parity) {
+    const int pr = lane & 7, cl = lane >> 3;
+    const int prc = min(8 * hf + pr, (M - 1) >> 1);
     u32x4_t x[8];
-    if (!dm_poll_s<8, 32 * 256>(buf, (uint32_t)(cg * 256 + rpc * 16), x, lane, ab, err, code, poll_sleep)) return false;
+    if (!dm_poll_s<8, 8 * 256>(buf, (uint32_t)((gw * 64 + cl) * 256 + prc * 16), x, lane, ab, err, code, poll_sleep)) return false;
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -249,16 +253,22 @@ __device__ __forceinline__ bool dm_sweep_cols(const char* buf, int hf, int M, in
         f = lo2f(x[j].z); s1 += f * f; f = hi2f(x[j].z); s1 += f * f; f = lo2f(x[j].w); s1 += f * f; f = hi2f(x[j].w); s1 += f * f;
     }
 #pragma unroll
-    for (int o = 2; o < 64; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
-    const float r0 = 1.0f / sqrtf(s0 / 1024.0f + eps), r1 = 1.0f / sqrtf(s1 / 1024.0f + eps);
+    for (int o = 8; o < 64; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    // (two buffers by sweep parity: a wave may write the next sweep's partials while a slower one still reads this sweep's)
+    dp_lf32* ssq = (dp_lf32*)(lds + DM_L_SSQ) + (parity * 2 + hf) * 64;                 // [4 waves][16 rows]
+    if (lane < 8) { ssq[gw * 16 + 2 * pr] = s0; ssq[gw * 16 + 2 * pr + 1] = s1; }
+    sync();
+    const float t0 = ((ssq[2 * pr] + ssq[16 + 2 * pr]) + ssq[32 + 2 * pr]) + ssq[48 + 2 * pr];
+    const float t1 = ((ssq[2 * pr + 1] + ssq[16 + 2 * pr + 1]) + ssq[32 + 2 * pr + 1]) + ssq[48 + 2 * pr + 1];
+    const float r0 = 1.0f / sqrtf(t0 / 1024.0f + eps), r1 = 1.0f / sqrtf(t1 / 1024.0f + eps);
     const dp_lu32* g = (const dp_lu32*)(lds + DM_L_NORM + norm * 2048);
     typedef __attribute__((address_space(3))) unsigned long long dm_lu64;
     char* xb = lds + DM_L_XB + hf * 32768;
-    const int ra = 2 * rp, rb = 2 * rp + 1;
+    const int ra = 2 * pr, rb = 2 * pr + 1;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         asm volatile("" : "+v"(x[j]));            // unpack again here: fp32 copies kept from the sum-of-squares pass spill
-        const int c = j * 32 + cg;
+        const int c = gw * 64 + j * 8 + cl;
         const uint32_t g0 = g[2 * c], g1 = g[2 * c + 1];
         const uint32_t a0 = pack_bf(round_bf(lo2f(x[j].x) * r0) * lo2f(g0), round_bf(hi2f(x[j].x) * r0) * hi2f(g0));
         const uint32_t a1 = pack_bf(round_bf(lo2f(x[j].y) * r0) * lo2f(g1), round_bf(hi2f(x[j].y) * r0) * hi2f(g1));
@@ -547,7 +557,8 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
     const int gj = cu >> 4, gg = cu & 15;
     const int ps = a.poll_sleep;
     const int mpad = (a.M + 1) & ~1;
-    uint32_t kf = 0, quad_phase = 0;
+    uint32_t kf = 0, nsw = 0, quad_phase = 0;          // fills so far, normed sweeps so far
+    const DpQuadSync qsync{(dp_lvu32*)(misc + DM_M_BAR), ab, a.err, lane, &quad_phase, nullptr};      // barrier of the four gather waves
     const int n_steps = a.cb_last - a.cb_first + 1;
     // my lane's piece offsets in the row-major attention matrix and in my group's h blocks [16 j][32 rows][32 columns], per half
     uint32_t voff_a[NH], voff_g[NH];
@@ -565,11 +576,11 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
         for (int l = 0; l < DP_NL; ++l) {
             const int n = s * DP_NL + l;
             if (l > 0) {
-                ++kf;
+                ++kf; ++nsw;
 #pragma unroll 1
                 for (int hf = 0; hf < NH; ++hf) {
                     DM_FILL_BEGIN(hf, 0xB10u);
-                    if (!dm_sweep_cols(a.xchg + DM_OFF_X + ((n - 1) % DM_R) * DM_X_BYTES, hf, a.M, 2 * l, a.eps, lds, gw, lane, ab, a.err, 0x110u + l, ps)) return;
+                    if (!dm_sweep_cols(a.xchg + DM_OFF_X + ((n - 1) % DM_R) * DM_X_BYTES, hf, a.M, 2 * l, a.eps, lds, gw, lane, ab, a.err, 0x110u + l, ps, qsync, (int)(nsw & 1u))) return;
                     DM_FILL_END(hf);
                 }
                 if (gw == 0) DM_STAMP(l * 8 + 0);
@@ -603,11 +614,11 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
                 DM_FILL_END(hf);
             }
             if (gw == 0) DM_STAMP(l * 8 + 3);
-            ++kf;
+            ++kf; ++nsw;
 #pragma unroll 1
             for (int hf = 0; hf < NH; ++hf) {
                 DM_FILL_BEGIN(hf, 0xB30u);
-                if (!dm_sweep_cols(a.xchg + DM_OFF_H1 + (n % DM_R) * DM_X_BYTES, hf, a.M, 2 * l + 1, a.eps, lds, gw, lane, ab, a.err, 0x410u + l, ps)) return;
+                if (!dm_sweep_cols(a.xchg + DM_OFF_H1 + (n % DM_R) * DM_X_BYTES, hf, a.M, 2 * l + 1, a.eps, lds, gw, lane, ab, a.err, 0x410u + l, ps, qsync, (int)(nsw & 1u))) return;
                 DM_FILL_END(hf);
             }
             if (gw == 0) DM_STAMP(l * 8 + 4);
@@ -654,11 +665,11 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
         }
         {   // the stack's output rows -> final norm -> x of the head
             const int n = s * DP_NL + DP_NL - 1;
-            ++kf;
+            ++kf; ++nsw;
 #pragma unroll 1
             for (int hf = 0; hf < NH; ++hf) {
                 DM_FILL_BEGIN(hf, 0xB50u);
-                if (!dm_sweep_cols(a.xchg + DM_OFF_X + (n % DM_R) * DM_X_BYTES, hf, a.M, 8, a.eps, lds, gw, lane, ab, a.err, 0x710u, ps)) return;
+                if (!dm_sweep_cols(a.xchg + DM_OFF_X + (n % DM_R) * DM_X_BYTES, hf, a.M, 8, a.eps, lds, gw, lane, ab, a.err, 0x710u, ps, qsync, (int)(nsw & 1u))) return;
                 DM_FILL_END(hf);
             }
             if (gw == 0) DM_STAMP(32);
@@ -690,7 +701,7 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
             sc.cand_t = (lds_f32_t*)(scr + DM_L_CANDT); sc.cand_i = (lds_i32_t*)(scr + DM_L_CANDI); sc.s_max = (lds_u32_t*)(lds + DM_L_SMAX); sc.cand_q = (lds_f32_t*)(lds + DM_L_SMAX);
             sc.s_bv = (lds_f32_t*)(misc + DM_M_SBV); sc.s_bi = (lds_i32_t*)(misc + DM_M_SBI); sc.s_n = (lds_i32_t*)(misc + DM_M_SN);
             sc.s_tok = (lds_i32_t*)(misc + DM_M_STOK); sc.s_wtot = (lds_i32_t*)(misc + DM_M_SWTOT);
-            DpQuadSync sync{(dp_lvu32*)(misc + DM_M_BAR), ab, a.err, lane, &quad_phase, nullptr};
+            const DpQuadSync& sync = qsync;
             const uint64_t seed = (uint64_t)misc[DM_M_RNG] | ((uint64_t)misc[DM_M_RNG + 1] << 32), step = (uint64_t)misc[DM_M_RNG + 2] | ((uint64_t)misc[DM_M_RNG + 3] << 32);
             const int sV = (int)misc[DM_M_SARG], sK = (int)misc[DM_M_SARG + 2];
             const float sT = __uint_as_float(misc[DM_M_SARG + 1]);
