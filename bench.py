@@ -59,47 +59,29 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def dominant_kernels(model, dev, reps=400):
-    """The two kernels that take the most time in the frame (profiles/r01/final_kernel_stats.csv): the depth
-    decoder's fused RMSNorm+gate/up+SiLU GEMV and its down-projection GEMV.  Each is launched `reps` times
-    back to back on the current stream over the four decoder layers' real weights (cycling, like the frame
-    does) between HIP events; achieved = weight bytes of one launch / average duration."""
+def dominant_kernels(model, B, temperature, topk, reps=20):
+    """The launches that carry the timed frame step, timed live (HIP events on the launching stream, back-to-back launches on
+    the handle's current state; include/csm_hip_ops.h csm_debug_time_kernels): the persistent depth-decoder launch (codebooks
+    2..31 of a frame: csrc/dec_persist.cuh at B = 1, csrc/dec_persist_m.cuh at B = 2..32) and, at B = 1, the one-launch backbone
+    layer (csrc/bb_block.cuh).  bytes = weight bytes the launch streams; the decoder's come from the Infinity Cache after the first
+    step (30 x 226 MB per launch, 222 MB of decoder layers resident), so its rate is not an HBM rate."""
+    import ctypes as C
     from sesameai import _abi
-    dec = model.dec
-    d, ffn = dec.embed_dim, dec.intermediate_dim
+    out = (C.c_double * 4)()
     st = torch.cuda.current_stream().cuda_stream
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(1, d, generator=g).to(torch.bfloat16).to(dev)
-    act = torch.randn(1, ffn, generator=g).to(torch.bfloat16).to(dev)
-    out_a = torch.zeros(1, ffn, dtype=torch.bfloat16, device=dev)
-    out_h = torch.zeros(1, d, dtype=torch.bfloat16, device=dev)
-    W = model._w
+    with torch.cuda.device(model.device):
+        _abi.check(_abi.lib.csm_debug_time_kernels(model._h, B, reps, float(temperature), int(topk), out, st), model._h)
     res = []
-    for name, kind, K, N, xin, outp in (("decoder rmsnorm+gate/up+silu GEMV", 4, d, ffn, x, out_a),
-                                        ("decoder down-proj+residual GEMV", 1, ffn, d, act, out_h)):
-        def launch(l):
-            L = f"decoder.layers.{l}"
-            if kind == 4:
-                _abi.lib.csm_op_gemv(4, 1, K, N, xin.data_ptr(), K, 0, W[f"{L}.mlp_norm.scale"].data_ptr(), 1e-5,
-                                     W[f"{L}.mlp.w1.weight"].data_ptr(), W[f"{L}.mlp.w3.weight"].data_ptr(), None, None,
-                                     outp.data_ptr(), N, None, K, 0, 64, 0, 0, 0, 0, 1, None, None, None, None, st)
-            else:
-                _abi.lib.csm_op_gemv(1, 1, K, N, xin.data_ptr(), K, 0, None, 1e-5, W[f"{L}.mlp.w2.weight"].data_ptr(), None, None,
-                                     outp.data_ptr(), outp.data_ptr(), N, None, K, 0, 64, 0, 0, 0, 0, 1, None, None, None, None, st)
-        for i in range(20):
-            launch(i % dec.num_layers)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for i in range(reps):
-            launch(i % dec.num_layers)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / reps
-        nbytes = (2 if kind == 4 else 1) * K * N * 2
-        res.append({"kernel": name, "bytes_per_launch": nbytes, "avg_us": round(us, 2),
-                    "achieved_GBps": round(nbytes / us / 1e3, 1), "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 3),
-                    "note": "eager back-to-back launches (includes the ~1.6 us launch floor per kernel)"})
+    if out[0] == out[0]:
+        res.append({"kernel": "k_dec_persist" if B == 1 else f"k_dec_persist_m<{1 if B <= 16 else 2}>",
+                    "does": f"codebooks 2..31 of a frame for {B} utterance(s): 30 steps x (4 decoder layers + head + sampler) in one launch",
+                    "launches_per_frame": 1, "bytes_streamed_per_launch": out[1], "avg_us": round(out[0], 1),
+                    "streamed_GBps": round(out[1] / out[0] / 1e3, 1), "us_per_decoder_step": round(out[0] / 30.0, 2),
+                    "bound": "cross-workgroup hand-off latency (see DESIGN.md); bytes come from the 256 MB Infinity Cache"})
+    if out[2] == out[2]:
+        res.append({"kernel": "k_bb_layer", "does": "one backbone layer of a B = 1 decode step (attention block + MLP) in one launch",
+                    "launches_per_frame": 16, "bytes_per_launch": out[3], "avg_us": round(out[2], 2),
+                    "achieved_GBps": round(out[3] / out[2] / 1e3, 1), "frac_of_hbm_peak": round(out[3] / out[2] / 1e3 / HBM_PEAK_GBS, 3)})
     return res
 
 
@@ -157,24 +139,46 @@ def cpu_baseline(args):
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: this (GPU-free) parent starts the N rank processes itself with the
     torch.distributed environment and relays rank 0's JSON line.  Nothing here touches the GPU, and no process that has
-    initialised the GPU is ever replaced by another program."""
+    initialised the GPU is ever replaced by another program.  Every child is polled: the first one that fails takes the
+    others down with it (by PID) instead of leaving them in a rendezvous until the distributed timeout."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
+    import tempfile
+    sk = socket.socket()
+    sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    procs, out_f = [], tempfile.TemporaryFile(mode="w+")
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if r == 0:
+            sk.close()                    # held until the first child is about to start: the window in which another job can take the port is this line
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    lines = [l for l in (out or "").splitlines() if l.startswith("{")]
+                                      stdout=out_f if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + float(os.environ.get("BENCH_SPAWN_TIMEOUT", "3000"))
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            rc = abs(bad[0]) if bad else 124
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    out_f.seek(0)
+    lines = [l for l in out_f.read().splitlines() if l.startswith("{")]
     if lines:
         print(lines[-1], flush=True)
-    rc = max(abs(c) for c in rcs)
     if rc == 0 and not lines:
         rc = 3
     sys.exit(rc)
@@ -193,17 +197,15 @@ def timed_steps(model, B, n, temperature, topk, use_graph=True):
     return e0.elapsed_time(e1) / n
 
 
-def extras_legs(args, margs, sd, dev):
-    """BASELINE configs 3 and 5 and the long-context single-stream step, each a short run inside this same process so
-    the driver's one bench line carries them (`extras`).  Not part of `value`."""
+def batch32_leg(args, margs, sd, dev, n_steps, seed0=4000, barrier=None):
+    """BASELINE config 3 (and, per rank, config 4): B = 32 x the config-2 prompt, hipGraph-captured frame step.  Returns
+    (result dict, wall seconds of the timed steps)."""
     from sesameai.models import Model
-    ex = {}
     T, K = args.temperature, args.topk
-    # ---- config 3: B=32 x the config-2 prompt, hipGraph-captured frame step ----
-    B3, n3 = 32, args.extra_steps
-    tok, msk = synthetic_prompt(args, B3, margs.text_vocab_size, seed0=4000)
+    B3 = 32
+    tok, msk = synthetic_prompt(args, B3, margs.text_vocab_size, seed0=seed0)
     S = tok.shape[1]
-    m3 = Model(margs, sd, device=str(dev), max_frames=n3 + 16, max_prefill_rows=B3 * S)
+    m3 = Model(margs, sd, device=str(dev), max_frames=n_steps + 16, max_prefill_rows=B3 * S)
     m3.setup_caches(B3); m3.seed(77)
     pos = torch.arange(S).unsqueeze(0).repeat(B3, 1)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -211,12 +213,71 @@ def extras_legs(args, margs, sd, dev):
     torch.cuda.synchronize(); pre_ms = (time.perf_counter() - t0) * 1e3
     for _ in range(5):
         m3.step(B3, T, K)
-    ms = timed_steps(m3, B3, n3, T, K)
-    by = m3.bytes_per_frame(B3, S + 5 + n3 / 2.0)
-    ex["config3"] = {"workload": f"CSM-1B B={B3}, S={S} prompt rows each, hipGraph frame step, {n3} timed steps", "ms_per_step": round(ms, 4),
-                     "frames_per_s": round(B3 * 1e3 / ms, 1), "rtf_aggregate": round(B3 * 1e3 / ms / 12.5, 1),
-                     "prefill_plus_frame0_ms": round(pre_ms, 1), "roofline_frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if barrier is not None:
+        barrier()
+    t0 = time.perf_counter()
+    ms = timed_steps(m3, B3, n_steps, T, K)
+    wall = time.perf_counter() - t0
+    frames, _ = m3.read_frames(B3)                    # raises if a launch gave up
+    assert int(frames.min()) >= 0 and int(frames.max()) < margs.audio_vocab_size
+    by = m3.bytes_per_frame(B3, S + 5 + n_steps / 2.0)
+    res = {"workload": f"CSM-1B B={B3}, S={S} prompt rows each, hipGraph frame step, {n_steps} timed steps", "ms_per_step": round(ms, 4),
+           "frames_per_s": round(B3 * 1e3 / ms, 1), "rtf_aggregate": round(B3 * 1e3 / ms / 12.5, 1),
+           "prefill_plus_frame0_ms": round(pre_ms, 1), "roofline_frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "dominant_kernels": dominant_kernels(m3, B3, T, K, reps=5)}
     del m3
+    return res, wall
+
+
+def reference_loop_leg(args, margs, sd, dev, n_frames=60):
+    """ms per frame when the model is driven exactly like the reference's loop (tts_service.py:224-241, generator.py:283-294):
+    one Model.generate_frame call per frame with S = 1 host-built rows, `torch.all(sample == 0)` read on the host after every
+    frame (a device sync), next row assembled with torch.cat on the device."""
+    from sesameai.models import Model
+    T, K = args.temperature, args.topk
+    tok, msk = synthetic_prompt(args, 1, margs.text_vocab_size)
+    S = tok.shape[1]
+    m = Model(margs, sd, device=str(dev), max_frames=n_frames + 16, max_prefill_rows=S)
+    m.setup_caches(1); m.seed(5)
+    zeros_tok, zeros_msk = torch.zeros(1, 1, dtype=torch.long, device=dev), torch.zeros(1, 1, dtype=torch.bool, device=dev)
+
+    def loop(n):
+        m.reset_caches()
+        curr_tokens, curr_mask = tok.to(dev), msk.to(dev)
+        curr_pos = torch.arange(S, device=dev).unsqueeze(0)
+        samples = []
+        for _ in range(n):
+            sample = m.generate_frame(curr_tokens, curr_mask, curr_pos, T, K)
+            if torch.all(sample == 0):
+                break
+            samples.append(sample)
+            curr_tokens = torch.cat([sample, zeros_tok.to(sample.dtype)], dim=1).unsqueeze(1)
+            curr_mask = torch.cat([torch.ones_like(sample).bool(), zeros_msk], dim=1).unsqueeze(1)
+            curr_pos = curr_pos[:, -1:] + 1
+        return len(samples)
+    loop(6)                                            # captures the graph
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = loop(n_frames)
+    torch.cuda.synchronize(); wall = time.perf_counter() - t0
+    # frame 0 is the prompt (prefill + depth): time the S = 1 frames alone as well
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    loop(1)
+    torch.cuda.synchronize(); first = time.perf_counter() - t0
+    del m
+    return {"workload": f"reference-style host loop (tts_service.py:224-241): generate_frame per frame, host EOS check each frame, B=1, S={S} prompt, {n} frames",
+            "frames": n, "ms_per_frame_after_the_prompt": round((wall - first) * 1e3 / max(n - 1, 1), 4), "prompt_frame_ms": round(first * 1e3, 2),
+            "rtf": round(80.0 / ((wall - first) * 1e3 / max(n - 1, 1)), 2)}
+
+
+def extras_legs(args, margs, sd, dev):
+    """BASELINE configs 3 and 5 and the long-context single-stream step, each a short run inside this same process so
+    the driver's one bench line carries them (`extras`).  Not part of `value`."""
+    from sesameai.models import Model
+    ex = {}
+    T, K = args.temperature, args.topk
+    # ---- config 3: B=32 x the config-2 prompt, hipGraph-captured frame step ----
+    ex["config3"], _ = batch32_leg(args, margs, sd, dev, args.extra_steps)
+    ex["reference_loop"] = reference_loop_leg(args, margs, sd, dev)
     # ---- long context, single stream, bf16: ms per frame at p ~ 1700 (the KV stream grows by 32 KB per position) ----
     tok, msk = synthetic_prompt(args, 1, margs.text_vocab_size, seed0=5000, segments=10, ctx_text=30, ctx_frames=100)
     S5 = tok.shape[1]
@@ -253,12 +314,28 @@ def extras_legs(args, margs, sd, dev):
                 first_ms = (time.perf_counter() - t0) * 1e3
         torch.cuda.synchronize()
         wall_ms = (time.perf_counter() - t0) * 1e3
-    lm_ms = timed_steps(m5, 1, 40, T, K) if m5.num_frames() + 40 < n5 + 16 else None
     ex["config5"] = {"workload": f"CSM-1B B=1, fp8-e4m3 weight stream, S={S5} prompt rows (10 segments), {n_fr} frames, stateful Mimi decode every 10 frames",
                      "wall_ms": round(wall_ms, 1), "first_chunk_ms": round(first_ms, 1), "frames": n_fr, "pcm_samples": pcm_n,
                      "end_to_end_rtf": round(n_fr * 80.0 / wall_ms, 2),
                      "roofline_frac_end_to_end": round(m5.bytes_per_frame(1, S5 + n_fr / 2.0) * n_fr / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     del gen, codec, m5
+    # ---- config 5 at B = 32: fp8 weight stream, 32 x the 1334-row prompt, frames timed at positions ~1340-1380 ----
+    B5 = 32
+    tokb, mskb = synthetic_prompt(args, B5, margs.text_vocab_size, seed0=6000, segments=10, ctx_text=30, ctx_frames=100)
+    mb = Model(margs, sd, device=str(dev), max_frames=64, max_prefill_rows=B5 * S5, weights_dtype="fp8")
+    mb.setup_caches(B5); mb.seed(80)
+    posb = torch.arange(S5).unsqueeze(0).repeat(B5, 1)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mb.reset_caches(); mb.prefill(tokb.to(dev), mskb.to(dev), posb.to(dev)); mb.depth(B5, T, K, commit=True)
+    torch.cuda.synchronize(); pre_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(5):
+        mb.step(B5, T, K)
+    ms = timed_steps(mb, B5, 30, T, K)
+    ex["config5_b32"] = {"workload": f"CSM-1B B={B5}, fp8-e4m3 weight stream, S={S5} prompt rows each, 30 frames timed at positions ~{S5 + 6}-{S5 + 36}",
+                         "ms_per_step": round(ms, 4), "frames_per_s": round(B5 * 1e3 / ms, 1), "rtf_aggregate": round(B5 * 1e3 / ms / 12.5, 1),
+                         "prefill_plus_frame0_ms": round(pre_ms, 1),
+                         "roofline_frac": round(mb.bytes_per_frame(B5, S5 + 20.0) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del mb
     return ex
 
 
@@ -296,8 +373,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-        sys.exit(2)
+        if args.gpus == 1:                        # under a launcher without --gpus: the launcher's world is the job
+            args.gpus = world
+        else:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+            sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     # BENCH_SHARE_GPU0=1 (debug only, never a valid measurement): every rank uses cuda:0 over gloo, which lets the
     # multi-rank control flow (weight broadcast, barriers, max-over-ranks timing) be exercised on a 1-GPU box
@@ -325,9 +405,13 @@ def main():
     margs = csm_tiny_args() if args.tiny else csm_1b_args()
     B = args.batch
     # ---- weights: rank 0 seeds them, the others receive one RCCL broadcast over xGMI --------
+    bcast = None
     if world > 1:
-        from sesameai.parallel import broadcast_state_dict
-        sd = broadcast_state_dict(margs, synthetic_state_dict(margs, seed=1234) if rank == 0 else None, dev)
+        from sesameai.parallel import broadcast_state_dict, broadcast_flat
+        stats = {}
+        sd = broadcast_state_dict(margs, synthetic_state_dict(margs, seed=1234) if rank == 0 else None, dev, stats=stats)
+        bcast = {"csm_bytes": stats["bytes"], "csm_ms": round(stats["ms"], 2), "csm_GBps": round(stats["bytes"] / stats["ms"] / 1e6, 1),
+                 "collective": "one flat-blob broadcast (torch.distributed, backend " + dist.get_backend() + ")"}
     else:
         sd = synthetic_state_dict(margs, seed=1234)
     model = Model(margs, sd, device=str(dev), max_frames=args.steps + args.warmup + 8,
@@ -384,7 +468,15 @@ def main():
     mimi = None
     if not args.tiny and not args.no_mimi:
         from sesameai.mimi import MimiArgs, MimiCodec
-        codec = MimiCodec(MimiArgs(), None, device=str(dev), max_frames=max(frames.shape[0], 16))
+        mimi_sd = None
+        if world > 1:                                  # rank 0 seeds the codec's weights too; one more flat broadcast
+            from sesameai.mimi import synthetic_state_dict as mimi_synthetic
+            from sesameai.parallel import broadcast_named
+            st_m = {}
+            mimi_sd = broadcast_named(mimi_synthetic(MimiArgs()) if rank == 0 else None, dev, stats=st_m,
+                                      template=None if rank == 0 else mimi_synthetic(MimiArgs()))
+            bcast.update({"mimi_bytes": st_m["bytes"], "mimi_ms": round(st_m["ms"], 2)})
+        codec = MimiCodec(MimiArgs(), mimi_sd, device=str(dev), max_frames=max(frames.shape[0], 16))
         codes = frames[:, 0, :].t().unsqueeze(0).contiguous().to(dev)          # (1, 32, T) of utterance 0
         T = codes.shape[2]
 
@@ -452,7 +544,7 @@ def main():
         traffic = pj.get("traffic_bytes_per_frame")
         traffic_src = {"file": os.path.relpath(pmcs[-1], ROOT), "kernels_commit": pj.get("kernels_commit"),
                        "note": "separate rocprofv3 --pmc FETCH_SIZE pass of this command (x2 gfx950 correction), not measured in this run"}
-    kernels = None if (args.tiny or args.weights != "bf16") else dominant_kernels(model, dev)
+    kernels = None if (args.tiny or args.weights != "bf16") else dominant_kernels(model, B, args.temperature, args.topk)
     out = {
         "metric": "audio frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -473,9 +565,22 @@ def main():
                      "streamed_GBps": round((bytes_frame + 30 * 2 * 111.15e6 + 30 * 2 * 2.1e6) / t_frame / 1e9, 1),
                      "dominant_kernels": kernels},
     }
+    if bcast is not None:
+        out["weight_broadcast"] = bcast
     if world == 1 and B == 1 and not args.tiny and not args.no_extras and args.weights == "bf16":
         del model
         out["extras"] = extras_legs(args, margs, sd, dev)
+    elif world > 1 and not args.tiny and not args.no_extras and args.weights == "bf16":
+        # ---- BASELINE config 4: B = 32 per GPU on every rank (batch 32 x N sharded over the N GPUs, no per-step collective);
+        #      aggregate = all ranks' frames / the slowest rank's time, like `value`
+        del model
+        res, wall4 = batch32_leg(args, margs, sd, dev, args.extra_steps, seed0=4000 + 32 * rank, barrier=sync_all)
+        t4 = torch.tensor([wall4], device=dev, dtype=torch.float64)
+        dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+        res["workload"] = f"CSM-1B batch {32 * world} sharded over {world} GPUs (B=32 per GPU), S=190 prompt rows each, hipGraph frame step, {args.extra_steps} timed steps"
+        res["aggregate_frames_per_s"] = round(world * 32 * args.extra_steps / float(t4.item()), 1)
+        res["slowest_rank_ms_per_step"] = round(float(t4.item()) * 1e3 / args.extra_steps, 4)
+        out["extras"] = {"config4": res}
     if rank == 0:
         # the oracle beside it, on this host's cores, after the timed region (the other ranks wait at the barrier below)
         out["cpu_baseline"] = cpu_baseline(args) if not (args.no_cpu_baseline or args.tiny) else None

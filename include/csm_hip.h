@@ -139,6 +139,26 @@ int csm_copy_frame(csm_handle h, int B, int32_t* out_frame, void* stream);
 int csm_set_step_inputs(csm_handle h, const int32_t* tokens, const uint8_t* mask, const int32_t* pos,
                         int B, void* stream);
 
+/* Per-slot reset and refill of a live batch (SURVEY.md 8b `csm_reset(handle, batch_slots, n)`; the reference is batch-1 and resets
+ * its one cache set per utterance, generator.py:255).  Utterances of a batch end at different frames (generator.py:285): a finished
+ * one is retired and its slot given to the next prompt while the other slots keep generating.
+ * csm_reset_slots: position 0 and "no EOS yet" for the listed slots (host array); their K/V need no clearing.
+ * csm_prefill_slot: the prompt rows tokens [S][33] / mask [S][33] / pos [S] (dev) run through the backbone into slot `slot`'s
+ * caches, the depth pass produces the new utterance's frame 0 (written to out_frame [32] dev if given, and into the history at the
+ * NEWEST global frame index, replacing that slot's entry there), and the frame is staged as the slot's input of the next
+ * csm_frame_step.  The other slots' state is untouched: their frames are bit-identical to an undisturbed run.  Call between
+ * frame steps, on the stream that runs them.  A batch may also be FILLED slot by slot this way after csm_reset (prompts of
+ * different lengths): the first call opens global frame 0.                                                                       */
+int csm_reset_slots(csm_handle h, const int32_t* slots /*host*/, int n, void* stream);
+int csm_prefill_slot(csm_handle h, int slot, const int32_t* tokens, const uint8_t* mask, const int32_t* pos, int S,
+                     int prompt_mode, float temperature, int topk, int32_t* out_frame, void* stream);
+
+/* Why there is no csm_broadcast_weights here (SURVEY.md 8b lists one): the multi-GPU layout is replicas with ONE start-up
+ * broadcast of a flat weight blob and no per-step collective.  The communicator that does it belongs to
+ * torch.distributed (backend "nccl" = RCCL over xGMI; sesameai/parallel.py), which owns the process's single RCCL instance; a
+ * second communicator created by this library from its own copy of librccl would duplicate the bootstrap and the xGMI rings for
+ * one collective that is not on the hot path.  The C ABI therefore takes device pointers that are already populated.            */
+
 /* History readback: frames [n][B][32] i32 into host memory (synchronises the stream);
  * eos_at[b] = index of the first all-zero frame of sequence b, or -1.                        */
 int csm_num_frames(csm_handle h);

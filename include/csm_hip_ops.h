@@ -54,6 +54,14 @@ int csm_op_sample(int B, int V, int ldl, const void* logits, float temperature, 
  * libcsm_hip_timeline.so (make -C sesameai-tts_amd/csrc timeline, loaded with CSM_HIP_TIMELINE=1).                      */
 int csm_debug_persist_stamps(csm_handle h, uint64_t* host, int n_words);
 
+/* Measurement hook of bench.py (roofline.dominant_kernels): times, on the handle's current state after at least one frame
+ * step, `reps` back-to-back launches of (a) the persistent depth-decoder launch for batch B -- csrc/dec_persist.cuh at B = 1,
+ * csrc/dec_persist_m.cuh at B = 2..32 -- and (b) a batch-1 backbone decode step (16 one-launch layers, csrc/bb_block.cuh),
+ * each between HIP events on `stream`.  out[0] = avg us per decoder launch (NaN if the launch chain is in charge),
+ * out[1] = weight bytes it streams per launch, out[2] = avg us per backbone layer launch (NaN unless B == 1 and the
+ * one-launch layer is active), out[3] = weight bytes of one backbone layer.  Clobbers the current frame's codes.          */
+int csm_debug_time_kernels(csm_handle h, int B, int reps, float temperature, int topk, double* out /*[4] host*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

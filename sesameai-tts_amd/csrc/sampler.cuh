@@ -433,19 +433,22 @@ struct AdvanceArgs {
     int pos_inc;          // 1 after a backbone step consumed cur_pos, 0 after a prefill
     int max_seq;          // backbone positions are [0, max_seq)
     int* overflow;        // device flag: a step ran at a position >= max_seq (csm_read_frames -> CSM_E_TOO_LONG)
+    const uint32_t *err0, *err1;   // optional give-up words of the all-CU launches: non-zero -> this frame's codes are invalid, recorded as -1
 };
 
 __global__ __launch_bounds__(256) void k_advance(const AdvanceArgs a) {
     __shared__ int nz[256];                         // per-sequence count of non-zero codes (B <= 256)
     const int n = *a.n_frames;
+    const bool bad = (a.err0 != nullptr && *a.err0 != 0u) || (a.err1 != nullptr && *a.err1 != 0u);
     for (int b = threadIdx.x; b < a.B; b += blockDim.x) nz[b] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < a.B * a.ncb; i += blockDim.x) {
         const int b = i / a.ncb, c = i % a.ncb;
-        const int v = a.frame[i];
+        const int v = bad ? -1 : a.frame[i];
+        if (bad) const_cast<int*>(a.frame)[i] = -1;          // csm_copy_frame / the next reader sees it too
         if (v != 0) atomicAdd(&nz[b], 1);
         if (n < a.max_frames) a.history[((long)n * a.bstride + b) * a.ncb + c] = v;
-        a.cur_tokens[b * (a.ncb + 1) + c] = a.fed ? a.fed[i] : v;
+        a.cur_tokens[b * (a.ncb + 1) + c] = a.fed ? a.fed[i] : (v < 0 ? 0 : v);
         a.cur_mask[b * (a.ncb + 1) + c] = 1;
         if (a.out_frame) a.out_frame[i] = v;
     }

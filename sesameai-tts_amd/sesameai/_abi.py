@@ -72,6 +72,8 @@ SIGNATURES = {
     "csm_frame_step": (_i, [_vp, _i, _f, _i, _i, _vp]),
     "csm_copy_frame": (_i, [_vp, _i, _vp, _vp]),
     "csm_set_step_inputs": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "csm_reset_slots": (_i, [_vp, _vp, _i, _vp]),
+    "csm_prefill_slot": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp]),
     "csm_num_frames": (_i, [_vp]),
     "csm_read_frames": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "csm_frames_dev": (_vp, [_vp]),
@@ -85,6 +87,7 @@ SIGNATURES = {
     "csm_op_embed_sum": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csm_op_sample": (_i, [_i, _i, _i, _vp, _f, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "csm_debug_persist_stamps": (_i, [_vp, _vp, _i]),
+    "csm_debug_time_kernels": (_i, [_vp, _i, _i, _f, _i, _vp, _vp]),
 }
 
 # include/mimi_hip.h (bound when the symbols are present; tests/test_abi.py requires them)

@@ -8,6 +8,10 @@ EOS flag every few frames instead of synchronising on every frame (generator.py:
 from __future__ import annotations
 
 import os
+import queue
+import struct
+import threading
+import time
 from dataclasses import dataclass
 from typing import Callable, Generator as PyGenerator, List, Optional, Sequence, Tuple, Union
 
@@ -54,6 +58,7 @@ class Generator:
     def __init__(self, model: Model, audio_tokenizer=None, text_tokenizer=None, max_batch_size: int = 1):
         self._model = model
         self._model.setup_caches(max_batch_size)
+        self._max_batch = max_batch_size
         self._text_tokenizer = text_tokenizer if text_tokenizer is not None else load_llama3_tokenizer()
         self._audio_tokenizer = audio_tokenizer
         self.sample_rate = getattr(audio_tokenizer, "sample_rate", 24_000)
@@ -167,6 +172,82 @@ class Generator:
             blocks.append(fr)
         return torch.cat(blocks) if blocks else torch.empty(0, B, 32, dtype=torch.int32)
 
+    @torch.inference_mode()
+    def generate_codes_continuous(self, prompts: Sequence[Tuple[torch.Tensor, torch.Tensor]], max_generation_len: int,
+                                  temperature: float, topk: int, poll: Optional[int] = None) -> List[torch.Tensor]:
+        """Any number of prompts [(tokens (S_i,33), mask (S_i,33)), ...] of any lengths through a batch of ``max_batch_size``
+        slots that is kept FULL: an utterance that reaches its all-zero EOS frame (generator.py:285) or the length limit is
+        retired and its slot re-prefilled with the next prompt (Model.refill_slot) while the other slots keep generating --
+        their frames are bit-identical to an undisturbed run.  Returns each prompt's frames [n_i][32] int32 (CPU), cut at its
+        EOS like the reference's batch-1 loop."""
+        from collections import deque
+        m = self._model
+        for t, _ in prompts:
+            if t.shape[0] >= MAX_SEQ_LEN - max_generation_len:
+                raise ValueError(f"Inputs too long, must be below max_seq_len - max_generation_len: {MAX_SEQ_LEN - max_generation_len}")
+        results: List[Optional[torch.Tensor]] = [None] * len(prompts)
+        if not prompts:
+            return []
+        poll = poll or self._eos_poll
+        B = min(self._max_batch, len(prompts))
+        pending = deque(range(len(prompts)))
+        slot_idx: List[Optional[int]] = [None] * B
+        slot_frames: List[List[torch.Tensor]] = [[] for _ in range(B)]
+        empty = torch.empty(0, 32, dtype=torch.int32)
+        m.reset_caches()
+
+        def start(slot: int) -> bool:
+            while pending:
+                i = pending.popleft()
+                t, mk = prompts[i]
+                f0 = m.refill_slot(slot, t, mk, temperature, topk).cpu()
+                if max_generation_len <= 0 or bool((f0 == 0).all()):
+                    results[i] = empty                                  # EOS in the very first frame: empty utterance (generator.py:296)
+                    continue
+                slot_idx[slot], slot_frames[slot] = i, [f0]
+                return True
+            slot_idx[slot] = None
+            return False
+
+        for s_ in range(B):
+            start(s_)
+        g = m.num_frames()                                              # next global frame index
+        while any(i is not None for i in slot_idx):
+            active = [s_ for s_ in range(B) if slot_idx[s_] is not None]
+            done = [s_ for s_ in active if len(slot_frames[s_]) >= max_generation_len]
+            if not done:
+                n = min(poll, min(max_generation_len - len(slot_frames[s_]) for s_ in active))
+                for _ in range(n):
+                    m.step(B, temperature, topk)
+                fr, eos = m.read_frames(B, g, n)
+                for s_ in active:
+                    rows = fr[:, s_]
+                    if int(eos[s_]) >= 0:
+                        rows = rows[: max(int(eos[s_]) - g, 0)]
+                        done.append(s_)
+                    slot_frames[s_].extend(rows.unbind(0))
+                    if len(slot_frames[s_]) >= max_generation_len and s_ not in done:
+                        done.append(s_)
+                g += n
+            idle = []
+            for s_ in done:
+                results[slot_idx[s_]] = torch.stack(slot_frames[s_][:max_generation_len]).to(torch.int32)
+                if not start(s_):
+                    idle.append(s_)
+            if idle and any(i is not None for i in slot_idx):
+                m.reset_slots(idle)                                      # a retired slot keeps stepping: keep its position away from max_seq
+        return [r if r is not None else empty for r in results]
+
+    def generate_many(self, texts: Sequence, speakers: Sequence[int], contexts: Sequence[List[Segment]], max_audio_length_ms: float = 90_000,
+                      temperature: float = 0.7, topk: int = 30) -> List[torch.Tensor]:
+        """``generate`` for a list of requests through the continuously refilled batch: one audio tensor per request."""
+        max_generation_len = int(max_audio_length_ms / FRAME_MS)
+        prompts = [self._build_prompt(t, sp, ctx) for t, sp, ctx in zip(texts, speakers, contexts)]
+        out = []
+        for frames in self.generate_codes_continuous(prompts, max_generation_len, temperature, topk):
+            out.append(self._decode_frames(frames.unsqueeze(1)) if frames.shape[0] else torch.tensor([]))
+        return out
+
     def _decode_frames(self, frames: torch.Tensor) -> torch.Tensor:
         """frames [n][1][32] -> audio (n*1920,) (reference: _decode_frames, generator.py:111-117)."""
         if frames.shape[0] == 0:
@@ -238,6 +319,85 @@ class Generator:
         if frames.shape[0] == 0:
             return torch.tensor([])
         return self._decode_frames(frames)
+
+
+def save_wav_float32(filename: str, audio: torch.Tensor, sample_rate: int) -> None:
+    """(n,) float samples -> mono 32-bit IEEE-float WAV: what ``torchaudio.save(filename, audio.unsqueeze(0), sr)`` writes for a
+    float32 tensor (reference: generator.py:327); torchaudio is not a dependency here, the 44-byte header is written by hand."""
+    pcm = audio.detach().to(torch.float32).reshape(-1).cpu().contiguous().numpy().astype("<f4", copy=False).tobytes()
+    with open(filename, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 3, 1, sample_rate, sample_rate * 4, 4, 32))      # format 3 = IEEE float, mono
+        f.write(b"data" + struct.pack("<I", len(pcm)) + pcm)
+
+
+class AudioStreamWriter:
+    """reference: sesameai/generator.py:303-327 -- collects the chunks of a streaming generation (thread-safe: the
+    reference's player thread and the generator share it) and writes them as one file."""
+
+    def __init__(self, filename, sample_rate):
+        self.filename = filename
+        self.sample_rate = sample_rate
+        self.audio_chunks: List[torch.Tensor] = []
+        self.lock = threading.Lock()
+
+    def add_chunk(self, chunk):
+        with self.lock:
+            self.audio_chunks.append(chunk)
+
+    def write_file(self):
+        with self.lock:
+            if not self.audio_chunks:
+                return
+            save_wav_float32(self.filename, torch.cat([c.reshape(-1).cpu() for c in self.audio_chunks]), self.sample_rate)
+
+
+def generate_streaming_audio(generator: "Generator", text, speaker: int, context: List[Segment], output_file: str,
+                             max_audio_length_ms: float = 90_000, temperature: float = 0.7, topk: int = 30,
+                             play_audio: bool = False):
+    """reference: sesameai/generator.py:349-434 -- ``generate_stream`` with every chunk collected into ``output_file`` and,
+    with ``play_audio``, played as it arrives (``sounddevice`` on a player thread; without that package playback is switched
+    off with the reference's message and the file is still written)."""
+    writer = AudioStreamWriter(output_file, generator.sample_rate)
+    audio_queue: "queue.Queue[torch.Tensor]" = queue.Queue()
+    stop_event = threading.Event()
+    player_thread = None
+    if play_audio:
+        try:
+            import sounddevice as sd
+
+            def audio_player():
+                while not stop_event.is_set() or not audio_queue.empty():
+                    try:
+                        chunk = audio_queue.get(timeout=0.5)
+                        sd.play(chunk.cpu().numpy(), generator.sample_rate)
+                        sd.wait()
+                    except queue.Empty:
+                        continue
+
+            player_thread = threading.Thread(target=audio_player)
+            player_thread.start()
+        except ImportError:
+            print("sounddevice library not found. Install with 'pip install sounddevice' to enable real-time playback.")
+            play_audio = False
+
+    def on_chunk_generated(chunk):
+        writer.add_chunk(chunk)
+        if play_audio:
+            audio_queue.put(chunk)
+
+    print("Generating audio in streaming mode...")
+    start_time = time.time()
+    chunk_count = 0
+    for _ in generator.generate_stream(text=text, speaker=speaker, context=context, max_audio_length_ms=max_audio_length_ms,
+                                       temperature=temperature, topk=topk, on_chunk_generated=on_chunk_generated):
+        chunk_count += 1
+        print(f"Generated chunk {chunk_count}")
+    writer.write_file()
+    if player_thread is not None:
+        stop_event.set()
+        player_thread.join()
+    print(f"Audio generation completed in {time.time() - start_time:.2f} seconds")
 
 
 def load_csm_1b(device: str = "cuda", model_path: Optional[str] = None, mimi_path: Optional[str] = None,

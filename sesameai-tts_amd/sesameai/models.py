@@ -407,6 +407,31 @@ class Model:
         self.last_prefill_rows = s - start
         return s - start
 
+    def reset_slots(self, slots) -> None:
+        """Position 0 and "no EOS yet" for the listed batch slots; the other slots are untouched (csm_reset_slots)."""
+        self._require()
+        arr = (C.c_int32 * len(slots))(*[int(s) for s in slots])
+        with self._on_device():
+            check(lib.csm_reset_slots(self._h, arr, len(slots), _stream_ptr()), self._h)
+
+    def refill_slot(self, slot: int, tokens: torch.Tensor, tokens_mask: torch.Tensor, temperature: float, topk: int) -> torch.Tensor:
+        """A new prompt (S,33) starting at position 0 into batch slot ``slot`` of a live batch: backbone prefill into the slot's
+        caches, depth pass, the new utterance's frame 0 staged as the slot's next input.  Returns frame 0 (32,) int32 on the
+        device.  The other slots keep generating undisturbed (bit-identical frames); see include/csm_hip.h csm_prefill_slot."""
+        self._require()
+        s = tokens.shape[0]
+        if s >= self.bb.max_seq_len or s > max(self._max_prefill_rows, 2 * self._max_batch):
+            raise ValueError(f"prompt of {s} rows exceeds the limits (max_seq_len {self.bb.max_seq_len}, max_prefill_rows {self._max_prefill_rows})")
+        self._kv_prompt = None                                   # slot 0's cached prompt prefix no longer describes the caches
+        t = tokens.to(device=self.device, dtype=torch.int32).contiguous()
+        m = tokens_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        p = torch.arange(s, device=self.device, dtype=torch.int32)
+        out = torch.empty(self.config.audio_num_codebooks, dtype=torch.int32, device=self.device)
+        with self._on_device():
+            check(lib.csm_prefill_slot(self._h, int(slot), t.data_ptr(), m.data_ptr(), p.data_ptr(), s, 1, float(temperature), int(topk),
+                                       out.data_ptr(), _stream_ptr()), self._h)
+        return out
+
     def depth(self, batch: int, temperature: float, topk: int, *, forced: Optional[torch.Tensor] = None,
               noise: Optional[torch.Tensor] = None, want_logits: bool = False, commit: bool = True):
         """c0 head + 31 decoder steps on the current backbone state -> (B,32) int32 [, logits]."""

@@ -50,3 +50,47 @@ def test_bench_self_launches_its_ranks_when_no_launcher_is_present():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "replicas x2" and "cpu_baseline" in d
     assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) / d["value"] < 0.02      # two replicas' frames / max-over-ranks time
+    wb = d["weight_broadcast"]
+    assert wb["csm_bytes"] > 0 and wb["csm_ms"] > 0 and wb["csm_GBps"] > 0
+
+
+def test_two_full_size_ranks_carry_the_config4_leg_and_honest_kernel_entries():
+    """The N > 1 line at CSM-1B size (two ranks sharing this box's one GPU over gloo -- control flow only, never a
+    measurement): `extras.config4` = B = 32 per rank with the aggregate over the slowest rank's time, the weight broadcast's
+    size / time / rate for both blobs (CSM and the codec), and `roofline.dominant_kernels` naming launches that are on the
+    timed path (none in this debug mode: the all-CU launches are off when ranks share a GPU)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_SHARE_GPU0"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--extra-steps", "3",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    c4 = d["extras"]["config4"]
+    assert "batch 64 sharded over 2 GPUs" in c4["workload"]
+    assert abs(c4["aggregate_frames_per_s"] - 2 * 32 * 1000.0 / c4["slowest_rank_ms_per_step"]) / c4["aggregate_frames_per_s"] < 0.02
+    wb = d["weight_broadcast"]
+    assert wb["csm_bytes"] > 3e9 and wb["mimi_bytes"] > 1e8 and wb["csm_ms"] > 0 and wb["mimi_ms"] > 0
+    assert isinstance(d["roofline"]["dominant_kernels"], list)
+
+
+def test_single_gpu_line_names_the_kernels_it_timed():
+    """N = 1, CSM-1B: `roofline.dominant_kernels` must be the launches of the timed frame step -- the persistent depth decoder and
+    the one-launch backbone layer -- timed live in the run, and `extras` must carry config 3 (with ITS kernel), the
+    reference-style host loop, the long-context step, config 5 and config 5 at B = 32."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--extra-steps", "6", "--no-cpu-baseline", "--no-mimi"],
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    names = [k["kernel"] for k in d["roofline"]["dominant_kernels"]]
+    assert names == ["k_dec_persist", "k_bb_layer"], names
+    dk = d["roofline"]["dominant_kernels"]
+    assert 16 * dk[1]["avg_us"] * 1e-3 + dk[0]["avg_us"] * 1e-3 < d["ms_per_step"], "the dominant kernels take longer than the frame they are part of"
+    ex = d["extras"]
+    for k in ("config3", "reference_loop", "b1_long_context", "config5", "config5_b32"):
+        assert k in ex, k
+    assert ex["config3"]["dominant_kernels"][0]["kernel"] == "k_dec_persist_m<2>"
+    assert ex["reference_loop"]["ms_per_frame_after_the_prompt"] > d["ms_per_step"] * 0.9

@@ -681,6 +681,81 @@ def test_zeroed_heads_stop_at_the_prompt_frame_and_generate_returns_empty_audio(
     assert list(gen.generate_stream([3, 4, 5, 6], 0, [], max_audio_length_ms=800, temperature=1.0, topk=1)) == []
 
 
+def _tiny_prompt(rows, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.zeros(rows, 33, dtype=torch.long); m = torch.zeros(rows, 33, dtype=torch.bool)
+    n_text = rows // 3
+    t[:n_text, 32] = torch.randint(0, 1000, (n_text,), generator=g); m[:n_text, 32] = True
+    t[n_text:, :32] = torch.randint(0, 2048, (rows - n_text, 32), generator=g); m[n_text:, :32] = True
+    return t, m
+
+
+def test_slot_refill_leaves_the_other_slots_bit_identical(tiny):
+    """csm_prefill_slot (include/csm_hip.h; SURVEY.md 8b per-slot reset): B = 3 under greedy sampling; after 4 frames slot 1 is
+    retired and re-prefilled with a NEW prompt of a different length while slots 0 and 2 keep generating.  Slots 0 and 2 must
+    produce bit for bit the frames of an undisturbed run; the new utterance in slot 1 must produce bit for bit what it produces
+    when it sits in slot 1 from the start (rows do not depend on their neighbours or on the global frame index)."""
+    shape, w, m = tiny
+    B, S = 3, 12
+    pr = [_tiny_prompt(S, 50 + b) for b in range(B)]
+    new_t, new_m = _tiny_prompt(9, 99)
+    tok, msk = torch.stack([p[0] for p in pr]), torch.stack([p[1] for p in pr])
+
+    def run(refill_at):
+        m.reset_caches(); m.seed(11)
+        m.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+        m.depth(B, 1.0, 1, commit=True)
+        f0 = None
+        for k in range(1, 10):
+            if k == refill_at:
+                f0 = m.refill_slot(1, new_t, new_m, 1.0, 1).cpu()
+            m.step(B, 1.0, 1)
+        frames, eos = m.read_frames(B)
+        return frames, f0
+
+    und, _ = run(None)
+    dis, f0 = run(4)
+    assert und.shape == dis.shape == (10, B, 32)
+    assert torch.equal(dis[:, 0], und[:, 0]) and torch.equal(dis[:, 2], und[:, 2]), "the refill disturbed a neighbouring slot"
+    assert torch.equal(dis[:3, 1], und[:3, 1]) and torch.equal(dis[3, 1], f0), "history: the new utterance's frame 0 replaces the slot's newest entry"
+    assert not torch.equal(dis[4:, 1], und[4:, 1])
+    # the new utterance from the start of a batch that is filled slot by slot (prompts of different lengths)
+    m.reset_caches(); m.seed(11)
+    firsts = [m.refill_slot(b, *(pr[b] if b != 1 else (new_t, new_m)), 1.0, 1).cpu() for b in range(B)]
+    assert m.num_frames() == 1
+    for _ in range(6):
+        m.step(B, 1.0, 1)
+    ref, eos = m.read_frames(B)
+    assert torch.equal(ref[0], torch.stack(firsts))
+    assert torch.equal(firsts[1], f0) and torch.equal(ref[1:, 1], dis[4:, 1]), "the refilled utterance differs from the same utterance started with the batch"
+    assert torch.equal(ref[:, 0], und[:7, 0]), "slot-by-slot fill differs from the rectangular prefill of the same prompts"
+    m.reset_slots([1])
+    m.reset_caches()
+
+
+def test_continuous_batching_through_the_generator_matches_one_utterance_at_a_time(tiny):
+    """Generator.generate_codes_continuous on the device: 5 prompts of different lengths through 2 slots, 6 frames each (greedy;
+    random weights never emit the EOS frame, so utterances retire at the length limit) -- every utterance must equal the one the
+    same prompt produces when it is the only one refilled into slot 0 of the same 2-slot batch."""
+    from sesameai.generator import Generator
+    shape, w, m = tiny
+    gen = Generator.__new__(Generator)
+    gen._model, gen._max_batch, gen._eos_poll, gen.device = m, 2, 4, m.device
+    prompts = [_tiny_prompt(6 + 3 * i, 200 + i) for i in range(5)]
+    got = gen.generate_codes_continuous(prompts, 6, 1.0, 1)
+    idle = _tiny_prompt(5, 7)
+    for i, (t, mk) in enumerate(prompts):
+        m.reset_caches()
+        f0 = m.refill_slot(0, t, mk, 1.0, 1).cpu()
+        m.refill_slot(1, *idle, 1.0, 1)
+        for _ in range(5):
+            m.step(2, 1.0, 1)
+        fr, _ = m.read_frames(2)
+        want = torch.cat([f0.unsqueeze(0), fr[1:, 0]])
+        assert got[i].shape == (6, 32) and torch.equal(got[i], want), f"utterance {i}"
+    m.reset_caches()
+
+
 def test_positions_beyond_max_seq_are_reported_not_clamped(tiny):
     """ADVICE r1: pos >= max_seq used to be clamped silently inside the kernels.  Host-visible positions raise at once;
     positions that only exist on the device raise CSM_E_TOO_LONG at the next read_frames."""
@@ -1033,21 +1108,29 @@ def run():
     for _ in range(3): m.step(1, 0.9, 50)
     return m.read_frames(1)[0].clone()
 t0 = time.perf_counter()
+# the reference-style loop never calls read_frames: the frame it copies out (generate_frame -> csm_copy_frame) must say so itself
+m.reset_caches(); m.seed(3)
+m.prefill(tok, msk, torch.arange(S).unsqueeze(0))
+first = m.depth(1, 0.9, 50, commit=True)
+row = torch.zeros(1, 1, 33, dtype=torch.long); row[0, 0, :32] = first[0].clamp(min=0).long().cpu()
+rmask = torch.ones(1, 1, 33, dtype=torch.bool); rmask[0, 0, 32] = False
+nxt = m.generate_frame(row, rmask, torch.tensor([[S]]), 0.9, 50)
+print("FRAME_MARKED_INVALID" if int(first.min()) == -1 or int(nxt.min()) == -1 else "FRAME_NOT_MARKED", first[0, :4].tolist(), nxt[0, :4].tolist())
 try:
-    run(); torch.cuda.synchronize()
+    m.read_frames(1); torch.cuda.synchronize()
     print("NO_ERROR")
 except RuntimeError as e:
     print("ERROR_OK" if "gave up" in str(e) else "OTHER_ERROR " + str(e), f"{time.perf_counter() - t0:.2f}s")
 a = run(); b = run()
-print("RECOVERED" if torch.equal(a, b) and int(a.abs().sum()) > 0 else "NOT_RECOVERED")
+print("RECOVERED" if torch.equal(a, b) and int(a.min()) >= 0 and int(a.abs().sum()) > 0 else "NOT_RECOVERED")
 """
 
 
 def test_persistent_launch_gives_up_instead_of_hanging_and_the_handle_recovers(tmp_path):
     """Every spin of the persistent launch is bounded: with one hand-off granule withheld (fault injection of the
     timeline build, CSM_PERSIST_FAULT) the launch must END within its 50 ms budget, read_frames must report it
-    (CSM_E_HIP, "gave up"), and after reset_caches the same handle must generate again (the tag epoch moves past
-    whatever the aborted launch left in the granule buffers)."""
+    (CSM_E_HIP, "gave up"), every host-visible copy of the invalid frame must carry -1 (the reference-style loop reads frames
+    through generate_frame and never calls read_frames), and after reset_caches the same handle must generate again."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1056,10 +1139,18 @@ def test_persistent_launch_gives_up_instead_of_hanging_and_the_handle_recovers(t
         pytest.skip("libcsm_hip_timeline.so not built (make -C sesameai-tts_amd/csrc timeline)")
     script = tmp_path / "fault.py"
     script.write_text(_FAULT_SCRIPT)
-    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=240)
-    out = r.stdout
-    assert "ERROR_OK" in out, f"the faulted launch was not reported:\n{out}\n{r.stderr[-2000:]}"
-    assert "RECOVERED" in out and "NOT_RECOVERED" not in out, f"the handle did not recover:\n{out}\n{r.stderr[-2000:]}"
+    # default: after a give-up the handle falls back to the launch chain; CSM_KEEP_FAST_PATHS=1: the persistent launch itself must
+    # work again after reset_caches (the tag epoch moves past whatever the aborted launch left in the granule buffers)
+    for keep in ("0", "1"):
+        env = dict(os.environ)
+        env.pop("CSM_KEEP_FAST_PATHS", None)
+        if keep == "1":
+            env["CSM_KEEP_FAST_PATHS"] = "1"
+        r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=240, env=env)
+        out = r.stdout
+        assert "FRAME_MARKED_INVALID" in out, f"keep={keep}: generate_frame returned codes of a launch that gave up without marking them (-1):\n{out}\n{r.stderr[-2000:]}"
+        assert "ERROR_OK" in out, f"keep={keep}: the faulted launch was not reported:\n{out}\n{r.stderr[-2000:]}"
+        assert "RECOVERED" in out and "NOT_RECOVERED" not in out, f"keep={keep}: the handle did not recover:\n{out}\n{r.stderr[-2000:]}"
 
 
 def test_backbone_attention_block_vs_launch_chain(csm1b, monkeypatch):

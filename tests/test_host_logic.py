@@ -111,9 +111,15 @@ from sesameai.models import csm_tiny_args, synthetic_state_dict
 args = csm_tiny_args()
 rank = dist.get_rank()
 sd = synthetic_state_dict(args, seed=1234) if rank == 0 else None
-got = par.broadcast_state_dict(args, sd, torch.device("cpu"))
+stats = {}
+got = par.broadcast_state_dict(args, sd, torch.device("cpu"), stats=stats)
 ref = synthetic_state_dict(args, seed=1234)
-ok = all(torch.equal(got[k], ref[k]) for k in ref)
+ok = all(torch.equal(got[k], ref[k]) for k in ref) and stats["bytes"] > 0 and stats["ms"] > 0
+# a second blob whose names / shapes every rank knows (the codec's weights in bench.py): values come from rank 0 only
+named = {"a.w": torch.arange(70, dtype=torch.float32).view(7, 10), "b": torch.full((3,), 2.5)}
+tmpl = {k: torch.zeros_like(v) for k, v in named.items()}
+got2 = par.broadcast_named(named if rank == 0 else None, torch.device("cpu"), template=None if rank == 0 else tmpl)
+ok = ok and all(torch.equal(got2[k], named[k]) for k in named)
 sh = [list(par.shard_utterances(10, 4, r)) for r in range(4)]
 ok = ok and sum(sh, []) == list(range(10)) and sh[0] == [0, 1, 2]
 dist.barrier(); dist.destroy_process_group()
@@ -331,6 +337,155 @@ def test_generator_runs_to_the_length_limit_without_eos_and_streams_the_same_fra
     gen = Generator(_ScriptedModel(_scripted(64, 1, [0])), audio_tokenizer=_FakeCodec())
     assert gen.generate([1, 2, 3], 0, [], max_audio_length_ms=40 * 80).numel() == 0
     assert list(gen.generate_stream([1, 2, 3], 0, [], max_audio_length_ms=40 * 80)) == []
+
+
+class _ScriptedSlots:
+    """Stands in for sesameai.models.Model under Generator.generate_codes_continuous: every prompt (identified by its first text
+    token) has a scripted utterance; slots emit their utterance's next frame per step, all-zero frames once it is over, and the
+    EOS word of a slot is the GLOBAL index of its first all-zero frame since its last refill -- the contract of csm_prefill_slot /
+    k_advance (include/csm_hip.h)."""
+
+    def __init__(self, scripts, max_batch):
+        self.scripts, self.device, self._max_batch = scripts, torch.device("cpu"), max_batch
+        self.refills, self.resets = [], []
+
+    def setup_caches(self, b): pass
+
+    def reset_caches(self):
+        self.hist, self.slot, self.eos = [], {}, {}
+
+    def num_frames(self): return max(len(self.hist), 1) if self.slot else 0
+
+    def refill_slot(self, slot, tokens, mask, T, k):
+        pid = int(tokens[0, 32])
+        self.refills.append((slot, pid, self.num_frames()))
+        self.slot[slot] = [pid, 1]
+        f0 = self.scripts[pid][0].to(torch.int32)
+        if not self.hist:
+            self.hist.append({})
+        self.hist[-1][slot] = f0
+        self.eos[slot] = len(self.hist) - 1 if bool((f0 == 0).all()) else -1
+        return f0
+
+    def reset_slots(self, slots): self.resets.append(list(slots))
+
+    def step(self, B, T, k, use_graph=True):
+        row = {}
+        for s_ in range(B):
+            pid, cur = self.slot[s_]
+            sc = self.scripts[pid]
+            f = sc[cur].to(torch.int32) if cur < sc.shape[0] else torch.zeros(32, dtype=torch.int32)
+            self.slot[s_][1] = cur + 1
+            row[s_] = f
+            if self.eos[s_] < 0 and bool((f == 0).all()):
+                self.eos[s_] = len(self.hist)
+        self.hist.append(row)
+
+    def read_frames(self, B, first=0, n=None):
+        fr = torch.stack([torch.stack([self.hist[g][s_] for s_ in range(B)]) for g in range(first, first + n)]) if n else torch.empty(0, B, 32, dtype=torch.int32)
+        return fr, torch.tensor([self.eos[s_] for s_ in range(B)], dtype=torch.int32)
+
+
+def test_continuous_batching_retires_at_eos_and_refills_the_slot():
+    """7 utterances of different lengths (EOS after 0, 3, 5, 11, 17 frames, one that runs into the length limit, one that ends
+    exactly on a poll boundary) through 3 slots: every utterance comes back complete, cut at ITS all-zero frame like the
+    reference's batch-1 loop (generator.py:285), in prompt order; slots are refilled as they free up and retired slots that
+    have nothing left to do are rewound."""
+    from sesameai.generator import Generator
+    g = torch.Generator().manual_seed(3)
+    lens = [3, 17, 0, 5, 40, 11, 8]
+    scripts = []
+    for n in lens:
+        sc = torch.randint(1, 2048, (n + 1, 32), generator=g)
+        sc[n] = 0                                               # the all-zero EOS frame
+        scripts.append(sc)
+    model = _ScriptedSlots(scripts, 3)
+    gen = Generator(model, audio_tokenizer=_FakeCodec(), max_batch_size=3)
+    prompts = []
+    for i in range(len(lens)):
+        t = torch.zeros(4 + i, 33, dtype=torch.long); t[:, 32] = i
+        prompts.append((t, torch.zeros(4 + i, 33, dtype=torch.bool)))
+    out = gen.generate_codes_continuous(prompts, 25, 0.9, 50)
+    assert len(out) == len(lens)
+    for i, n in enumerate(lens):
+        want = scripts[i][: min(n, 25)].to(torch.int32)
+        assert out[i].shape == want.shape and torch.equal(out[i], want), f"utterance {i} (length {n})"
+    assert sorted(pid for _, pid, _ in model.refills) == list(range(len(lens)))          # every prompt was started exactly once
+    assert len({slot for slot, _, _ in model.refills}) == 3 and model.resets                # three slots in use; idle ones rewound
+    with pytest.raises(ValueError):
+        gen.generate_codes_continuous([(torch.zeros(2030, 33, dtype=torch.long), torch.zeros(2030, 33, dtype=torch.bool))], 25, 0.9, 50)
+
+
+def test_rope_table_fp32_tensor_form_vs_the_double_form_over_the_positions_each_stack_reads():
+    """torchtune 0.4.0's ``Llama3ScaledRoPE.apply_scaling`` iterates over the elements of an fp32 TENSOR (``for freq in freqs``:
+    wavelength, smoothing and the scaled frequency are 0-dim fp32 tensor arithmetic); the oracle (oracle/csm_ref.py:158-175)
+    and the product (sesameai/models.py llama3_rope_table) iterate over Python doubles.  Both end as the bf16 table the
+    model rounds at ``model.to(bf16)`` (generator.py:343).  The two forms must give the same bf16 table wherever a stack reads
+    it: every one of the backbone's 2048 positions (head_dim 64) and the depth decoder's 32 positions (head_dim 128).  Beyond
+    those, the head_dim-128 table may differ in a handful of entries (one bf16 ulp, positions the 32-position decoder never
+    reaches); the count is printed, not hidden."""
+    import math
+    from oracle import csm_ref as C
+    from sesameai.models import FLAVORS, llama3_rope_table
+
+    def torchtune_form(head_dim, base=500_000.0, scale_factor=32.0, low=1.0, high=4.0, old_len=8192, max_seq=2048):
+        freqs = 1.0 / (base ** (torch.arange(0, head_dim, 2)[: head_dim // 2].float() / head_dim))
+        low_wl, high_wl = old_len / low, old_len / high
+        new = []
+        for freq in freqs:                                        # 0-dim fp32 tensors, as in torchtune
+            wavelen = 2 * math.pi / freq
+            if wavelen < high_wl:
+                new.append(freq)
+            elif wavelen > low_wl:
+                new.append(freq / scale_factor)
+            else:
+                smooth = (old_len / wavelen - low) / (high - low)
+                new.append((1 - smooth) * freq / scale_factor + smooth * freq)
+        theta = torch.tensor(new, dtype=freqs.dtype)
+        idx = torch.einsum("i, j -> ij", torch.arange(max_seq, dtype=theta.dtype), theta).float()
+        return torch.stack([torch.cos(idx), torch.sin(idx)], dim=-1).to(torch.bfloat16)
+
+    for flavor, shape, reads in (("llama-1B", C.csm_1b().backbone, 2048), ("llama-100M", C.csm_1b().decoder, 32)):
+        tt = torchtune_form(FLAVORS[flavor].head_dim)
+        oracle = C.rope_table(shape)
+        product = llama3_rope_table(FLAVORS[flavor])
+        assert torch.equal(oracle, product), f"{flavor}: oracle and product tables differ"
+        diff = (tt.view(torch.int16) != oracle.view(torch.int16))
+        n_all = int(diff.sum())
+        first_pos = int(diff.any(dim=2).any(dim=1).nonzero()[0]) if n_all else None
+        print(f"{flavor} (head_dim {FLAVORS[flavor].head_dim}): {n_all} of {diff.numel()} table entries differ between the fp32-tensor and the double form"
+              + (f", first at position {first_pos}" if n_all else "") + f"; the stack reads positions 0..{reads - 1}")
+        assert not bool(diff[:reads].any()), f"{flavor}: the two forms differ inside the positions the stack reads"
+        assert n_all <= 8
+
+
+def test_generate_streaming_audio_writes_every_chunk_to_one_file(tmp_path, capsys):
+    """reference: generate_streaming_audio / AudioStreamWriter (sesameai/generator.py:303-327,349-434): every streamed chunk is
+    handed to the writer as it is produced, the file holds all of them in order (mono float32 WAV, what torchaudio.save
+    writes for a float tensor), playback without `sounddevice` is switched off with the reference's message."""
+    import struct
+    import numpy as np
+    from sesameai.generator import AudioStreamWriter, Generator, generate_streaming_audio
+    script = _scripted(64, 1, [23])
+    gen = Generator(_ScriptedModel(script), audio_tokenizer=_FakeCodec())
+    out = str(tmp_path / "stream.wav")
+    generate_streaming_audio(gen, [1, 2, 3], 0, [], out, max_audio_length_ms=40 * 80, play_audio=True)
+    printed = capsys.readouterr().out
+    assert "Generated chunk 3" in printed and "Generated chunk 4" not in printed and "Audio generation completed" in printed
+    try:
+        import sounddevice  # noqa: F401
+    except ImportError:
+        assert "sounddevice library not found" in printed
+    raw = open(out, "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:16] == b"WAVEfmt "
+    fmt, ch, sr, _, _, bits = struct.unpack("<HHIIHH", raw[20:36])
+    assert (fmt, ch, sr, bits) == (3, 1, 24_000, 32)
+    pcm = np.frombuffer(raw[44:], dtype="<f4")
+    assert pcm.shape[0] == 23 * 1920 and np.array_equal(pcm[::1920], script[:23, 0, 0].float().numpy())
+    # the writer alone: thread-safe appends, nothing written when nothing was generated
+    w = AudioStreamWriter(str(tmp_path / "empty.wav"), 24_000)
+    w.write_file()
+    assert not (tmp_path / "empty.wav").exists()
 
 
 def test_generator_batch_stops_when_every_sequence_has_hit_eos():
