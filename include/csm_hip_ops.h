@@ -54,6 +54,11 @@ int csm_op_sample(int B, int V, int ldl, const void* logits, float temperature, 
  * libcsm_hip_timeline.so (make -C sesameai-tts_amd/csrc timeline, loaded with CSM_HIP_TIMELINE=1).                      */
 int csm_debug_persist_stamps(csm_handle h, uint64_t* host, int n_words);
 
+/* Which optional all-CU launches the handle runs (so a test can assert the path it means to cover): bit 0 persistent depth decoder
+ * (B = 1), bit 1 batched persistent depth decoder (B = 2..32), bit 2 backbone attention block, bit 3 one-launch backbone layer
+ * (bf16 stream), bit 4 one-launch backbone layer (e4m3 stream, fp8 mode).                                                        */
+int csm_debug_fast_paths(csm_handle h);
+
 /* Measurement hook of bench.py (roofline.dominant_kernels): times, on the handle's current state after at least one frame
  * step, `reps` back-to-back launches of (a) the persistent depth-decoder launch for batch B -- csrc/dec_persist.cuh at B = 1,
  * csrc/dec_persist_m.cuh at B = 2..32 -- and (b) a batch-1 backbone decode step (16 one-launch layers, csrc/bb_block.cuh),

@@ -331,6 +331,7 @@ struct BbLayerArgs {
     const uint4* w2t;                     // W2 re-tiled [256 cu][4 k chunks][2048 rows] 16-byte pieces (k_bb_retile_w2)
     dp_u64 *gH, *gP;                      // [8][1024] h1 granules; [256 owners][256 producers][8 rows] fp32 partials
     dp_u64* stamps;                       // timeline build: 16 s_memrealtime stamps of workgroup 100 (layer 8)
+    const float *sq, *sk, *sv, *so, *s1, *s3, *s2;   // F8: per-output-row scales of the e4m3 matrices (wq.. then point to bytes, w2t to k_bb_retile_w2_fp8's pieces)
 };
 #ifdef DP_TIMELINE
 #define BL_STAMP(i_, cond_) do { if (a.stamps != nullptr && cu == 100 && lane == 0 && (cond_)) a.stamps[i_] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -345,6 +346,14 @@ struct BbLayerArgs {
 #define BL_M_FH 4
 #define BL_M_CD 5
 
+// e4m3 W2 [2048 rows][8192] bytes -> [256 cu][2 k chunks][2048 rows] 16-byte pieces (workgroup cu's 32 columns, 16 at a time)
+__global__ void k_bb_retile_w2_fp8(const uint8_t* w2, uint4* w2t) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 256L * 2 * BB_D) return;
+    const int n = (int)(i % BB_D), q = (int)((i / BB_D) % 2), c = (int)(i / (2 * BB_D));
+    w2t[i] = *reinterpret_cast<const uint4*>(w2 + (long)n * 8192 + c * 32 + q * 16);
+}
+
 __global__ void k_bb_retile_w2(const bf16_t* w2, uint4* w2t) {       // w2 [2048 rows][8192]
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 256L * 4 * BB_D) return;
@@ -352,10 +361,17 @@ __global__ void k_bb_retile_w2(const bf16_t* w2, uint4* w2t) {       // w2 [2048
     w2t[i] = *reinterpret_cast<const uint4*>(w2 + (long)n * 8192 + c * 32 + q * 8);
 }
 
+// F8: the seven weight matrices arrive as OCP-e4m3 bytes with one power-of-two fp32 scale per output row (BASELINE config 5): a lane's
+// 16-byte piece holds 16 k values instead of 8, so the activations are kept in the matching order (piece q of a lane = elements
+// 16 ((q >> 1) * 64 + lane) + 8 (q & 1) ..), the dot products run through v_cvt_scalef32_pk_bf16_fp8 + v_dot2c_f32_bf16 (dot16_fp8) and the
+// row scale multiplies the fp32 sum (exact).  61 MB per layer instead of 122.
+template <bool F8>
 __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
+    constexpr int NW = F8 ? 2 : 4;                                      // 16-byte weight pieces per lane per 2048-long row
     extern __shared__ __attribute__((aligned(16))) char lds[];          // BL_LDS_BYTES (dynamic: 143 KB)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cu = blockIdx.x;
     const int lane = threadIdx.x & 63;
+    auto xi = [&](int q) -> int { return F8 ? 2 * ((q >> 1) * 64 + lane) + (q & 1) : q * 64 + lane; };      // index of a lane's q-th 16-byte activation piece
     dp_lu32* misc = (dp_lu32*)(lds + BB_L_MISC);
     dp_lvu32* ab = (dp_lvu32*)(misc + BB_M_ABORT);
     if (threadIdx.x < 16) misc[threadIdx.x] = 0;
@@ -363,23 +379,28 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
     // ---- everything that does not depend on the step's position: issued now, in the order it is consumed ---------------
     uint4 hv[4], g[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) hv[i] = reinterpret_cast<const uint4*>(a.h)[i * 64 + lane];
+    for (int i = 0; i < 4; ++i) hv[i] = reinterpret_cast<const uint4*>(a.h)[xi(i)];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) g[i] = reinterpret_cast<const uint4*>(a.sa_norm)[i * 64 + lane];
+    for (int i = 0; i < 4; ++i) g[i] = reinterpret_cast<const uint4*>(a.sa_norm)[xi(i)];
     const int orow = 8 * cu + 2 * (wave & 3);                         // waves 0..3: output rows orow, orow + 1
     const uint32_t hres = *reinterpret_cast<const uint32_t*>(a.h + orow);
     const int pair = 6 * cu + wave;                                   // waves 0..5: rows 2 pair, 2 pair + 1 of [q; k; v]
     const int R0 = 2 * (wave < 6 ? pair : 0);
-    const bf16_t* wr = R0 < 2048 ? a.wq + (long)R0 * BB_D : R0 < 2560 ? a.wk + (long)(R0 - 2048) * BB_D : a.wv + (long)(R0 - 2560) * BB_D;
-    uint4 w0[4], w1[4], wo[4], wo1[4];
+    constexpr int EB = F8 ? 1 : 2;                                      // bytes per weight
+    const int rq = R0 < 2048 ? R0 : R0 < 2560 ? R0 - 2048 : R0 - 2560;  // row inside its matrix
+    const char* wr = (const char*)(R0 < 2048 ? a.wq : R0 < 2560 ? a.wk : a.wv) + (long)rq * BB_D * EB;
+    float sc0 = 1.f, sc1 = 1.f, so0 = 1.f, so1 = 1.f;                   // F8: the rows' scales
+    if (F8 && wave < 6) { const float* sp = R0 < 2048 ? a.sq : R0 < 2560 ? a.sk : a.sv; sc0 = sp[rq]; sc1 = sp[rq + 1]; }
+    if (F8 && wave < 4) { so0 = a.so[orow]; so1 = a.so[orow + 1]; }
+    uint4 w0[NW], w1[NW], wo[NW], wo1[NW];
     if (wave < 6) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { w0[i] = ldg16<true>(reinterpret_cast<const uint4*>(wr) + i * 64 + lane); w1[i] = ldg16<true>(reinterpret_cast<const uint4*>(wr + BB_D) + i * 64 + lane); }
+        for (int i = 0; i < NW; ++i) { w0[i] = ldg16<true>(reinterpret_cast<const uint4*>(wr) + i * 64 + lane); w1[i] = ldg16<true>(reinterpret_cast<const uint4*>(wr + BB_D * EB) + i * 64 + lane); }
     }
     if (wave < 4) {                                     // o-projection rows: BEFORE the MLP weights in the queue (issued after them these 32 KB
                                                         // arrived last, ~16 us in, and held the whole layer up)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { wo[i] = ldg16<true>(reinterpret_cast<const uint4*>(a.wo + (long)orow * BB_D) + i * 64 + lane); wo1[i] = ldg16<true>(reinterpret_cast<const uint4*>(a.wo + (long)(orow + 1) * BB_D) + i * 64 + lane); }
+        for (int i = 0; i < NW; ++i) { wo[i] = ldg16<true>(reinterpret_cast<const uint4*>((const char*)a.wo + (long)orow * BB_D * EB) + i * 64 + lane); wo1[i] = ldg16<true>(reinterpret_cast<const uint4*>((const char*)a.wo + (long)(orow + 1) * BB_D * EB) + i * 64 + lane); }
     }
     const uint32_t base = *a.epoch;
     const int p = min(max(*a.pos, 0), a.smax - 1);
@@ -397,9 +418,14 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
     const int slot = lane >> 3, e8 = lane & 7;
     // buf: K / V rows on an attention CU (until its attention is done), else the first three (gate, up) pairs of this wave
     uint4 buf[24], gu3[8];
-    auto load_gu = [&](int i, int gq, int c) -> uint4 {                 // pair i of this wave, gq 0 = gate row, 1 = up row, chunk c
+    auto load_gu = [&](int i, int gq, int c) -> uint4 {                 // pair i of this wave, gq 0 = gate row, 1 = up row, chunk c (F8: c < 2)
         const long prow = 32L * cu + 4 * wave + i;
-        return ldg16<true>(reinterpret_cast<const uint4*>((gq ? a.w3 : a.w1) + prow * BB_D) + c * 64 + lane);
+        return ldg16<true>(reinterpret_cast<const uint4*>((const char*)(gq ? a.w3 : a.w1) + prow * BB_D * EB) + c * 64 + lane);
+    };
+    // all (gate, up) pieces of pairs 0..2 of this wave into buf, in the order (pair, gate | up, chunk)
+    auto load_buf = [&]() {
+#pragma unroll
+        for (int q = 0; q < 6 * NW; ++q) buf[q] = load_gu(q / (2 * NW), (q / NW) & 1, q % NW);
     };
     if (attn_cu) {
         const int kvh = head / (BB_NH / BB_NKV);
@@ -412,10 +438,7 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
             buf[j] = *reinterpret_cast<const uint4*>(kb + (long)key * BB_HD + e8 * 8);
             buf[12 + j] = *reinterpret_cast<const uint4*>(vb + (long)key * BB_HD + e8 * 8);
         }
-    } else if (wave < 7) {
-#pragma unroll
-        for (int q = 0; q < 24; ++q) buf[q] = load_gu(q >> 3, (q >> 2) & 1, q & 3);
-    }
+    } else if (wave < 7) load_buf();
     // (misc zeroed.  A bare s_barrier: __syncthreads() would also wait for every load issued above)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const uint32_t tagQ = base + 1u, tagA = base + 2u, tagS = base + 3u, tagH = base + 4u, tagP = base + 5u;
@@ -435,8 +458,11 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
     if (wave < 6) {
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { a0 = dot8(w0[i], xn[i], a0); a1 = dot8(w1[i], xn[i], a1); }
-        a0 = wave_sum(a0); a1 = wave_sum(a1);
+        for (int i = 0; i < NW; ++i) {
+            if (F8) { a0 = dot16_fp8(w0[i], xn[2 * i], xn[2 * i + 1], a0); a1 = dot16_fp8(w1[i], xn[2 * i], xn[2 * i + 1], a1); }
+            else { a0 = dot8(w0[i], xn[i], a0); a1 = dot8(w1[i], xn[i], a1); }
+        }
+        a0 = wave_sum(a0) * sc0; a1 = wave_sum(a1) * sc1;
         const uint32_t outw = dp_rope_pair(a0, a1, cs, R0 < 2560);
         if (lane < DP_NREP) dp_gran_store(a.gQ + lane * BB_NQKV_PAIRS + pair, tagQ, outw);
         BL_STAMP(1, wave == 0);
@@ -450,13 +476,13 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
     // registers -- with it in VGPRs the kernel spilled 41 dwords per lane.  Piece (row block rb, k chunk kc) at index rb * 4 + kc.
     auto load_w2_lds = [&]() {
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.w2t + ((long)cu * 4 + (q & 3)) * BB_D + 256 * wave + 64 * (q >> 2) + lane),
+        for (int q = 0; q < 4 * NW; ++q)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.w2t + ((long)cu * NW + (q % NW)) * BB_D + 256 * wave + 64 * (q / NW) + lane),
                                              (void __attribute__((address_space(3)))*)(lds + BL_L_W2 + ((wave * 16 + q) * 64) * 16), 16, 0, 0);
     };
     if (wave < 7) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) gu3[q] = load_gu(3, q >> 2, q & 3);
+        for (int q = 0; q < 2 * NW; ++q) gu3[q] = load_gu(3, q / NW, q % NW);
         load_w2_lds();
     }
     if (wave == 6) {                                    // mlp_norm's scale -> LDS (16 registers per wave otherwise, held for 10 us)
@@ -547,10 +573,7 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(misc + BB_M_CNT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (wave >= 1 && wave < 7) {                    // K / V are consumed: the registers take this wave's first three (gate, up) pairs
-#pragma unroll
-            for (int q = 0; q < 24; ++q) buf[q] = load_gu(q >> 3, (q >> 2) & 1, q & 3);
-        }
+        if (wave >= 1 && wave < 7) load_buf();          // K / V are consumed: the registers take this wave's first three (gate, up) pairs
         if (wave == 0) {
             const dp_u64 t0 = __builtin_amdgcn_s_memrealtime();
             for (uint32_t spins = 1; *(dp_lvu32*)(misc + BB_M_CNT) < 8u; ++spins) {
@@ -604,10 +627,7 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
             }
         }
     }
-    if (attn_cu && wave == 0) {                         // (wave 0 had the fold and the publishing to do first)
-#pragma unroll
-        for (int q = 0; q < 24; ++q) buf[q] = load_gu(q >> 3, (q >> 2) & 1, q & 3);
-    }
+    if (attn_cu && wave == 0) load_buf();               // (wave 0 had the fold and the publishing to do first)
     // ---- every CU: the attention vector -> o-projection rows (waves 0..3: two each) + residual -> h1 granules ---------------
     if (wave == 7) {
         uint32_t v[16];
@@ -618,18 +638,20 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
         BL_STAMP(2, true);
         // the gather wave's own share of the MLP weights: only now -- its sweeps wait on vmcnt(0), and loads issued at entry
         // would have put the whole 100 MB stream of the chip in front of the attention hand-off
+        load_buf();
 #pragma unroll
-        for (int q = 0; q < 24; ++q) buf[q] = load_gu(q >> 3, (q >> 2) & 1, q & 3);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) gu3[q] = load_gu(3, q >> 2, q & 3);
+        for (int q = 0; q < 2 * NW; ++q) gu3[q] = load_gu(3, q / NW, q % NW);
         load_w2_lds();
     } else if (!bb_wait_flag((dp_lvu32*)(misc + BB_M_FATT), tagA, ab, a.err, 0xC05u, lane)) return;
     if (wave < 4) {
         const dp_lu4* xs = (const dp_lu4*)(lds + BB_L_ATT);
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const uint4 x = dp_ldq(xs + i * 64 + lane); a0 = dot8(wo[i], x, a0); a1 = dot8(wo1[i], x, a1); }
-        a0 = wave_sum(a0); a1 = wave_sum(a1);
+        for (int i = 0; i < NW; ++i) {
+            if (F8) { const uint4 x0 = dp_ldq(xs + xi(2 * i)), x1 = dp_ldq(xs + xi(2 * i + 1)); a0 = dot16_fp8(wo[i], x0, x1, a0); a1 = dot16_fp8(wo1[i], x0, x1, a1); }
+            else { const uint4 x = dp_ldq(xs + i * 64 + lane); a0 = dot8(wo[i], x, a0); a1 = dot8(wo1[i], x, a1); }
+        }
+        a0 = wave_sum(a0) * so0; a1 = wave_sum(a1) * so1;
         const uint32_t outw = dp_resid_pair(a0, a1, hres);
         if (lane < DP_NREP) dp_gran_store(a.gH + lane * 1024 + 4 * cu + wave, tagH, outw);
         BL_STAMP(3, wave == 0);
@@ -652,21 +674,23 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
         uint4 x2[4];
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { x2[i] = dp_ldq(hs + i * 64 + lane); ss += dp_chunk_ss(x2[i]); }
+        for (int i = 0; i < 4; ++i) { x2[i] = dp_ldq(hs + xi(i)); ss += dp_chunk_ss(x2[i]); }
         ss = wave_sum(ss);
         const float r = 1.0f / sqrtf(ss / (float)BB_D + a.eps);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x2[i] = dp_chunk_norm(x2[i], dp_ldq((const dp_lu4*)(lds + BL_L_G2) + i * 64 + lane), r);
-        // pair i: gate row in [i * 8 + 0..3], up row in [i * 8 + 4..7] of buf (i < 3) / gu3 (i = 3)
+        for (int i = 0; i < 4; ++i) x2[i] = dp_chunk_norm(x2[i], dp_ldq((const dp_lu4*)(lds + BL_L_G2) + xi(i)), r);
+        // pair i: gate row in [i * 2 NW + 0..NW-1], up row in [i * 2 NW + NW..] of buf (i < 3) / gu3 (i = 3)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float ag = 0.f, au = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint4 wg = i < 3 ? buf[i * 8 + c] : gu3[c], wu = i < 3 ? buf[i * 8 + 4 + c] : gu3[4 + c];
-                ag = dot8(wg, x2[c], ag); au = dot8(wu, x2[c], au);
+            for (int c = 0; c < NW; ++c) {
+                const uint4 wg = i < 3 ? buf[i * 2 * NW + c] : gu3[c], wu = i < 3 ? buf[i * 2 * NW + NW + c] : gu3[NW + c];
+                if (F8) { ag = dot16_fp8(wg, x2[2 * c], x2[2 * c + 1], ag); au = dot16_fp8(wu, x2[2 * c], x2[2 * c + 1], au); }
+                else { ag = dot8(wg, x2[c], ag); au = dot8(wu, x2[c], au); }
             }
             ag = wave_sum(ag); au = wave_sum(au);
+            if (F8) { const long prow = 32L * cu + 4 * wave + i; ag *= a.s1[prow]; au *= a.s3[prow]; }
             const uint32_t hv1 = dp_swiglu(ag, au);
             if (lane == 0) ((dp_lu16*)(lds + BL_L_HL))[4 * wave + i] = (unsigned short)hv1;
         }
@@ -688,11 +712,17 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             const int row = 256 * wave + 64 * rb + lane;
-            const dp_lu4* wl = (const dp_lu4*)(lds + BL_L_W2) + (wave * 16 + rb * 4) * 64 + lane;
-            float pacc = dot8(dp_ldq(wl), hk[0], 0.f);
-            pacc = dot8(dp_ldq(wl + 64), hk[1], pacc);
-            pacc = dot8(dp_ldq(wl + 128), hk[2], pacc);
-            pacc = dot8(dp_ldq(wl + 192), hk[3], pacc);
+            const dp_lu4* wl = (const dp_lu4*)(lds + BL_L_W2) + (wave * 16 + rb * NW) * 64 + lane;
+            float pacc;
+            if (F8) {       // two 16-byte pieces = the CU's 32 columns (the row's scale is applied by the row's owner, to the sum)
+                pacc = dot16_fp8(dp_ldq(wl), hk[0], hk[1], 0.f);
+                pacc = dot16_fp8(dp_ldq(wl + 64), hk[2], hk[3], pacc);
+            } else {
+                pacc = dot8(dp_ldq(wl), hk[0], 0.f);
+                pacc = dot8(dp_ldq(wl + 64), hk[1], pacc);
+                pacc = dot8(dp_ldq(wl + 128), hk[2], pacc);
+                pacc = dot8(dp_ldq(wl + 192), hk[3], pacc);
+            }
             dp_gran_store(a.gP + ((long)(row >> 3) * 256 + cu) * 8 + (row & 7), tagP, __float_as_uint(pacc));
         }
     }
@@ -716,6 +746,7 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
         for (int o = 4; o < 64; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
         if (lane < 4) {
             const uint32_t h1w = ((const dp_lu32*)(lds + BL_L_H1))[4 * cu + lane];          // rows 8 cu + 2 lane, + 1 of h1
+            if (F8) { s0 *= a.s2[8 * cu + 2 * lane]; s1 *= a.s2[8 * cu + 2 * lane + 1]; }
             *reinterpret_cast<uint32_t*>(a.h + 8 * cu + 2 * lane) = dp_resid_pair(s0, s1, h1w);
         }
     }

@@ -87,6 +87,8 @@ struct CsmModel {
     bool bb_layer;                      // ... and the MLP in the same launch (k_bb_layer)
     dp_u64 *bg_h, *bg_p;
     uint4* b_w2t;                       // [layers] W2 re-tiled, 256 * 4 * 2048 pieces each
+    uint4* b_w2t8;                      // fp8 mode: [layers] e4m3 W2 re-tiled, 256 * 2 * 2048 pieces each
+    bool bb_layer8;                     // fp8 mode: the one-launch layer streams the e4m3 bytes (k_bb_layer<true>)
     uint32_t* b_state;                  // [0] tag epoch, [1] give-up code
     uint4 *p_w2s, *p_w13p;              // [4 layers] re-tiled W2 / packed W1|W3, constant layer stride
     bf16_t *p_wsm, *p_norms;            // [4][2560][1024] q|k|v|o rows, [4][2][1024] norm scales
@@ -597,23 +599,35 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
             a.s0 = (const float*)S.w8s[l].wq; a.s1 = (const float*)S.w8s[l].wk; a.s2 = (const float*)S.w8s[l].wv;
         }
         bool block_done = false;
-        if (&S == &m->bb && M == 1 && m->bb_block && !m->bb_disabled && !f8 && pos != nullptr) {
+        if (&S == &m->bb && M == 1 && m->bb_block && !m->bb_disabled && (!f8 || m->bb_layer8) && pos != nullptr) {
             // (1)-(3) as ONE launch (bb_block.cuh): q|k|v + RoPE + KV append -> attention -> o-projection + residual
             BbBlockArgs b;
             memset(&b, 0, sizeof b);
             b.wq = (const bf16_t*)w.wq; b.wk = (const bf16_t*)w.wk; b.wv = (const bf16_t*)w.wv; b.wo = (const bf16_t*)w.wo;
             b.sa_norm = (const bf16_t*)w.sa_norm; b.rope = S.rope; b.h = h; b.kc = kc; b.vc = vc; b.pos = pos; b.smax = S.cache_len;
             b.eps = S.d.norm_eps; b.gQ = m->bg_q; b.gA = m->bg_a; b.gS = m->bg_s; b.err = m->b_state + 1; b.epoch = m->b_state; b.poll_sleep = m->persist ? m->p_poll : 1;
-            if (m->bb_layer) {
+            if (m->bb_layer || f8) {
                 // ... and the MLP: the whole layer in one launch
                 BbLayerArgs L;
                 memset(&L, 0, sizeof L);
                 L.wq = b.wq; L.wk = b.wk; L.wv = b.wv; L.wo = b.wo; L.sa_norm = b.sa_norm; L.rope = b.rope; L.h = b.h; L.kc = b.kc; L.vc = b.vc;
                 L.pos = b.pos; L.smax = b.smax; L.eps = b.eps; L.gQ = b.gQ; L.gA = b.gA; L.gS = b.gS; L.err = b.err; L.epoch = b.epoch; L.poll_sleep = b.poll_sleep;
                 L.w1 = (const bf16_t*)w.w1; L.w3 = (const bf16_t*)w.w3; L.mlp_norm = (const bf16_t*)w.mlp_norm;
-                L.w2t = m->b_w2t + (size_t)l * 256 * 4 * BB_D; L.gH = m->bg_h; L.gP = m->bg_p;
+                L.gH = m->bg_h; L.gP = m->bg_p;
                 L.stamps = (m->p_stamps != nullptr && l == 8) ? m->p_stamps + 5312 : nullptr;        // (timeline build only)
-                hipLaunchKernelGGL(k_bb_layer, dim3(DP_NB), dim3(512), BL_LDS_BYTES, st, L);
+                if (f8) {
+                    // the e4m3 stream: bytes + one power-of-two scale per output row (k_bb_layer<true>)
+                    const CsmLayerWeights &w8 = S.w8[l], &s8 = S.w8s[l];
+                    L.wq = (const bf16_t*)w8.wq; L.wk = (const bf16_t*)w8.wk; L.wv = (const bf16_t*)w8.wv; L.wo = (const bf16_t*)w8.wo;
+                    L.w1 = (const bf16_t*)w8.w1; L.w3 = (const bf16_t*)w8.w3;
+                    L.sq = (const float*)s8.wq; L.sk = (const float*)s8.wk; L.sv = (const float*)s8.wv; L.so = (const float*)s8.wo;
+                    L.s1 = (const float*)s8.w1; L.s3 = (const float*)s8.w3; L.s2 = (const float*)s8.w2;
+                    L.w2t = m->b_w2t8 + (size_t)l * 256 * 2 * BB_D;
+                    hipLaunchKernelGGL(k_bb_layer<true>, dim3(DP_NB), dim3(512), BL_LDS_BYTES, st, L);
+                } else {
+                    L.w2t = m->b_w2t + (size_t)l * 256 * 4 * BB_D;
+                    hipLaunchKernelGGL(k_bb_layer<false>, dim3(DP_NB), dim3(512), BL_LDS_BYTES, st, L);
+                }
                 if ((e = hipGetLastError()) != hipSuccess) return e;
                 continue;
             }
@@ -1056,27 +1070,40 @@ static void setup_persist(CsmModel* m) {
 static void setup_bb_block(CsmModel* m) {
     const char* ev = getenv("CSM_BB_BLOCK");
     const CsmLlamaDims& bc = m->cfg.backbone;
-    if ((ev && ev[0] == '0') || bc.dim != BB_D || bc.n_heads != BB_NH || bc.n_kv_heads != BB_NKV || m->w.fp8) return;
+    const bool f8 = m->w.fp8 != 0;
+    m->bb_layer8 = false; m->b_w2t8 = nullptr;
+    if ((ev && ev[0] == '0') || bc.dim != BB_D || bc.n_heads != BB_NH || bc.n_kv_heads != BB_NKV) return;
+    const char* ev2 = getenv("CSM_BB_LAYER");
+    const bool want_layer = !(ev2 && ev2[0] == '0') && bc.ffn == 8192;
+    if (f8 && !want_layer) return;                       // the fp8 stream exists only in the one-launch layer (the three-launch block is bf16)
     if (!all_cu_launch_fits(k_bb_attn_block, 0, "one-launch backbone attention block")) return;
     OptAllocs A;
     A.get(&m->bg_q, (size_t)DP_NREP * BB_NQKV_PAIRS * 8); A.get(&m->bg_a, (size_t)DP_NREP * 1024 * 8); A.get(&m->b_state, 16);
     A.get(&m->bg_s, (size_t)BB_NH * 8 * 72 * 8);
     if (!A.ok || hipDeviceSynchronize() != hipSuccess) { A.drop(); m->b_state = nullptr; note_fallback("one-launch backbone attention block", "allocation failed"); return; }
+    if (!want_layer) { m->bb_block = true; m->bb_allocs = A.ptrs; return; }
+    const bool fits = f8 ? all_cu_launch_fits(k_bb_layer<true>, BL_LDS_BYTES, "one-launch backbone layer (fp8)") : all_cu_launch_fits(k_bb_layer<false>, BL_LDS_BYTES, "one-launch backbone layer");
+    if (!fits) { if (f8) { A.drop(); m->b_state = nullptr; } else { m->bb_block = true; m->bb_allocs = A.ptrs; } return; }
+    const size_t per_layer = (size_t)256 * (f8 ? 2 : 4) * BB_D;
+    OptAllocs L;
+    L.get(&m->bg_h, (size_t)DP_NREP * 1024 * 8); L.get(&m->bg_p, (size_t)256 * 256 * 8 * 8);
+    uint4* w2t = nullptr;
+    L.get(&w2t, per_layer * 16 * bc.n_layers);
+    bool ok = L.ok;
+    for (int l = 0; l < bc.n_layers && ok; ++l) {
+        if (f8) hipLaunchKernelGGL(k_bb_retile_w2_fp8, dim3((unsigned)((per_layer + 255) / 256)), dim3(256), 0, nullptr, (const uint8_t*)m->w.bb8[l].w2, w2t + (size_t)l * per_layer);
+        else hipLaunchKernelGGL(k_bb_retile_w2, dim3((unsigned)((per_layer + 255) / 256)), dim3(256), 0, nullptr, (const bf16_t*)m->w.bb[l].w2, w2t + (size_t)l * per_layer);
+    }
+    ok = ok && hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError(); L.drop(); note_fallback("one-launch backbone layer", "allocation / weight re-tiling failed");
+        if (f8) { A.drop(); m->b_state = nullptr; } else { m->bb_block = true; m->bb_allocs = A.ptrs; }
+        return;
+    }
     m->bb_block = true;
     m->bb_allocs = A.ptrs;
-    const char* ev2 = getenv("CSM_BB_LAYER");
-    if ((ev2 && ev2[0] == '0') || bc.ffn != 8192) return;
-    if (!all_cu_launch_fits(k_bb_layer, BL_LDS_BYTES, "one-launch backbone layer")) return;
-    const size_t per_layer = (size_t)256 * 4 * BB_D;
-    OptAllocs L;
-    L.get(&m->bg_h, (size_t)DP_NREP * 1024 * 8); L.get(&m->bg_p, (size_t)256 * 256 * 8 * 8); L.get(&m->b_w2t, per_layer * 16 * bc.n_layers);
-    if (!L.ok) { L.drop(); note_fallback("one-launch backbone layer", "allocation failed"); return; }
-    for (int l = 0; l < bc.n_layers; ++l)
-        hipLaunchKernelGGL(k_bb_retile_w2, dim3((unsigned)((per_layer + 255) / 256)), dim3(256), 0, nullptr, (const bf16_t*)m->w.bb[l].w2,
-                           m->b_w2t + (size_t)l * per_layer);
-    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); L.drop(); note_fallback("one-launch backbone layer", "weight re-tiling failed"); return; }
-    m->bb_layer = true;
     m->bb_allocs.insert(m->bb_allocs.end(), L.ptrs.begin(), L.ptrs.end());
+    if (f8) { m->b_w2t8 = w2t; m->bb_layer8 = true; } else { m->b_w2t = w2t; m->bb_layer = true; }
 }
 
 extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_batch, int max_rows, int max_frames,
@@ -1500,6 +1527,14 @@ extern "C" int csm_debug_persist_stamps(csm_handle m, uint64_t* host, int n_word
     return CSM_OK;
 }
 
+// which optional all-CU launches this handle runs (tests assert the path they mean to cover): bit 0 persistent decoder (B = 1), 1 batched
+// persistent decoder (B = 2..32), 2 backbone attention block, 3 one-launch backbone layer (bf16), 4 one-launch backbone layer (e4m3 stream)
+extern "C" int csm_debug_fast_paths(csm_handle m) {
+    if (!m) return 0;
+    return (m->persist && !m->persist_disabled ? 1 : 0) | (m->persist_m && !m->persist_disabled ? 2 : 0) | (m->bb_block && !m->bb_disabled ? 4 : 0) |
+           (m->bb_layer && !m->bb_disabled ? 8 : 0) | (m->bb_layer8 && !m->bb_disabled ? 16 : 0);
+}
+
 // Times the two dominant launches of a decode step on the handle's CURRENT state, each `reps` times back to back between HIP events on
 // `stream` (bench.py's roofline.dominant_kernels): out[0] = avg us of the persistent depth-decoder launch for batch B (NaN when the launch
 // chain is in charge), out[1] = bytes it streams per launch (n_codebooks - 2 steps x (4 layers + 1 head)), out[2] = avg us of one backbone layer
@@ -1527,7 +1562,7 @@ extern "C" int csm_debug_time_kernels(csm_handle m, int B, int reps, float tempe
         HIPCHK(m, hipEventElapsedTime(&ms, e0, e1));
         out[0] = ms * 1e3 / reps;
     }
-    if (B == 1 && m->bb_layer && !m->bb_disabled) {
+    if (B == 1 && (m->bb_layer || m->bb_layer8) && !m->bb_disabled) {
         HIPCHK(m, run_stack(m, m->bb, m->h, m->q, m->att, m->act, 1, 1, m->cur_pos, -1, st));
         HIPCHK(m, hipEventRecord(e0, st));
         for (int i = 0; i < reps; ++i) HIPCHK(m, run_stack(m, m->bb, m->h, m->q, m->att, m->act, 1, 1, m->cur_pos, -1, st));

@@ -87,6 +87,7 @@ SIGNATURES = {
     "csm_op_embed_sum": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "csm_op_sample": (_i, [_i, _i, _i, _vp, _f, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "csm_debug_persist_stamps": (_i, [_vp, _vp, _i]),
+    "csm_debug_fast_paths": (_i, [_vp]),
     "csm_debug_time_kernels": (_i, [_vp, _i, _i, _f, _i, _vp, _vp]),
 }
 

@@ -506,5 +506,9 @@ class Model:
         self.step(b, temperature, topk)
         return self.last_frame(b)
 
+    def fast_paths(self) -> int:
+        """bit mask of the all-CU launches this handle runs (include/csm_hip_ops.h csm_debug_fast_paths)."""
+        return int(lib.csm_debug_fast_paths(self._h))
+
     def bytes_per_frame(self, batch: int, p_mean: float) -> float:
         return lib.csm_bytes_per_frame(self._h, batch, float(p_mean))
