@@ -483,7 +483,7 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                     const int b = 16 * hf + bl;
                     if (b < a.M) {
                         const uint32_t hv = dp_swiglu(acc[0], acc[1]) | (dp_swiglu(acc[2], acc[3]) << 16);
-                        const uint32_t off = (uint32_t)(gg * 32768 + gj * 2048 + b * 64 + (8 * w + 2 * g4) * 2);
+                        const uint32_t off = (uint32_t)(gg * 32768 + (gj * 4 + w) * 512 + b * 16 + g4 * 4);      // [g][piece 4 j + w][32 rows][8 columns]: a wave's 16 rows are 256 contiguous bytes
                         dm_sst4(xg, off, hv);
                         dm_sst4(xg2, off, 0xffffffffu);
                     }
@@ -560,13 +560,13 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
     uint32_t kf = 0, nsw = 0, quad_phase = 0;          // fills so far, normed sweeps so far
     const DpQuadSync qsync{(dp_lvu32*)(misc + DM_M_BAR), ab, a.err, lane, &quad_phase, nullptr};      // barrier of the four gather waves
     const int n_steps = a.cb_last - a.cb_first + 1;
-    // my lane's piece offsets in the row-major attention matrix and in my group's h blocks [16 j][32 rows][32 columns], per half
+    // my lane's piece offsets in the row-major attention matrix and in my group's h pieces [64 pieces = 4 j + wave][32 rows][8 columns], per half
     uint32_t voff_a[NH], voff_g[NH];
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf) {
         const int rowc = min(16 * hf + gw * 4 + (lane & 3), a.M - 1), pg = lane >> 2;
         voff_a[hf] = (uint32_t)(rowc * 2048 + pg * 16);
-        voff_g[hf] = (uint32_t)((pg >> 2) * 2048 + rowc * 64 + (pg & 3) * 16);
+        voff_g[hf] = (uint32_t)(pg * 512 + rowc * 16);
     }
     // fill k of a half's activation buffer may start once that half's phase k - 1 has read it
 #define DM_FILL_BEGIN(hf_, code_) do { if (!dm_wait_ge(cdone + (hf_), 4u * (kf - 1), ab, a.err, (code_), lane)) return; } while (0)
