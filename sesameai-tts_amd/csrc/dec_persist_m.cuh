@@ -508,7 +508,7 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                     dm_arrive(misc + DM_M_CDONE + hf, lane);
                     const int b = 16 * hf + bl;
                     if (b < a.M) {
-                        const uint32_t off = (uint32_t)((((gj * 16 + gg) * 32 + b) * 64 + 16 * w + 4 * g4) * 4);
+                        const uint32_t off = (uint32_t)((((((gj * 16 + gg) * 4 + w) * 32 + b) * 16) + 4 * g4) * 4);      // [j][g][wave][32 rows][16 columns] f32: a wave's 16 rows are 1 KB contiguous
                         u32x4_t o; o.x = __float_as_uint(acc[0]); o.y = __float_as_uint(acc[1]); o.z = __float_as_uint(acc[2]); o.w = __float_as_uint(acc[3]);
                         u32x4_t ff; ff.x = ff.y = ff.z = ff.w = 0xffffffffu;
                         dm_sst16(xp, off, o);
@@ -639,7 +639,7 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
                     const char* p[4];
                     u32x4_t x[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) p[i] = pb + ((((long)gj * 16 + (qt * 4 + i)) * 32 + bc) * 64 + 4 * gg) * 4;
+                    for (int i = 0; i < 4; ++i) p[i] = pb + ((((((long)gj * 16 + (qt * 4 + i)) * 4 + (gg >> 2)) * 32 + bc) * 16) + 4 * (gg & 3)) * 4;
                     if (!dm_poll<4>(p, x, lane, ab, a.err, 0x610u + l, ps)) return;
                     float t[4] = {__uint_as_float(x[0].x), __uint_as_float(x[0].y), __uint_as_float(x[0].z), __uint_as_float(x[0].w)};
 #pragma unroll
