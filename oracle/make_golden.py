@@ -188,7 +188,7 @@ def main():
         gold = frames_golden(shape, w, toy_prompt(shape, 2025, 16, 0), a.frames, keep_full=False, with_fp32=True)
         gold.update(weight_seed=1234, prompt_seed=2025)
         torch.save(gold, os.path.join(OUT, "csm1b_frames.pt"))
-    if want("cfg2") or want("cfg3") or want("cfg5"):
+    if want("cfg2") or want("cfg3") or want("cfg5") or want("cfg5b"):
         shape = C.csm_1b()
         w = C.make_weights(shape, seed=1234)
         if want("cfg2"):
@@ -214,6 +214,15 @@ def main():
             for d in (g5, gl):
                 d["prompt_tokens"] = d["prompt_tokens"].to(torch.int32)
             torch.save(gold, os.path.join(OUT, "csm1b_cfg5.pt"))
+        if want("cfg5b"):
+            # BASELINE config 5, batched (SURVEY.md 8d lists B = 32; B = 4 keeps the fixture small): 4 different 1334-row prompts,
+            # fp8-dequantised weights, 2 teacher-forced frames of the BATCHED oracle
+            w8 = C.fp8_dequantized(w)
+            ps = [bench_prompt(shape, 6000 + b, segments=10, ctx_text=30, ctx_frames=100) for b in range(4)]
+            gold = frames_golden_batch(shape, w8, torch.stack([p[0] for p in ps]), torch.stack([p[1] for p in ps]), 2)
+            gold.update(weight_seed=1234, prompt_seed=6000)
+            gold["prompt_tokens"] = gold["prompt_tokens"].to(torch.int32)
+            torch.save(gold, os.path.join(OUT, "csm1b_cfg5b.pt"))
 
 
 if __name__ == "__main__":

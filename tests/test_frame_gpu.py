@@ -942,6 +942,53 @@ def test_csm1b_config5_fp8_long_context_vs_golden(csm1b):
         assert _same_until_a_near_tie(got1, g["codes"][1].reshape(-1), g["margin"][1], noise, f"graph step at p={S}") >= 1
 
 
+def test_csm1b_config5_batched_fp8_long_context_vs_golden(csm1b):
+    """BASELINE config 5, batched (SURVEY.md 8d lists B = 32 for it; the fixture keeps B = 4): four DIFFERENT 1334-row prompts, fp8-e4m3
+    weight stream, against the BATCHED oracle on the dequantised weights -- the LDS-tiled prefill at 5,336 rows, the batched
+    decode step's split-K attention over 1,335 keys per row, the e4m3 matrix-core path and the batched persistent decoder."""
+    import bench
+    from types import SimpleNamespace
+    from oracle import csm_ref as C
+    from sesameai.models import Model, csm_1b_args
+    _, sd = csm1b
+    path = os.path.join(GOLD, "csm1b_cfg5b.pt")
+    if not os.path.exists(path):
+        pytest.skip("csm1b_cfg5b golden not generated (oracle/make_golden.py --only cfg5b)")
+    gold = torch.load(path)
+    g5 = torch.load(os.path.join(GOLD, "csm1b_cfg5.pt"))
+    noise = float(g5["s1334"]["bf16_vs_fp32_gap"].max())
+    tok, msk = gold["prompt_tokens"].long(), gold["prompt_mask"]
+    B, S = tok.shape[0], tok.shape[1]
+    assert (B, S) == (4, 1334)
+    bt, bm = bench.synthetic_prompt(SimpleNamespace(ctx_text=30, ctx_frames=100, gen_text=24), B, C.csm_1b().text_vocab_size, seed0=6000,
+                                    segments=10, ctx_text=30, ctx_frames=100)
+    assert torch.equal(bt, tok) and torch.equal(bm, msk), "golden prompts are not bench.py's config-5 prompts"
+    m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S, weights_dtype="fp8")
+    m.setup_caches(B)
+    assert m.fast_paths() & 2, "the batched persistent decoder must be on this path"
+    m.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+    codes0 = gold["codes"][0]
+    out, logits = m.depth(B, 1.0, 1, forced=codes0, want_logits=True, commit=True)
+    d0 = (torch.gather(logits.float().cpu(), 2, gold["top_i"][0].long()) - gold["top_v"][0].float()).abs().max().item()
+    bad = (out.cpu() != codes0).nonzero()
+    for b, cb in bad.tolist():
+        assert float(gold["margin"][0][cb, b]) <= 2 * noise, f"frame 0 utterance {b} codebook {cb}"
+    row = torch.zeros(B, 1, 33, dtype=torch.long); row[:, 0, :32] = codes0.long()
+    rmask = torch.ones(B, 1, 33, dtype=torch.bool); rmask[:, 0, 32] = False
+    got = m.generate_frame(row, rmask, torch.full((B, 1), S), 1.0, 1).cpu()
+    n_cmp = sum(_same_until_a_near_tie(got[b], gold["codes"][1][b], gold["margin"][1][:, b], noise, f"graph step, utterance {b}") for b in range(B))
+    m2 = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S, weights_dtype="fp8")
+    m2.setup_caches(B)
+    m2.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+    m2.prefill(row, rmask, torch.full((B, 1), S))
+    out1, logits1 = m2.depth(B, 1.0, 1, forced=gold["codes"][1], want_logits=True, commit=False)
+    d1 = (torch.gather(logits1.float().cpu(), 2, gold["top_i"][1].long()) - gold["top_v"][1].float()).abs().max().item()
+    print(f"config 5 batched (B=4, S=1334, fp8): max|dlogit| frame 0 {d0:.4f}, frame 1 {d1:.4f} (gap {noise:.4f}); {len(bad)} of {B * 32} greedy rows excused; "
+          f"{n_cmp} of {B * 32} graph-step decisions compared")
+    assert max(d0, d1) <= noise
+    assert len(bad) <= 0.08 * B * 32 + 1 and n_cmp >= B * 4
+
+
 @pytest.mark.parametrize("weights", ["bf16", "fp8"])
 def test_tiny_long_context_vs_live_oracle(weights):
     """The tiny shapes with the real 2048-position cache: a 1334-row prompt (flash prompt attention over 1334 keys), then
