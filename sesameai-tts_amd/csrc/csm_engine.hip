@@ -23,6 +23,7 @@
 #include "dec_persist.cuh"
 #include "dec_persist_m.cuh"
 #include "bb_block.cuh"
+#include "bb_attn_m.cuh"
 
 #define BB_NSPLIT_MAX 8
 #define PART_ROWS 32
@@ -89,6 +90,10 @@ struct CsmModel {
     uint4* b_w2t;                       // [layers] W2 re-tiled, 256 * 4 * 2048 pieces each
     uint4* b_w2t8;                      // fp8 mode: [layers] e4m3 W2 re-tiled, 256 * 2 * 2048 pieces each
     bool bb_layer8;                     // fp8 mode: the one-launch layer streams the e4m3 bytes (k_bb_layer<true>)
+    // batched decode steps (2..32 rows): the backbone's attention block as one launch per layer (bb_attn_m.cuh; env CSM_BB_ATTN_M=0 disables)
+    bool bb_attn_m;
+    char* bm_xchg;
+    int bm_max_rows;                    // rows up to which it is used (env CSM_BB_ATTN_M_MAX)
     uint32_t* b_state;                  // [0] tag epoch, [1] give-up code
     uint4 *p_w2s, *p_w13p;              // [4 layers] re-tiled W2 / packed W1|W3, constant layer stride
     bf16_t *p_wsm, *p_norms;            // [4][2560][1024] q|k|v|o rows, [4][2][1024] norm scales
@@ -398,6 +403,22 @@ static hipError_t launch_attn_auto(const Stack& S, const AttnArgs& t, bool promp
 // row-major x / act around it.
 static const int g128_gateup_rows = getenv("CSM_G128_GATEUP_ROWS") ? atoi(getenv("CSM_G128_GATEUP_ROWS")) : (1 << 30);
 
+// batched decode step of the backbone (2..32 rows, one per utterance): attention block of layer l as one launch (bb_attn_m.cuh)
+static bool bb_attn_m_usable(const CsmModel* m, const Stack& S, int M, int rows_per_seq, bool prompt) {
+    return m->bb_attn_m && !m->bb_disabled && &S == &m->bb && !prompt && rows_per_seq == 1 && M >= 2 && M <= m->bm_max_rows;
+}
+static hipError_t launch_bb_attn_m(CsmModel* m, Stack& S, int l, bf16_t* h, int M, const int* pos, hipStream_t st, const bf16_t* xn = nullptr, bool xn_packed = false) {
+    const CsmLayerWeights& w = S.lw[l];
+    BbAttnMArgs a;
+    memset(&a, 0, sizeof a);
+    a.wq = (const bf16_t*)w.wq; a.wk = (const bf16_t*)w.wk; a.wv = (const bf16_t*)w.wv; a.wo = (const bf16_t*)w.wo; a.sa_norm = (const bf16_t*)w.sa_norm;
+    a.rope = S.rope; a.h = h; a.xn = xn; a.xn_packed = xn_packed ? 1 : 0; a.kc = S.kc + (long)l * S.layer_stride + S.slot_off; a.vc = S.vc + (long)l * S.layer_stride + S.slot_off;
+    a.pos = pos; a.smax = S.cache_len; a.M = M; a.eps = S.d.norm_eps; a.xchg = m->bm_xchg; a.set = l & 1; a.err = m->b_state + 1; a.poll_sleep = 1;
+    if (M <= 16) hipLaunchKernelGGL(k_bb_attn_m<1>, dim3(DP_NB), dim3(512), BM_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL(k_bb_attn_m<2>, dim3(DP_NB), dim3(512), BM_LDS_BYTES, st, a);
+    return hipGetLastError();
+}
+
 // where the stack's final RMSNorm of each sequence's LAST row goes on the wide path (fused into the last finisher)
 struct FinalNorm { const bf16_t* scale; bf16_t* out; long out_stride; };
 
@@ -487,6 +508,16 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         const bool mid = (prompt || rows_per_seq > 2) && !f8 && mmt_ok(M, d, S.nq + 2 * S.nkv) && mmt_ok(M, S.nq, d) && mmt_ok(M, d, S.d.ffn) && mmt_ok(M, S.d.ffn, d);
         // layer 0 normalises h directly; later layers got xn from the previous down-projection's finisher.
         // (layer 0 of a depth-decoder step >= 2: q/k/v were gathered from the precomputed table by the sampler)
+        int kg = 1;
+        const bool fused_attn = bb_attn_m_usable(m, S, M, rows_per_seq, prompt);
+        if (fused_attn) {
+            // q|k|v -> attention -> o-projection + residual in ONE launch; mlp_norm(h) for gate / up by the row-norm kernel
+            // (its normalised input: layer 0 from the row-norm kernel, later layers from the previous layer's finisher, both in `att`)
+            if (l == 0 && !x_normed && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st, xp0)) != hipSuccess) return e;
+            if ((e = launch_bb_attn_m(m, S, l, h, M, pos, st, att, l > 0 ? xp : xp0)) != hipSuccess) return e;
+            if ((e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st, xp)) != hipSuccess) return e;
+        }
+        if (!fused_attn) {
         if (!(l == 0 && qkv0_done)) {
             if (l == 0 && !x_normed && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st, xp0)) != hipSuccess) return e;
             memset(&a, 0, sizeof a);
@@ -518,12 +549,13 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         // o-proj -> fp32 slabs; finisher: h += sum(slabs), xn = mlp_norm(h)
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = S.nq; a.M = M; a.w0 = (const bf16_t*)pk.wo; a.N = d; a.slab = m->slab;
-        int kg = mid && (MMT_OPS & 4) ? 4 : slab_groups(S.nq, prompt);
+        kg = mid && (MMT_OPS & 4) ? 4 : slab_groups(S.nq, prompt);
         if (f8) { a.w0 = (const bf16_t*)p8.wo; a.s0 = (const float*)S.w8s[l].wo; }
         if (mid && (MMT_OPS & 4)) e = launch_mmq(S.nq, a, st, xp);
         else e = launch_mm_slab(S.nq, kg, a, st, f8, xp);
         if (e != hipSuccess) return e;
         if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st, prompt, xp)) != hipSuccess) return e;
+        }
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = d; a.M = M; a.w0 = (const bf16_t*)pk.w1; a.w1 = (const bf16_t*)pk.w3; a.N = S.d.ffn;
         a.out = act; a.ldo = S.d.ffn; a.out_packed = xp;
@@ -599,6 +631,11 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
             a.s0 = (const float*)S.w8s[l].wq; a.s1 = (const float*)S.w8s[l].wk; a.s2 = (const float*)S.w8s[l].wv;
         }
         bool block_done = false;
+        if (bb_attn_m_usable(m, S, M, rows_per_seq, false) && pos != nullptr) {
+            // (1)-(3) of a 2-row decode step as ONE launch (bb_attn_m.cuh); the gate / up kernel below normalises h itself
+            if ((e = launch_bb_attn_m(m, S, l, h, M, pos, st)) != hipSuccess) return e;
+            block_done = true;
+        }
         if (&S == &m->bb && M == 1 && m->bb_block && !m->bb_disabled && (!f8 || m->bb_layer8) && pos != nullptr) {
             // (1)-(3) as ONE launch (bb_block.cuh): q|k|v + RoPE + KV append -> attention -> o-projection + residual
             BbBlockArgs b;
@@ -827,7 +864,7 @@ static hipError_t launch_advance(CsmModel* m, int B, const int* fed, int pos_inc
     a.n_frames = m->n_frames; a.max_frames = m->max_frames; a.eos_at = m->eos_at; a.cur_tokens = m->cur_tokens;
     a.cur_mask = m->cur_mask; a.cur_pos = m->cur_pos; a.rng = m->rng; a.out_frame = nullptr; a.fed = fed; a.pos_inc = pos_inc;
     a.max_seq = m->cfg.backbone.max_seq; a.overflow = m->n_frames + 1;
-    a.err0 = m->persist ? m->p_state + 1 : nullptr; a.err1 = m->bb_block ? m->b_state + 1 : nullptr;
+    a.err0 = m->p_state + 1; a.err1 = m->b_state + 1;
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(256), 0, st, a);
     return hipGetLastError();
 }
@@ -1022,10 +1059,10 @@ static void setup_persist(CsmModel* m) {
     if (!all_cu_launch_fits(k_dec_persist, DP_LDS_BYTES, "persistent depth decoder")) return;
     OptAllocs A;
     A.get(&m->pg_q, (size_t)DP_NREP * 768 * 8); A.get(&m->pg_h1, (size_t)DP_NREP * 512 * 8); A.get(&m->pg_h2, (size_t)DP_NREP * 512 * 8);
-    A.get(&m->pg_l, (size_t)DP_NREP * DP_LSLOTS * 8); A.get(&m->pg_p, (size_t)256 * 1024 * 8); A.get(&m->p_state, 16);
+    A.get(&m->pg_l, (size_t)DP_NREP * DP_LSLOTS * 8); A.get(&m->pg_p, (size_t)256 * 1024 * 8);
     A.get(&m->p_w2s, (size_t)DP_NL * DP_W2S_U4 * 16); A.get(&m->p_w13p, (size_t)DP_NL * DP_W13P_U4 * 16);
     A.get(&m->p_wsm, (size_t)DP_NL * DP_WSM_ROWS * DP_D * 2); A.get(&m->p_norms, (size_t)DP_NL * 2 * DP_D * 2);
-    if (!A.ok) { A.drop(); m->p_state = nullptr; note_fallback("persistent depth decoder", "allocation failed"); return; }
+    if (!A.ok) { A.drop(); note_fallback("persistent depth decoder", "allocation failed"); return; }
     bool ok = true;
     for (int l = 0; l < DP_NL && ok; ++l) {
         const CsmLayerWeights& lw = m->w.dec[l];
@@ -1041,7 +1078,7 @@ static void setup_persist(CsmModel* m) {
         ok = ok && hipMemcpy(m->p_norms + (size_t)(2 * l + 1) * DP_D, lw.mlp_norm, (size_t)DP_D * 2, hipMemcpyDeviceToDevice) == hipSuccess;
     }
     ok = ok && hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); A.drop(); m->p_state = nullptr; note_fallback("persistent depth decoder", "weight re-tiling failed"); return; }
+    if (!ok) { (void)hipGetLastError(); A.drop(); note_fallback("persistent depth decoder", "weight re-tiling failed"); return; }
     { const char* e2 = getenv("CSM_PERSIST_TRICKLE"); m->p_trickle = e2 ? atoi(e2) : 8; }       // (swept 4..16 x 0..3 at the final state: 8 / 1)
     { const char* e2 = getenv("CSM_PERSIST_POLL"); m->p_poll = e2 ? atoi(e2) : 1; }
     m->persist = true;
@@ -1078,12 +1115,12 @@ static void setup_bb_block(CsmModel* m) {
     if (f8 && !want_layer) return;                       // the fp8 stream exists only in the one-launch layer (the three-launch block is bf16)
     if (!all_cu_launch_fits(k_bb_attn_block, 0, "one-launch backbone attention block")) return;
     OptAllocs A;
-    A.get(&m->bg_q, (size_t)DP_NREP * BB_NQKV_PAIRS * 8); A.get(&m->bg_a, (size_t)DP_NREP * 1024 * 8); A.get(&m->b_state, 16);
+    A.get(&m->bg_q, (size_t)DP_NREP * BB_NQKV_PAIRS * 8); A.get(&m->bg_a, (size_t)DP_NREP * 1024 * 8);
     A.get(&m->bg_s, (size_t)BB_NH * 8 * 72 * 8);
-    if (!A.ok || hipDeviceSynchronize() != hipSuccess) { A.drop(); m->b_state = nullptr; note_fallback("one-launch backbone attention block", "allocation failed"); return; }
+    if (!A.ok || hipDeviceSynchronize() != hipSuccess) { A.drop(); note_fallback("one-launch backbone attention block", "allocation failed"); return; }
     if (!want_layer) { m->bb_block = true; m->bb_allocs = A.ptrs; return; }
     const bool fits = f8 ? all_cu_launch_fits(k_bb_layer<true>, BL_LDS_BYTES, "one-launch backbone layer (fp8)") : all_cu_launch_fits(k_bb_layer<false>, BL_LDS_BYTES, "one-launch backbone layer");
-    if (!fits) { if (f8) { A.drop(); m->b_state = nullptr; } else { m->bb_block = true; m->bb_allocs = A.ptrs; } return; }
+    if (!fits) { if (f8) { A.drop(); } else { m->bb_block = true; m->bb_allocs = A.ptrs; } return; }
     const size_t per_layer = (size_t)256 * (f8 ? 2 : 4) * BB_D;
     OptAllocs L;
     L.get(&m->bg_h, (size_t)DP_NREP * 1024 * 8); L.get(&m->bg_p, (size_t)256 * 256 * 8 * 8);
@@ -1097,13 +1134,27 @@ static void setup_bb_block(CsmModel* m) {
     ok = ok && hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     if (!ok) {
         (void)hipGetLastError(); L.drop(); note_fallback("one-launch backbone layer", "allocation / weight re-tiling failed");
-        if (f8) { A.drop(); m->b_state = nullptr; } else { m->bb_block = true; m->bb_allocs = A.ptrs; }
+        if (f8) { A.drop(); } else { m->bb_block = true; m->bb_allocs = A.ptrs; }
         return;
     }
     m->bb_block = true;
     m->bb_allocs = A.ptrs;
     m->bb_allocs.insert(m->bb_allocs.end(), L.ptrs.begin(), L.ptrs.end());
     if (f8) { m->b_w2t8 = w2t; m->bb_layer8 = true; } else { m->b_w2t = w2t; m->bb_layer = true; }
+}
+
+static void setup_bb_attn_m(CsmModel* m) {
+    const char* ev = getenv("CSM_BB_ATTN_M");
+    const CsmLlamaDims& bc = m->cfg.backbone;
+    if ((ev && ev[0] == '0') || m->max_batch < 2 || bc.dim != BM_D || bc.n_heads != 32 || bc.n_kv_heads != 8 || (bc.n_layers & 1)) return;
+    if (!all_cu_launch_fits(k_bb_attn_m<1>, BM_LDS_BYTES, "batched backbone attention block") ||
+        !all_cu_launch_fits(k_bb_attn_m<2>, BM_LDS_BYTES, "batched backbone attention block")) return;
+    OptAllocs A;
+    A.get(&m->bm_xchg, (size_t)BM_XCHG_BYTES, 0xFF);
+    if (!A.ok || hipDeviceSynchronize() != hipSuccess) { A.drop(); m->bm_xchg = nullptr; note_fallback("batched backbone attention block", "allocation failed"); return; }
+    m->bb_attn_m = true;
+    { const char* e2 = getenv("CSM_BB_ATTN_M_MAX"); m->bm_max_rows = e2 ? atoi(e2) : 32; if (m->bm_max_rows > 32) m->bm_max_rows = 32; }
+    m->bb_allocs.insert(m->bb_allocs.end(), A.ptrs.begin(), A.ptrs.end());
 }
 
 extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_batch, int max_rows, int max_frames,
@@ -1178,6 +1229,8 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     ALLOC(m->rng, 16);
     ALLOC(m->dec_pos, (size_t)(ncb + 1) * 2 * max_batch * 4);
     ALLOC(m->slot_scratch, (size_t)max_batch * 4);
+    ALLOC(m->p_state, 16);
+    ALLOC(m->b_state, 16);
 #undef ALLOC
     // decoder positions: slot 0 = {0,1} pairs (first decoder call), slot k = k (one row per sequence)
     std::vector<int> dp((size_t)(ncb + 1) * 2 * max_batch);
@@ -1186,6 +1239,8 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     HIPCHK((CsmModel*)nullptr, hipMemcpy(m->dec_pos, dp.data(), dp.size() * 4, hipMemcpyHostToDevice));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->logits, 0, (size_t)max_batch * m->ldl * 2));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->rng, 0, 16));
+    HIPCHK((CsmModel*)nullptr, hipMemset(m->p_state, 0, 16));
+    HIPCHK((CsmModel*)nullptr, hipMemset(m->b_state, 0, 16));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->n_frames, 0, 16));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->cur_pos, 0, (size_t)max_batch * 4));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->eos_at, 0xff, (size_t)max_batch * 4));
@@ -1237,9 +1292,10 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     // ---- all-CU launches (persistent depth decoders, one-launch backbone layers): optional fast paths.  Anything that
     //      fails here (shape, device, occupancy, allocation) leaves the flag off and the launch chain in charge.
     m->persist = false; m->persist_m = false; m->p_stamps = nullptr; m->bb_block = false; m->bb_layer = false; m->persist_disabled = false; m->bb_disabled = false;
-    m->p_state = nullptr; m->b_state = nullptr;
+    m->bb_attn_m = false; m->bm_xchg = nullptr;
     setup_persist(m);
     setup_bb_block(m);
+    setup_bb_attn_m(m);
     *out = m;
     return CSM_OK;
 }
@@ -1251,7 +1307,7 @@ extern "C" void csm_destroy(csm_handle m) {
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     void* ptrs[] = {m->bb.kc, m->bb.vc, m->dec.kc, m->dec.vc, m->h, m->q, m->att, m->act, m->part, m->dec_in, m->proj_emb, m->slab,
                     m->hdec, m->qd, m->attd, m->actd, m->logits, m->frame, m->cur_tokens, m->cur_mask, m->cur_pos,
-                    m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos, m->slot_scratch, m->qkv0_tab};
+                    m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos, m->slot_scratch, m->p_state, m->b_state, m->qkv0_tab};
     for (void* p : ptrs) (void)hipFree(p);
     for (void* p : m->pk_allocs) (void)hipFree(p);
     for (void* p : m->persist_allocs) (void)hipFree(p);
@@ -1271,8 +1327,9 @@ __global__ void k_persist_recover(uint32_t* state) {
 extern "C" int csm_reset(csm_handle m, void* stream) {
     if (!m) return CSM_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    if (m->persist) hipLaunchKernelGGL(k_persist_recover, dim3(1), dim3(1), 0, st, m->p_state);
-    if (m->bb_block) hipLaunchKernelGGL(k_persist_recover, dim3(1), dim3(1), 0, st, m->b_state);
+    hipLaunchKernelGGL(k_persist_recover, dim3(1), dim3(1), 0, st, m->p_state);
+    hipLaunchKernelGGL(k_persist_recover, dim3(1), dim3(1), 0, st, m->b_state);
+    if (m->bb_attn_m) HIPCHK(m, hipMemsetAsync(m->bm_xchg, 0xFF, BM_XCHG_BYTES, st));     // (an aborted launch may have left half a layer in an exchange set)
     HIPCHK(m, hipMemsetAsync(m->n_frames, 0, 8, st));          // frame counter + position-overflow flag
     HIPCHK(m, hipMemsetAsync(m->cur_pos, 0, (size_t)m->max_batch * 4, st));
     HIPCHK(m, hipMemsetAsync(m->eos_at, 0xff, (size_t)m->max_batch * 4, st));
@@ -1311,9 +1368,8 @@ extern "C" int csm_depth(csm_handle m, int B, float temperature, int topk, const
     HIPCHK(m, run_depth(m, B, m->last_S, temperature, topk, forced, logits_out, noise, st));
     if (out_frame) {
         HIPCHK(m, hipMemcpyAsync(out_frame, m->frame, (size_t)B * m->cfg.n_codebooks * 4, hipMemcpyDeviceToDevice, st));
-        if (m->persist || m->bb_block) {
-            hipLaunchKernelGGL(k_invalidate_on_error, dim3(1), dim3(256), 0, st, out_frame, B * m->cfg.n_codebooks, m->persist ? m->p_state + 1 : nullptr,
-                               m->bb_block ? m->b_state + 1 : nullptr);
+        if (m->persist || m->bb_block || m->bb_attn_m) {
+            hipLaunchKernelGGL(k_invalidate_on_error, dim3(1), dim3(256), 0, st, out_frame, B * m->cfg.n_codebooks, m->p_state + 1, m->b_state + 1);
             HIPCHK(m, hipGetLastError());
         }
     }
@@ -1328,9 +1384,8 @@ extern "C" int csm_depth(csm_handle m, int B, float temperature, int topk, const
 extern "C" int csm_copy_frame(csm_handle m, int B, int32_t* out_frame, void* stream) {
     if (!m || !out_frame || B < 1 || B > m->max_batch) return fail(m, CSM_E_INVALID, "csm_copy_frame: bad argument");
     HIPCHK(m, hipMemcpyAsync(out_frame, m->frame, (size_t)B * m->cfg.n_codebooks * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    if (m->persist || m->bb_block) {      // (a frame step's k_advance has already turned an invalid frame into -1; this covers frames that were not committed)
-        hipLaunchKernelGGL(k_invalidate_on_error, dim3(1), dim3(256), 0, (hipStream_t)stream, out_frame, B * m->cfg.n_codebooks, m->persist ? m->p_state + 1 : nullptr,
-                           m->bb_block ? m->b_state + 1 : nullptr);
+    if (m->persist || m->bb_block || m->bb_attn_m) {      // (a frame step's k_advance has already turned an invalid frame into -1; this covers frames that were not committed)
+        hipLaunchKernelGGL(k_invalidate_on_error, dim3(1), dim3(256), 0, (hipStream_t)stream, out_frame, B * m->cfg.n_codebooks, m->p_state + 1, m->b_state + 1);
         HIPCHK(m, hipGetLastError());
     }
     return CSM_OK;
@@ -1443,7 +1498,7 @@ extern "C" int csm_prefill_slot(csm_handle m, int slot, const int32_t* tokens, c
     HIPCHK(m, hipGetLastError());
     HIPCHK(m, run_depth(m, 1, S, temperature, topk, nullptr, nullptr, nullptr, st));
     hipLaunchKernelGGL(k_stage_slot, dim3(1), dim3(64), 0, st, m->frame, m->cfg.n_codebooks, slot, m->max_batch, m->history, m->n_frames, m->max_frames,
-                       m->eos_at, m->cur_tokens, m->cur_mask, out_frame, m->persist ? m->p_state + 1 : nullptr, m->bb_block ? m->b_state + 1 : nullptr);
+                       m->eos_at, m->cur_tokens, m->cur_mask, out_frame, m->p_state + 1, m->b_state + 1);
     HIPCHK(m, hipGetLastError());
     if (m->host_frames == 0) m->host_frames = 1;
     m->have_last = true; m->last_S = 1;
@@ -1465,8 +1520,8 @@ extern "C" int csm_read_frames(csm_handle m, int B, int first, int n, int32_t* h
     uint32_t pcode = 0;
     HIPCHK(m, hipMemcpyAsync(&overflow, m->n_frames + 1, 4, hipMemcpyDeviceToHost, st));
     uint32_t bcode = 0;
-    if (m->persist) HIPCHK(m, hipMemcpyAsync(&pcode, m->p_state + 1, 4, hipMemcpyDeviceToHost, st));
-    if (m->bb_block) HIPCHK(m, hipMemcpyAsync(&bcode, m->b_state + 1, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(m, hipMemcpyAsync(&pcode, m->p_state + 1, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(m, hipMemcpyAsync(&bcode, m->b_state + 1, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(m, hipStreamSynchronize(st));
     if (bcode || pcode) {
         // The launch could not get its 256 workgroups resident together (another kernel holds compute units).  Frames since the last
@@ -1532,7 +1587,7 @@ extern "C" int csm_debug_persist_stamps(csm_handle m, uint64_t* host, int n_word
 extern "C" int csm_debug_fast_paths(csm_handle m) {
     if (!m) return 0;
     return (m->persist && !m->persist_disabled ? 1 : 0) | (m->persist_m && !m->persist_disabled ? 2 : 0) | (m->bb_block && !m->bb_disabled ? 4 : 0) |
-           (m->bb_layer && !m->bb_disabled ? 8 : 0) | (m->bb_layer8 && !m->bb_disabled ? 16 : 0);
+           (m->bb_layer && !m->bb_disabled ? 8 : 0) | (m->bb_layer8 && !m->bb_disabled ? 16 : 0) | (m->bb_attn_m && !m->bb_disabled ? 32 : 0);
 }
 
 // Times the two dominant launches of a decode step on the handle's CURRENT state, each `reps` times back to back between HIP events on

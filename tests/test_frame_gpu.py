@@ -1146,6 +1146,55 @@ def test_batched_persistent_decoder_vs_launch_chain(csm1b, monkeypatch, B):
     assert n_idx <= 0.03 * 3 * 32 * B + 1, "too many greedy picks differ between the two decoder paths"
 
 
+@pytest.mark.parametrize("B", [2, 3, 16, 17, 32])
+def test_batched_backbone_attention_block_vs_launch_chain(csm1b, monkeypatch, B):
+    """Batched decode steps run q|k|v -> attention -> o-projection of every backbone layer as ONE launch (csrc/bb_attn_m.cuh)
+    instead of four (B = 2: instead of three GEMV launches).  Same rounding points, different fp32 summation orders.  Rows sit at
+    DIFFERENT positions (each utterance of a batch has its own), decode rows are teacher-forced: after every step the logits of
+    all 32 codebooks must agree with the launch chain's within the oracle's own bf16-vs-fp32 gap (a backbone difference travels
+    through 16 layers: the batch-1 block measures 0.065 against its chain the same way), greedy picks may differ
+    only at near-ties, and the K / V the launch appended must serve the following steps (three steps in a row)."""
+    import bench
+    from oracle import csm_ref as C
+    from sesameai.models import Model, csm_1b_args
+    gold, sd = csm1b
+    noise = float(gold["bf16_vs_fp32_gap"].max())
+    tok, msk = bench.synthetic_prompt(_bench_args(), B, C.csm_1b().text_vocab_size, seed0=8000)
+    tok, msk = tok[:, :40], msk[:, :40]
+    S = tok.shape[1]
+    g = torch.Generator().manual_seed(B)
+    forced = torch.randint(0, 2048, (3, B, 32), generator=g)
+    base = torch.tensor([S - (b * 5) % 23 for b in range(B)])                   # per-row positions: S, S-5, S-10, ...
+    outs = {}
+    for name, env in (("fused", "1"), ("chain", "0")):
+        monkeypatch.setenv("CSM_BB_ATTN_M", env)
+        m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S)
+        m.setup_caches(B)
+        assert bool(m.fast_paths() & 32) == (env == "1")
+        m.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+        per = []
+        for f in range(3):
+            row = torch.zeros(B, 1, 33, dtype=torch.long); row[:, 0, :32] = forced[f]
+            rmask = torch.ones(B, 1, 33, dtype=torch.bool); rmask[:, 0, 32] = False
+            m.prefill(row, rmask, (base + f).unsqueeze(1))                       # one decode row per utterance, each at its own position
+            out, logits = m.depth(B, 1.0, 1, forced=forced[f], want_logits=True, commit=False)
+            per.append((out.cpu(), logits.float().cpu()))
+        m.read_frames(B)                                                         # raises if a launch gave up
+        outs[name] = per
+        del m
+    worst, n_idx = 0.0, 0
+    for f in range(3):
+        (of, lf), (oc, lc) = outs["fused"][f], outs["chain"][f]
+        worst = max(worst, (lf - lc).abs().max().item())
+        top2 = torch.topk(lc, 2, dim=-1)[0]
+        for b, cb in (of != oc).nonzero().tolist():
+            n_idx += 1
+            assert float(top2[cb, b, 0] - top2[cb, b, 1]) <= 2 * noise, f"step {f} utterance {b} codebook {cb}: greedy index differs away from a tie"
+    print(f"batched backbone attention block vs chain, B={B}: max|dlogit| = {worst:.4f} (oracle noise floor {noise:.4f}); {n_idx} of {3 * 32 * B} greedy indices differ")
+    assert worst <= noise
+    assert n_idx <= 0.05 * 3 * 32 * B + 1
+
+
 _FAULT_SCRIPT = r"""
 import os, sys, time
 os.environ["CSM_HIP_TIMELINE"] = "1"          # the library build that carries the fault-injection hook
