@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512) void k_bb_attn_m(const BbAttnMArgs a) {
         // K / V rows of keys 0..p-1, requested now (they do not depend on this step; the q|k|v exchange takes longer than they do to arrive):
         // keys 32 j + 8 gw + slot, 16-byte piece e8 of each 128-byte row.  (Requested before the normalisation above they spilled: 96 registers
         // beside its 64.)
-        p_own = min(max(a.pos[ob], 0), a.smax - 1);
+        p_own = min(max((int)dp_sload32(a.pos + ob), 0), a.smax - 1);
         kb = a.kc + ((long)ob * 8 + kvh) * a.smax * 64;
         vb = a.vc + ((long)ob * 8 + kvh) * a.smax * 64;
 #pragma unroll

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(512) void k_bb_attn_block(const BbBlockArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) g[i] = reinterpret_cast<const uint4*>(a.sa_norm)[i * 64 + lane];
     const int orow = 8 * cu + wave;
-    const bf16_t hres = a.h[orow];
+    const uint32_t hres2 = dp_sload32(a.h + (orow & ~1));
+    const bf16_t hres = (bf16_t)((orow & 1) ? hres2 >> 16 : hres2 & 0xffffu);
     const int pair = 6 * cu + wave;                                   // waves 0..5: rows 2 pair, 2 pair + 1 of [q; k; v]
     const int R0 = 2 * (wave < 6 ? pair : 0);
     const bf16_t* wr = R0 < 2048 ? a.wq + (long)R0 * BB_D : R0 < 2560 ? a.wk + (long)(R0 - 2048) * BB_D : a.wv + (long)(R0 - 2560) * BB_D;
@@ -90,11 +91,11 @@ __global__ __launch_bounds__(512) void k_bb_attn_block(const BbBlockArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) wo[i] = ldg16<true>(reinterpret_cast<const uint4*>(a.wo + (long)orow * BB_D) + i * 64 + lane);
-    const uint32_t base = *a.epoch;
-    const int p = min(max(*a.pos, 0), a.smax - 1);
+    const uint32_t base = dp_sload32(a.epoch);
+    const int p = min(max((int)dp_sload32(a.pos), 0), a.smax - 1);
     // (cos, sin) of this wave's pair at position p
     const int e0 = R0 % BB_HD;
-    const uint32_t cs = reinterpret_cast<const uint32_t*>(a.rope)[(long)p * (BB_HD / 2) + e0 / 2];
+    const uint32_t cs = dp_sload32(reinterpret_cast<const uint32_t*>(a.rope) + (long)p * (BB_HD / 2) + e0 / 2);
     // attention CUs: K / V rows of keys 0..p-1 of this head's KV group.  Load j of wave w: keys 64 j + 8 w + (lane >> 3),
     // 16-byte piece lane & 7 of each 128-byte row (8 rows = one contiguous 1 KB per wave load)
     // Short contexts: head h = CU h walks all its keys (one hand-off less).  From BB_KMAX keys on the range is split over 8 CUs
@@ -383,12 +384,15 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) g[i] = reinterpret_cast<const uint4*>(a.sa_norm)[xi(i)];
     const int orow = 8 * cu + 2 * (wave & 3);                         // waves 0..3: output rows orow, orow + 1
-    const uint32_t hres = *reinterpret_cast<const uint32_t*>(a.h + orow);
+    const uint32_t hres = dp_sload32(a.h + orow);
     const int pair = 6 * cu + wave;                                   // waves 0..5: rows 2 pair, 2 pair + 1 of [q; k; v]
     const int R0 = 2 * (wave < 6 ? pair : 0);
     constexpr int EB = F8 ? 1 : 2;                                      // bytes per weight
     const int rq = R0 < 2048 ? R0 : R0 < 2560 ? R0 - 2048 : R0 - 2560;  // row inside its matrix
-    const char* wr = (const char*)(R0 < 2048 ? a.wq : R0 < 2560 ? a.wk : a.wv) + (long)rq * BB_D * EB;
+    // (this exact form -- a select between three complete addresses.  Selecting the base first and adding the row offset after it, the
+    //  same addresses, made the launch 2 us slower: 32.2 against 29.9 us per layer, A/B on one box, round 3)
+    const char* wr = R0 < 2048 ? (const char*)a.wq + (long)R0 * BB_D * EB : R0 < 2560 ? (const char*)a.wk + (long)(R0 - 2048) * BB_D * EB
+                                                                                      : (const char*)a.wv + (long)(R0 - 2560) * BB_D * EB;
     float sc0 = 1.f, sc1 = 1.f, so0 = 1.f, so1 = 1.f;                   // F8: the rows' scales
     if (F8 && wave < 6) { const float* sp = R0 < 2048 ? a.sq : R0 < 2560 ? a.sk : a.sv; sc0 = sp[rq]; sc1 = sp[rq + 1]; }
     if (F8 && wave < 4) { so0 = a.so[orow]; so1 = a.so[orow + 1]; }
@@ -402,11 +406,11 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) { wo[i] = ldg16<true>(reinterpret_cast<const uint4*>((const char*)a.wo + (long)orow * BB_D * EB) + i * 64 + lane); wo1[i] = ldg16<true>(reinterpret_cast<const uint4*>((const char*)a.wo + (long)(orow + 1) * BB_D * EB) + i * 64 + lane); }
     }
-    const uint32_t base = *a.epoch;
-    const int p = min(max(*a.pos, 0), a.smax - 1);
+    const uint32_t base = dp_sload32(a.epoch);
+    const int p = min(max((int)dp_sload32(a.pos), 0), a.smax - 1);
     // (cos, sin) of this wave's pair at position p
     const int e0 = R0 % BB_HD;
-    const uint32_t cs = reinterpret_cast<const uint32_t*>(a.rope)[(long)p * (BB_HD / 2) + e0 / 2];
+    const uint32_t cs = dp_sload32(reinterpret_cast<const uint32_t*>(a.rope) + (long)p * (BB_HD / 2) + e0 / 2);
     // attention CUs: K / V rows of keys 0..p-1 of this head's KV group.  Load j of wave w: keys 64 j + 8 w + (lane >> 3),
     // 16-byte piece lane & 7 of each 128-byte row (8 rows = one contiguous 1 KB per wave load)
     // Short contexts: head h = CU h walks all its keys (one hand-off less).  From BB_KMAX keys on the range is split over 8 CUs
@@ -423,10 +427,7 @@ __global__ __launch_bounds__(512) void k_bb_layer(const BbLayerArgs a) {
         return ldg16<true>(reinterpret_cast<const uint4*>((const char*)(gq ? a.w3 : a.w1) + prow * BB_D * EB) + c * 64 + lane);
     };
     // all (gate, up) pieces of pairs 0..2 of this wave into buf, in the order (pair, gate | up, chunk)
-    auto load_buf = [&]() {
-#pragma unroll
-        for (int q = 0; q < 6 * NW; ++q) buf[q] = load_gu(q / (2 * NW), (q / NW) & 1, q % NW);
-    };
+#define load_buf() do { _Pragma("unroll") for (int q = 0; q < 6 * NW; ++q) buf[q] = load_gu(q / (2 * NW), (q / NW) & 1, q % NW); } while (0)
     if (attn_cu) {
         const int kvh = head / (BB_NH / BB_NKV);
         const bf16_t* kb = a.kc + (long)kvh * a.smax * BB_HD;

@@ -14,6 +14,7 @@
 
 #include "../../include/csm_hip.h"
 #include "../../include/csm_hip_ops.h"
+#define CSM_DEC_PERSIST_ELSEWHERE    /* k_dec_persist: csm_dec_persist.hip */
 #include "attn.cuh"
 #include "gemv.cuh"
 #include "mm.cuh"
@@ -106,6 +107,7 @@ struct CsmModel {
     int pm_trickle;                     // its weight-trickle nap (env CSM_PERSIST_M_TRICKLE; swept 2..16 x poll 0..4 at B = 4 and 32: 4)
     dp_u64* p_stamps;                   // debug timeline (csm_debug_persist_stamps), else nullptr
     std::vector<void*> persist_allocs, bb_allocs;   // device memory of the optional all-CU launches
+    char* xslab; size_t xslab_used, xslab_align;     // the small exchange buffers of the B = 1 all-CU launches live in one 2 MB-aligned slab (placement under our control)
     bool persist_disabled, bb_disabled;             // a launch gave up once: the chain runs from then on (the buffers stay: error words are still read)
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
     int last_S;                         // rows per sequence of the h buffer feeding csm_depth
@@ -748,8 +750,7 @@ static hipError_t launch_dec_persist(CsmModel* m, int B, float temperature, int 
         p.stamps = m->p_stamps;
         { static int faults_left = getenv("CSM_PERSIST_FAULT") ? atoi(getenv("CSM_PERSIST_FAULT")) : 0;     // timeline build: the first n launches withhold a granule
           p.fault = faults_left > 0 ? 1 : 0; if (faults_left > 0) --faults_left; }
-        hipLaunchKernelGGL(k_dec_persist, dim3(DP_NB), dim3(512), DP_LDS_BYTES, st, p);
-        return hipGetLastError();
+        return csm_launch_dec_persist(p, st);
     }
     DecPersistMArgs p;
     memset(&p, 0, sizeof p);
@@ -1014,6 +1015,7 @@ static hipError_t build_qkv0_table(CsmModel* m) {
 // ---------------------------------------------------------------------------------------
 // optional all-CU launches: set-up that may fail without failing csm_create
 // ---------------------------------------------------------------------------------------
+#define XSLAB_BYTES ((size_t)4 << 20)
 struct OptAllocs {                                   // allocations of one optional block: freed together when the block is abandoned
     std::vector<void*> ptrs;
     bool ok = true;
@@ -1025,6 +1027,13 @@ struct OptAllocs {                                   // allocations of one optio
         ptrs.push_back(v); *p = (T*)v;
     }
     void drop() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }
+    // a small exchange buffer, carved from the model's slab (zero-filled at creation; never freed on its own)
+    template <class T> void small(CsmModel* m, T** p, size_t bytes) {
+        if (m->xslab == nullptr) { get(p, bytes); return; }
+        const size_t al = m->xslab_align, off = (m->xslab_used + al - 1) / al * al;
+        if (off + bytes > XSLAB_BYTES) { get(p, bytes); return; }
+        *p = (T*)(m->xslab + off); m->xslab_used = off + bytes;
+    }
 };
 static void note_fallback(const char* what, const char* why) {
     if (getenv("CSM_QUIET") == nullptr) fprintf(stderr, "libcsm_hip: %s disabled (%s): the launch chain runs instead\n", what, why);
@@ -1056,10 +1065,10 @@ static void setup_persist(CsmModel* m) {
     // (fp8 mode too: the launch streams the bf16 weights, which there ARE the dequantised e4m3 values -- byte * scale is
     //  exactly a bf16 -- so it computes what the fp8 chain computes; the decoder is bound by its hand-offs, not by bytes)
     if ((ev && ev[0] == '0') || !shape_ok || m->qkv0_tab == nullptr) return;
-    if (!all_cu_launch_fits(k_dec_persist, DP_LDS_BYTES, "persistent depth decoder")) return;
+    if (!all_cu_launch_fits(csm_dec_persist_kernel(), DP_LDS_BYTES, "persistent depth decoder")) return;
     OptAllocs A;
-    A.get(&m->pg_q, (size_t)DP_NREP * 768 * 8); A.get(&m->pg_h1, (size_t)DP_NREP * 512 * 8); A.get(&m->pg_h2, (size_t)DP_NREP * 512 * 8);
-    A.get(&m->pg_l, (size_t)DP_NREP * DP_LSLOTS * 8); A.get(&m->pg_p, (size_t)256 * 1024 * 8);
+    A.small(m, &m->pg_q, (size_t)DP_NREP * 768 * 8); A.small(m, &m->pg_h1, (size_t)DP_NREP * 512 * 8); A.small(m, &m->pg_h2, (size_t)DP_NREP * 512 * 8);
+    A.small(m, &m->pg_l, (size_t)DP_NREP * DP_LSLOTS * 8); A.get(&m->pg_p, (size_t)256 * 1024 * 8);
     A.get(&m->p_w2s, (size_t)DP_NL * DP_W2S_U4 * 16); A.get(&m->p_w13p, (size_t)DP_NL * DP_W13P_U4 * 16);
     A.get(&m->p_wsm, (size_t)DP_NL * DP_WSM_ROWS * DP_D * 2); A.get(&m->p_norms, (size_t)DP_NL * 2 * DP_D * 2);
     if (!A.ok) { A.drop(); note_fallback("persistent depth decoder", "allocation failed"); return; }
@@ -1115,15 +1124,15 @@ static void setup_bb_block(CsmModel* m) {
     if (f8 && !want_layer) return;                       // the fp8 stream exists only in the one-launch layer (the three-launch block is bf16)
     if (!all_cu_launch_fits(k_bb_attn_block, 0, "one-launch backbone attention block")) return;
     OptAllocs A;
-    A.get(&m->bg_q, (size_t)DP_NREP * BB_NQKV_PAIRS * 8); A.get(&m->bg_a, (size_t)DP_NREP * 1024 * 8);
-    A.get(&m->bg_s, (size_t)BB_NH * 8 * 72 * 8);
+    A.small(m, &m->bg_q, (size_t)DP_NREP * BB_NQKV_PAIRS * 8); A.small(m, &m->bg_a, (size_t)DP_NREP * 1024 * 8);
+    A.small(m, &m->bg_s, (size_t)BB_NH * 8 * 72 * 8);
     if (!A.ok || hipDeviceSynchronize() != hipSuccess) { A.drop(); note_fallback("one-launch backbone attention block", "allocation failed"); return; }
     if (!want_layer) { m->bb_block = true; m->bb_allocs = A.ptrs; return; }
     const bool fits = f8 ? all_cu_launch_fits(k_bb_layer<true>, BL_LDS_BYTES, "one-launch backbone layer (fp8)") : all_cu_launch_fits(k_bb_layer<false>, BL_LDS_BYTES, "one-launch backbone layer");
     if (!fits) { if (f8) { A.drop(); } else { m->bb_block = true; m->bb_allocs = A.ptrs; } return; }
     const size_t per_layer = (size_t)256 * (f8 ? 2 : 4) * BB_D;
     OptAllocs L;
-    L.get(&m->bg_h, (size_t)DP_NREP * 1024 * 8); L.get(&m->bg_p, (size_t)256 * 256 * 8 * 8);
+    L.small(m, &m->bg_h, (size_t)DP_NREP * 1024 * 8); L.get(&m->bg_p, (size_t)256 * 256 * 8 * 8);
     uint4* w2t = nullptr;
     L.get(&w2t, per_layer * 16 * bc.n_layers);
     bool ok = L.ok;
@@ -1297,6 +1306,19 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     //      fails here (shape, device, occupancy, allocation) leaves the flag off and the launch chain in charge.
     m->persist = false; m->persist_m = false; m->p_stamps = nullptr; m->bb_block = false; m->bb_layer = false; m->persist_disabled = false; m->bb_disabled = false;
     m->bb_attn_m = false; m->bm_xchg = nullptr;
+    // the B = 1 launches' small exchange buffers (granule replicas: 18..96 KB each) come from ONE 2 MB-aligned slab at 4 KB steps instead of
+    // wherever hipMalloc's sub-allocator has room -- same placement in every process (A/B: k_bb_layer 32.2..32.8 -> 31.9 us before the
+    // scalar-load fix, within the noise after it; kept for the determinism).  CSM_XSLAB=0: separate allocations.
+    m->xslab = nullptr; m->xslab_used = 0; m->xslab_align = 4096;
+    {
+        const char* ev = getenv("CSM_XSLAB");
+        const bool want = !(ev && ev[0] == '0');
+        if (want && (hipMalloc((void**)&m->xslab, XSLAB_BYTES) != hipSuccess || hipMemset(m->xslab, 0, XSLAB_BYTES) != hipSuccess)) {
+            (void)hipGetLastError();
+            if (m->xslab) (void)hipFree(m->xslab);
+            m->xslab = nullptr;
+        }
+    }
     setup_persist(m);
     setup_bb_block(m);
     setup_bb_attn_m(m);
@@ -1314,6 +1336,7 @@ extern "C" void csm_destroy(csm_handle m) {
                     m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos, m->slot_scratch, m->p_state, m->b_state, m->qkv0_tab};
     for (void* p : ptrs) (void)hipFree(p);
     for (void* p : m->pk_allocs) (void)hipFree(p);
+    if (m->xslab) (void)hipFree(m->xslab);
     for (void* p : m->persist_allocs) (void)hipFree(p);
     for (void* p : m->bb_allocs) (void)hipFree(p);
     if (m->p_stamps) (void)hipFree(m->p_stamps);

@@ -52,6 +52,15 @@ typedef __attribute__((address_space(3))) volatile uint32_t dp_lvu32;
 typedef __attribute__((address_space(3))) u32x4_t dp_lu4;
 typedef __attribute__((address_space(3))) unsigned short dp_lu16;
 typedef __attribute__((address_space(3))) float dp_lf32;
+// One uniform dword through the SCALAR cache (s_load_dword), whatever the compiler concludes about aliasing.  A plain `*p` of a
+// wave-uniform address becomes s_load_dword only when hipcc can prove that nothing in the kernel wrote the location before; when it
+// cannot it emits global_load_dword, whose result comes back IN ORDER behind every weight load the wave has already issued -- the
+// backbone layer then sees its position / epoch / residual words several us late (measured: 32.2 instead of 29.9 us per launch,
+// flipped by an unrelated edit).  Use only for words no workgroup of the SAME launch writes before this read.
+typedef __attribute__((address_space(4))) const uint32_t dp_cu32;
+__device__ __forceinline__ uint32_t dp_sload32(const void* p) {
+    return *(dp_cu32*)(unsigned long long)p;
+}
 __device__ __forceinline__ uint4 dp_ldq(const dp_lu4* p) { const u32x4_t v = *p; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void dp_stq(dp_lu4* p, const uint4& v) { u32x4_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *p = t; }
 
@@ -624,7 +633,10 @@ __device__ __forceinline__ void dp_compute_wave(const DecPersistArgs& a, char* l
     }
 }
 
-__global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
+// (Emitted only by csm_dec_persist.hip -- a code object of its own: in the engine's 2.6 MB code object the same instructions ran 0.7 %
+//  slower, 2090-2105 against 2074-2093 us per launch, three A/B pairs on one box.  csm_engine.hip defines CSM_DEC_PERSIST_ELSEWHERE.)
+#ifndef CSM_DEC_PERSIST_ELSEWHERE
+static __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cu = blockIdx.x;
     const unsigned lane = threadIdx.x & 63;
@@ -660,7 +672,7 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
         if (threadIdx.x == 128) { misc[DP_M_SARG] = (uint32_t)a.V; misc[DP_M_SARG + 1] = __float_as_uint(a.temperature); misc[DP_M_SARG + 2] = (uint32_t)a.topk; misc[DP_M_SARG + 3] = a.noise != nullptr; }
     }
     __syncthreads();
-    const uint32_t base = *a.epoch;
+    const uint32_t base = dp_sload32(a.epoch);
     if (wave == 7) {
         // ------------------------------------------------------------------------------------------------ gather wave
         __builtin_amdgcn_s_setprio(2);
@@ -798,10 +810,11 @@ __global__ __launch_bounds__(512) void k_dec_persist(const DecPersistArgs a) {
     else dp_compute_wave<false, 3, 0>(a, lds, wave, lane, cu, base, ropev);
 #endif
 }
+#endif
 
 // W1, W3 [8192][1024] -> [256 cu][4 tiles][32 k steps][64 lanes] 16-byte operand pieces: tile q of workgroup cu holds the
 // gate rows (tile rows 0..7) and up rows (8..15) of pairs cu*32 + 8q .. + 7; lane l of step t: row l & 15, k = 32t + 8 (l >> 4)
-__global__ void k_dp_pack_gateup(const bf16_t* w1, const bf16_t* w3, uint4* out) {
+static __global__ void k_dp_pack_gateup(const bf16_t* w1, const bf16_t* w3, uint4* out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 256L * 4 * 32 * 64) return;
     const int lane = (int)(i & 63), t = (int)((i >> 6) & 31), q = (int)((i >> 11) & 3), c = (int)(i >> 13);
@@ -811,9 +824,13 @@ __global__ void k_dp_pack_gateup(const bf16_t* w1, const bf16_t* w3, uint4* out)
 }
 
 // W2 [1024][8192] -> [256 cu][4 k chunks][1024 rows] 16-byte pieces (workgroup cu's 32 columns, 8 at a time)
-__global__ void k_dp_retile_w2(const bf16_t* w2, uint4* w2s) {
+static __global__ void k_dp_retile_w2(const bf16_t* w2, uint4* w2s) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 256L * 4 * 1024) return;
     const int n = (int)(i % 1024), q = (int)((i / 1024) % 4), c = (int)(i / 4096);
     w2s[i] = *reinterpret_cast<const uint4*>(w2 + (long)n * DP_FFN + c * 32 + q * 8);
 }
+
+// the launch, from the translation unit that holds the kernel (csm_dec_persist.hip)
+hipError_t csm_launch_dec_persist(const DecPersistArgs& p, hipStream_t st);
+const void* csm_dec_persist_kernel();           // for hipFuncSetAttribute / the occupancy query

@@ -10,7 +10,7 @@
 // slot order, one bf16 rounding.  Masked-out slots are skipped (the reference looks them up
 // and multiplies by 0).  grid = M rows, block = 256, 8 columns per thread.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_embed_sum(const int* tokens /*[M][33]*/, const uint8_t* mask /*[M][33]*/,
+static __global__ __launch_bounds__(256) void k_embed_sum(const int* tokens /*[M][33]*/, const uint8_t* mask /*[M][33]*/,
                                                    const bf16_t* text_emb, const bf16_t* audio_emb,
                                                    int audio_vocab, int text_vocab, int ncb, int d,
                                                    bf16_t* h /*[M][d]*/) {
@@ -436,7 +436,7 @@ struct AdvanceArgs {
     const uint32_t *err0, *err1;   // optional give-up words of the all-CU launches: non-zero -> this frame's codes are invalid, recorded as -1
 };
 
-__global__ __launch_bounds__(256) void k_advance(const AdvanceArgs a) {
+static __global__ __launch_bounds__(256) void k_advance(const AdvanceArgs a) {
     __shared__ int nz[256];                         // per-sequence count of non-zero codes (B <= 256)
     const int n = *a.n_frames;
     const bool bad = (a.err0 != nullptr && *a.err0 != 0u) || (a.err1 != nullptr && *a.err1 != 0u);
