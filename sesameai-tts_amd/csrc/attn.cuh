@@ -23,7 +23,17 @@ struct AttnArgs {
     bf16_t* out;            // [M][H*HD]                 (nsplit == 1)
     float* part;            // [M][H][nsplit][HD + 4]    (nsplit  > 1): o[HD], m, l
     int out_packed;         // out in matrix-core operand order (common.cuh xp_off), K = H*HD
+    int* ctr;               // nsplit > 1: [M][KV] arrival counters (zero between launches) -> the LAST key-range block of a
+                            // (row, KV head) merges the partials itself (no k_attn_combine launch); nullptr: partials only
 };
+
+#define ATTN_MAX_SPLIT 8            // key ranges per (row, KV head) the in-kernel merge handles (csm_engine.hip BB_NSPLIT_MAX)
+__device__ __forceinline__ void attn_st16_sc1(float* p, const float4& v) {
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void attn_st4_sc1(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 
 // U = key rows per lane in flight per batch (hd 128 / depth decoder: 8, so its <= 32 keys are ONE round trip)
 template <int HD, int U = 4>
@@ -102,10 +112,58 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
                 *reinterpret_cast<uint4*>(dst) = r;
             } else {
                 float* dst = a.part + (((long)m * a.H + h) * a.nsplit + sp) * (HD + 4);
-                *reinterpret_cast<float4*>(dst + e * 8) = make_float4(o[0], o[1], o[2], o[3]);
-                *reinterpret_cast<float4*>(dst + e * 8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
-                if (e == 0) { dst[HD] = mx; dst[HD + 1] = l; }
+                if (a.ctr != nullptr) {           // merged in this launch by a block that may sit on another XCD: write through (sc1)
+                    attn_st16_sc1(dst + e * 8, make_float4(o[0], o[1], o[2], o[3]));
+                    attn_st16_sc1(dst + e * 8 + 4, make_float4(o[4], o[5], o[6], o[7]));
+                    if (e == 0) { attn_st4_sc1(dst + HD, mx); attn_st4_sc1(dst + HD + 1, l); }
+                } else {
+                    *reinterpret_cast<float4*>(dst + e * 8) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4*>(dst + e * 8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                    if (e == 0) { dst[HD] = mx; dst[HD + 1] = l; }
+                }
             }
+        }
+    }
+    if (a.nsplit > 1 && a.ctr != nullptr) {
+        // The last of the nsplit blocks of this (row, KV head) to get here merges: k_attn_combine's arithmetic in k_attn_combine's
+        // order (same bits), one launch less per layer.  No block waits for another (the merge is done by whoever comes last), so
+        // nothing depends on the blocks being resident together.  The partials travel like the persistent launches' exchanges:
+        // write-through stores, acknowledged (vmcnt 0) before the arrival is counted, read back with L2-bypassing loads -- agent-scope
+        // fences instead cost a whole-L2 write-back per block (measured: +58 us per layer at 32 rows).
+        __shared__ int s_ticket;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(a.ctr + m * a.KV + kvh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ticket != a.nsplit - 1) return;
+        if (threadIdx.x == 0) a.ctr[m * a.KV + kvh] = 0;                 // for the next launch (ordered by the kernel boundary)
+        for (int idx = threadIdx.x; idx < G * HD; idx += 256) {
+            const int h = kvh * G + idx / HD, t = idx % HD;
+            const float* src = a.part + ((long)m * a.H + h) * a.nsplit * (HD + 4);
+            float ms[ATTN_MAX_SPLIT], ls[ATTN_MAX_SPLIT], vs[ATTN_MAX_SPLIT];
+#pragma unroll
+            for (int s = 0; s < ATTN_MAX_SPLIT; ++s) {                   // every load in flight at once (splits past nsplit re-read the last one)
+                const float* ps = src + min(s, a.nsplit - 1) * (HD + 4);
+                asm volatile("global_load_dword %0, %1, off sc1" : "=v"(ms[s]) : "v"(ps + HD) : "memory");
+                asm volatile("global_load_dword %0, %1, off sc1" : "=v"(ls[s]) : "v"(ps + HD + 1) : "memory");
+                asm volatile("global_load_dword %0, %1, off sc1" : "=v"(vs[s]) : "v"(ps + t) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < ATTN_MAX_SPLIT; ++s) asm volatile("" : "+v"(ms[s]), "+v"(ls[s]), "+v"(vs[s]));
+            float mxx = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < ATTN_MAX_SPLIT; ++s) if (s < a.nsplit) mxx = fmaxf(mxx, ms[s]);
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int s = 0; s < ATTN_MAX_SPLIT; ++s) {
+                if (s < a.nsplit) {
+                    const float w = (ms[s] == -INFINITY) ? 0.f : __expf(ms[s] - mxx);
+                    num += w * vs[s];
+                    den += w * ls[s];
+                }
+            }
+            a.out[a.out_packed ? xp_off(m, h * HD + t, (long)a.H * HD) : ((long)m * a.H + h) * HD + t] = f2bf(num / den);
         }
     }
 }

@@ -57,6 +57,7 @@ struct CsmModel {
     bf16_t *h, *q, *att, *act;          // backbone rows [max_rows][..]
     float* part;                        // [max(PART_ROWS, max_batch)][H][NSPLIT][hd+4] split-K attention partials
     int part_rows;
+    int* attn_ctr;                      // [part_rows][KV heads] arrival counters of the split-K attention's in-kernel merge (attn.cuh); nullptr: CSM_ATTN_MERGE=0
     bf16_t *dec_in;                     // [B][2][d_bb]   row0 = last_h, row1 = c0 embedding
     float* slab;                        // [8][max_rows][max(d_bb, d_dec)] fp32 split-K partials of the wide path
     bf16_t *pk_projection, *pk_c0_head, *pk_audio_head;   // packed copies for the wide-M path
@@ -374,7 +375,7 @@ static hipError_t launch_attn(int hd, const AttnArgs& a, hipStream_t st, bool co
         else hipLaunchKernelGGL((k_attn<128>), grid, dim3(256), 0, st, a);
     }
     else return hipErrorInvalidValue;
-    if (a.nsplit > 1 && combine) {
+    if (a.nsplit > 1 && combine && a.ctr == nullptr) {
         if (hd == 64) hipLaunchKernelGGL((k_attn_combine<64>), dim3(a.M, a.H), dim3(64), 0, st, a.part, a.nsplit, a.out, a.H, a.out_packed);
         else hipLaunchKernelGGL((k_attn_combine<128>), dim3(a.M, a.H), dim3(128), 0, st, a.part, a.nsplit, a.out, a.H, a.out_packed);
     }
@@ -452,7 +453,7 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
             AttnArgs t;
             t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
             t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = 1;
-            t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part; t.out_packed = 0;
+            t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part; t.out_packed = 0; t.ctr = nullptr;
             if ((e = launch_attn_auto(S, t, prompt, st)) != hipSuccess) return e;
             memset(&a, 0, sizeof a);
             // residual projections: d/128 column tiles only -- below ~2 tiles per CU split K into its four quarters over
@@ -540,12 +541,13 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         AttnArgs t;
         t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
         t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = 1;
-        t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part; t.out_packed = xp;
+        t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part; t.out_packed = xp; t.ctr = nullptr;
         // batched backbone decode step (one row per sequence, long key ranges): a (row, KV head) block alone walks
         // its ~200+ keys in ~8 dependent round trips -- split the keys over up to 8 blocks like the B = 1 path
         if (!prompt && rows_per_seq == 1 && &S == &m->bb && M <= m->part_rows) {
             int ns = 1024 / (M * S.d.n_kv_heads);
             t.nsplit = ns < 1 ? 1 : (ns > BB_NSPLIT_MAX ? BB_NSPLIT_MAX : ns);
+            if (t.nsplit > 1) t.ctr = m->attn_ctr;            // the last key-range block of a (row, KV head) merges (no k_attn_combine launch)
         }
         if ((e = launch_attn_auto(S, t, prompt, st)) != hipSuccess) return e;
         // o-proj -> fp32 slabs; finisher: h += sum(slabs), xn = mlp_norm(h)
@@ -683,7 +685,7 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
             AttnArgs t;
             t.q = q; t.kcache = kc; t.vcache = vc; t.pos = pos; t.M = M; t.rows_per_seq = rows_per_seq;
             t.H = S.d.n_heads; t.KV = S.d.n_kv_heads; t.smax = S.cache_len; t.nsplit = nsplit;
-            t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part; t.out_packed = 0;
+            t.scale = 1.0f / sqrtf((float)S.hd); t.out = att; t.part = m->part; t.out_packed = 0; t.ctr = nullptr;
             fuse_comb = nsplit > 1 && S.hd == 64;
             if ((e = launch_attn(S.hd, t, st, !fuse_comb)) != hipSuccess) return e;
         }
@@ -1223,6 +1225,12 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     ALLOC(m->act, (size_t)max_rows * cfg->backbone.ffn * 2);
     m->part_rows = max_batch > PART_ROWS ? max_batch : PART_ROWS;
     ALLOC(m->part, (size_t)m->part_rows * cfg->backbone.n_heads * BB_NSPLIT_MAX * (m->bb.hd + 4) * 4);
+    m->attn_ctr = nullptr;
+    { const char* ev = getenv("CSM_ATTN_MERGE");
+      if (!(ev && ev[0] == '0')) {
+          ALLOC(m->attn_ctr, (size_t)m->part_rows * cfg->backbone.n_kv_heads * 4);
+          HIPCHK((CsmModel*)nullptr, hipMemset(m->attn_ctr, 0, (size_t)m->part_rows * cfg->backbone.n_kv_heads * 4));
+      } }
     ALLOC(m->dec_in, (size_t)max_batch * 2 * dbb * 2);
     ALLOC(m->proj_emb, (size_t)ncb * cfg->audio_vocab * dd * 2);
     ALLOC(m->slab, (size_t)8 * max_rows * (dbb > dd ? dbb : dd) * 4);
@@ -1331,7 +1339,7 @@ extern "C" void csm_destroy(csm_handle m) {
     if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
     if (m->graph) (void)hipGraphDestroy(m->graph);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
-    void* ptrs[] = {m->bb.kc, m->bb.vc, m->dec.kc, m->dec.vc, m->h, m->q, m->att, m->act, m->part, m->dec_in, m->proj_emb, m->slab,
+    void* ptrs[] = {m->bb.kc, m->bb.vc, m->dec.kc, m->dec.vc, m->h, m->q, m->att, m->act, m->part, m->attn_ctr, m->dec_in, m->proj_emb, m->slab,
                     m->hdec, m->qd, m->attd, m->actd, m->logits, m->frame, m->cur_tokens, m->cur_mask, m->cur_pos,
                     m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos, m->slot_scratch, m->p_state, m->b_state, m->qkv0_tab};
     for (void* p : ptrs) (void)hipFree(p);
@@ -1357,6 +1365,7 @@ extern "C" int csm_reset(csm_handle m, void* stream) {
     hipLaunchKernelGGL(k_persist_recover, dim3(1), dim3(1), 0, st, m->p_state);
     hipLaunchKernelGGL(k_persist_recover, dim3(1), dim3(1), 0, st, m->b_state);
     if (m->bb_attn_m) HIPCHK(m, hipMemsetAsync(m->bm_xchg, 0xFF, BM_XCHG_BYTES, st));     // (an aborted launch may have left half a layer in an exchange set)
+    if (m->attn_ctr) HIPCHK(m, hipMemsetAsync(m->attn_ctr, 0, (size_t)m->part_rows * m->cfg.backbone.n_kv_heads * 4, st));
     HIPCHK(m, hipMemsetAsync(m->n_frames, 0, 8, st));          // frame counter + position-overflow flag
     HIPCHK(m, hipMemsetAsync(m->cur_pos, 0, (size_t)m->max_batch * 4, st));
     HIPCHK(m, hipMemsetAsync(m->eos_at, 0xff, (size_t)m->max_batch * 4, st));
@@ -1721,7 +1730,7 @@ extern "C" int csm_op_attn(int M, int rows_per_seq, int H, int KV, int head_dim,
     t.q = (const bf16_t*)q; t.kcache = (const bf16_t*)kcache; t.vcache = (const bf16_t*)vcache; t.pos = pos; t.M = M;
     // nsplit == 0: the matrix-core prompt kernel (attn_flash.cuh; head_dim 64); nsplit >= 1: one row per block
     t.rows_per_seq = rows_per_seq; t.H = H; t.KV = KV; t.smax = smax; t.nsplit = nsplit < 1 ? 1 : nsplit;
-    t.scale = 1.0f / sqrtf((float)head_dim); t.out = (bf16_t*)out; t.part = part; t.out_packed = 0;
+    t.scale = 1.0f / sqrtf((float)head_dim); t.out = (bf16_t*)out; t.part = part; t.out_packed = 0; t.ctr = nullptr;
     hipError_t e;
     if (nsplit < 1) {
         if (head_dim != 64 || H % KV != 0 || (H / KV) % 4 != 0) return CSM_E_INVALID;

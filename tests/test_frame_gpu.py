@@ -1196,6 +1196,36 @@ def test_batched_backbone_attention_block_vs_launch_chain(csm1b, monkeypatch, B)
     assert n_idx <= 0.05 * 3 * 32 * B + 1
 
 
+@pytest.mark.parametrize("B", [3, 8, 32])
+def test_split_key_attention_merged_in_kernel_gives_the_merge_launch_bits(csm1b, monkeypatch, B):
+    """Batched backbone decode steps split a (row, KV head)'s keys over up to 8 workgroups (csrc/attn.cuh).  The last of them to finish
+    merges the partial softmax states itself (default) instead of a second launch (CSM_ATTN_MERGE=0): the same arithmetic in the same
+    order, so sampled frames AND logits must be bit-identical, at different positions per row and over several steps (the counters
+    must return to zero by themselves)."""
+    import bench
+    from oracle import csm_ref as C
+    from sesameai.models import Model, csm_1b_args
+    gold, sd = csm1b
+    tok, msk = bench.synthetic_prompt(_bench_args(), B, C.csm_1b().text_vocab_size, seed0=8100)
+    tok, msk = tok[:, :150], msk[:, :150]
+    S = tok.shape[1]
+    outs = {}
+    for env in ("1", "0"):
+        monkeypatch.setenv("CSM_ATTN_MERGE", env)
+        m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S)
+        m.setup_caches(B); m.seed(11)
+        m.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+        m.depth(B, 0.9, 50, commit=True)
+        for _ in range(5):
+            m.step(B, 0.9, 50)
+        frames, _ = m.read_frames(B)
+        _, logits = m.depth(B, 1.0, 1, want_logits=True, commit=False)
+        outs[env] = (frames.cpu(), logits.float().cpu())
+        del m
+    assert torch.equal(outs["1"][0], outs["0"][0])
+    assert torch.equal(outs["1"][1], outs["0"][1])
+
+
 _FAULT_SCRIPT = r"""
 import os, sys, time
 os.environ["CSM_HIP_TIMELINE"] = "1"          # the library build that carries the fault-injection hook
