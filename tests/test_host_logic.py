@@ -339,6 +339,35 @@ def test_generator_runs_to_the_length_limit_without_eos_and_streams_the_same_fra
     assert list(gen.generate_stream([1, 2, 3], 0, [], max_audio_length_ms=40 * 80)) == []
 
 
+def test_first_stream_chunk_is_decoded_before_more_frames_are_queued_and_the_next_block_before_the_user_gets_it():
+    """Time to first audio: the first block is exactly one buffer (frame 0 + 9 steps), nothing else is queued while it is decoded (the
+    decode would otherwise squeeze between frame steps whose persistent launches hold every CU), and the second block is queued before
+    the first chunk reaches the user (a user who plays each chunk before asking for the next must not starve the GPU)."""
+    from sesameai.generator import Generator
+    script = _scripted(64, 1, [None])
+    model = _ScriptedModel(script)
+    events = []
+    codec = _FakeCodec()
+    dec = codec.decode
+    codec.decode = lambda codes: (events.append(("decode", model.launched)), dec(codes))[1]
+    gen = Generator(model, audio_tokenizer=codec)
+    launched_when_user_got_chunk = []
+    for chunk in gen.generate_stream([1, 2, 3], 0, [], max_audio_length_ms=35 * 80):
+        launched_when_user_got_chunk.append(model.launched)
+    assert events[0] == ("decode", 10)                        # first decode: exactly 10 frames launched, none beyond
+    assert launched_when_user_got_chunk[0] == 20              # ... and the next block was queued before the user saw the chunk
+    assert events[1] == ("decode", 30)                        # steady state: the next block is queued before the current one is decoded
+    assert [e[0] for e in events] == ["decode"] * 4 and launched_when_user_got_chunk[-1] == 35
+    # generate_codes (nobody calls the release hook): same frames, the second block is queued when the first has been taken
+    model2 = _ScriptedModel(script)
+    gen2 = Generator(model2, audio_tokenizer=_FakeCodec())
+    seen = []
+    prompt = torch.zeros(5, 33, dtype=torch.long); mask = torch.zeros(5, 33, dtype=torch.bool)
+    frames = gen2.generate_codes(prompt, mask, 35, 0.9, 50, on_frames=lambda f: seen.append((f.shape[0], model2.launched)), poll=10)
+    assert frames.shape[0] == 35 and seen[0] == (10, 10) and seen[1] == (10, 30)
+    assert gen2._release_first_block is None
+
+
 class _ScriptedSlots:
     """Stands in for sesameai.models.Model under Generator.generate_codes_continuous: every prompt (identified by its first text
     token) has a scripted utterance; slots emit their utterance's next frame per step, all-zero frames once it is over, and the
