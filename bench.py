@@ -296,7 +296,7 @@ def extras_legs(args, margs, sd, dev):
     from sesameai.generator import Generator
     from sesameai.mimi import MimiArgs, MimiCodec
     n5 = 375
-    m5 = Model(margs, sd, device=str(dev), max_frames=n5 + 16, max_prefill_rows=S5, weights_dtype="fp8")
+    m5 = Model(margs, sd, device=str(dev), max_frames=n5 + 64, max_prefill_rows=S5, weights_dtype="fp8")
     codec = MimiCodec(MimiArgs(), None, device=str(dev), max_frames=n5 + 16)
     gen = Generator(m5, audio_tokenizer=codec)
     m5.seed(79); m5.prefix_reuse = False
@@ -318,6 +318,16 @@ def extras_legs(args, margs, sd, dev):
                      "wall_ms": round(wall_ms, 1), "first_chunk_ms": round(first_ms, 1), "frames": n_fr, "pcm_samples": pcm_n,
                      "end_to_end_rtf": round(n_fr * 80.0 / wall_ms, 2),
                      "roofline_frac_end_to_end": round(m5.bytes_per_frame(1, S5 + n_fr / 2.0) * n_fr / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    # the fp8 frame step alone, right after those 375 frames (positions ~1710-1750; `b1_long_context` times the bf16 step at
+    # ~1680-1720): the like-for-like comparison of the two weight streams -- the end-to-end figure above also holds the
+    # 1,334-row prefill and the codec
+    if m5.num_frames() + 40 <= n5 + 64:
+        ms8 = timed_steps(m5, 1, 40, T, K)
+        ex["config5"].update({"frame_step_ms": round(ms8, 4), "frame_step_rtf": round(80.0 / ms8, 2),
+                              "frame_step_positions": f"~{S5 + m5.num_frames() - 40}-{S5 + m5.num_frames()}",
+                              "frame_step_vs_bf16": {"bf16_ms_per_step": ex["b1_long_context"]["ms_per_step"], "fp8_ms_per_step": round(ms8, 4),
+                                                     "fp8_over_bf16_speed": round(ex["b1_long_context"]["ms_per_step"] / ms8, 4),
+                                                     "note": "like for like: frame steps only, fp8 ~30 positions later than bf16; end_to_end_rtf also holds the 1,334-row prefill and the codec"}})
     del gen, codec, m5
     # ---- config 5 at B = 32: fp8 weight stream, 32 x the 1334-row prompt, frames timed at positions ~1340-1380 ----
     B5 = 32

@@ -1090,8 +1090,8 @@ static void setup_persist(CsmModel* m) {
     }
     ok = ok && hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     if (!ok) { (void)hipGetLastError(); A.drop(); note_fallback("persistent depth decoder", "weight re-tiling failed"); return; }
-    { const char* e2 = getenv("CSM_PERSIST_TRICKLE"); m->p_trickle = e2 ? atoi(e2) : 8; }       // (swept 4..16 x 0..3 at the final state: 8 / 1)
-    { const char* e2 = getenv("CSM_PERSIST_POLL"); m->p_poll = e2 ? atoi(e2) : 1; }
+    { const char* e2 = getenv("CSM_PERSIST_TRICKLE"); m->p_trickle = e2 ? atoi(e2) : 8; }       // (swept 4..16 x 0..3 at round 2's final state: 8 / 1; re-swept in round 3: 8..10 / 0)
+    { const char* e2 = getenv("CSM_PERSIST_POLL"); m->p_poll = e2 ? atoi(e2) : 0; }             // (round 3, alternating A/B at the final state: 0 beats 1 by 17 us per frame, 2.744 against 2.762 ms)
     m->persist = true;
     m->persist_allocs = A.ptrs;
     // ---- the batched form (2..32 rows): shares the q|k|v|o rows and the norms, own packed MLP weights and exchange buffers ----
