@@ -77,19 +77,32 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const GemvArgs a, const int 
         }
         pb[i] = wsrc + (long)n * ldw + seg * 8;
     }
-    u32x4_t ra[4], rb[4];                 // compiler vector type: HIP's uint4 struct kept these in scratch memory
-#define G128_GLOAD(kc)                                                                   \
+    // TWO K slices in flight in registers (round 3): slice s + 2 is requested while slice s feeds the MFMAs and slice s + 1 (requested an
+    // iteration ago) is written to the idle LDS buffer.  With one slice in flight a block paid one memory round trip per 64-deep
+    // slice (32 slices x ~2 us at K = 2048: q|k|v 67 us for 17 GFLOP) -- latency, neither LDS nor matrix-core time.  The loop is
+    // unrolled by two so that the register set of a slice is a compile-time choice (a runtime index would put them in scratch).
+    u32x4_t ra[2][4], rb[2][4];           // compiler vector type: HIP's uint4 struct kept these in scratch memory
+    // (asm loads + hand-written waits: with plain loads hipcc's wait-count pass put vmcnt(0) at the loop header -- it waited for the
+    //  OLDER slice before requesting the next one, i.e. one slice in flight again.  Requests return in order, so "all but the 8
+    //  youngest" is exactly the older register set.  No scratch in these kernels (tools/kres.sh): an asm-loaded register that is
+    //  spilled before its wait would be saved with stale contents.)
+#define G128_GLOAD(set, kc)                                                              \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
-        ra[i] = *reinterpret_cast<const u32x4_t*>(pa[i] + (kc));                          \
-        rb[i] = *reinterpret_cast<const u32x4_t*>(pb[i] + (kc));                          \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[set][i]) : "v"(pa[i] + (kc)) : "memory"); \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[set][i]) : "v"(pb[i] + (kc)) : "memory"); \
+    }
+#define G128_ARRIVED(set, younger)                                                       \
+    {                                                                                    \
+        if (younger) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ra[set][i]), "+v"(rb[set][i])); \
     }
     // rows row0 + 32 i share (row >> 1) & 7, so one swizzled segment serves all four pieces
     const int wseg = seg ^ ((row0 >> 1) & 7);
     bf16_t* const wbase = lds + row0 * G128_LD + wseg * 8;
-#define G128_LWRITE(buf)                                                                 \
+#define G128_LWRITE(set, buf)                                                            \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
-        *reinterpret_cast<u32x4_t*>(wbase + (buf) * (256 * G128_LD) + (32 * i) * G128_LD) = ra[i];      \
-        *reinterpret_cast<u32x4_t*>(wbase + (buf) * (256 * G128_LD) + (128 + 32 * i) * G128_LD) = rb[i];  \
+        *reinterpret_cast<u32x4_t*>(wbase + (buf) * (256 * G128_LD) + (32 * i) * G128_LD) = ra[set][i];      \
+        *reinterpret_cast<u32x4_t*>(wbase + (buf) * (256 * G128_LD) + (128 + 32 * i) * G128_LD) = rb[set][i];  \
     }
     const int sw = (r >> 1) & 7;              // fragment rows are wm*64 + mi*32 + r: (row >> 1) & 7 == (r >> 1) & 7
 
@@ -102,41 +115,57 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const GemvArgs a, const int 
             for (int i = 0; i < 16; ++i) { tot[mi][ni][i] = 0.f; acc[mi][ni][i] = 0.f; }
 
     const int per_quarter = K / 256;
-    const int c_first = EPI == EPI_SLAB ? kq * per_quarter : 0, nk = EPI == EPI_SLAB ? c_first + per_quarter : K / 64;
-    G128_GLOAD(c_first * 64)
-    G128_LWRITE(c_first & 1)
-    __syncthreads();
+    const int c_first = EPI == EPI_SLAB ? kq * per_quarter : 0, ns = EPI == EPI_SLAB ? per_quarter : K / 64;   // slices c_first .. c_first + ns - 1
     int in_quarter = 0;
-    for (int c = c_first; c < nk; ++c) {
-        // unconditional (the last iteration re-loads its own slice into the idle buffer): no control flow around the
-        // register staging
-        if (DBG != 1) { G128_GLOAD(min(c + 1, nk - 1) * 64) }
-        const bf16_t* A = lds + (c & 1) * (256 * G128_LD) + (wm * 64 + r) * G128_LD;
-        const bf16_t* B = lds + (c & 1) * (256 * G128_LD) + (128 + wn * 64 + r) * G128_LD;
-#pragma unroll
-        for (int q = 0; q < (DBG == 2 ? 0 : 4); ++q) {
-            const int so = ((4 * h + q) ^ sw) * 8;
-            const u32x4_t a0 = *reinterpret_cast<const u32x4_t*>(A + so);
-            const u32x4_t a1 = *reinterpret_cast<const u32x4_t*>(A + 32 * G128_LD + so);
-            const u32x4_t b0 = *reinterpret_cast<const u32x4_t*>(B + so);
-            const u32x4_t b1 = *reinterpret_cast<const u32x4_t*>(B + 32 * G128_LD + so);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(b0), acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(b1), acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(b0), acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(b1), acc[1][1], 0, 0, 0);
-        }
-        if (++in_quarter == per_quarter) {                 // end of a K quarter: fold the partial, restart the chain
-            in_quarter = 0;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { tot[mi][ni][i] += acc[mi][ni][i]; acc[mi][ni][i] = 0.f; }
-        }
-        G128_LWRITE((c + 1) & 1)
+    // one slice from LDS buffer `buf`: the same MFMA chain per K quarter as before (k ascending; fold at the quarter's end)
+#define G128_MMA(buf)                                                                    \
+    {                                                                                    \
+        const bf16_t* A = lds + (buf) * (256 * G128_LD) + (wm * 64 + r) * G128_LD;       \
+        const bf16_t* B = lds + (buf) * (256 * G128_LD) + (128 + wn * 64 + r) * G128_LD; \
+        _Pragma("unroll") for (int q = 0; q < (DBG == 2 ? 0 : 4); ++q) {                 \
+            const int so = ((4 * h + q) ^ sw) * 8;                                       \
+            const u32x4_t a0 = *reinterpret_cast<const u32x4_t*>(A + so);                \
+            const u32x4_t a1 = *reinterpret_cast<const u32x4_t*>(A + 32 * G128_LD + so); \
+            const u32x4_t b0 = *reinterpret_cast<const u32x4_t*>(B + so);                \
+            const u32x4_t b1 = *reinterpret_cast<const u32x4_t*>(B + 32 * G128_LD + so); \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(b0), acc[0][0], 0, 0, 0); \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(b1), acc[0][1], 0, 0, 0); \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(b0), acc[1][0], 0, 0, 0); \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(b1), acc[1][1], 0, 0, 0); \
+        }                                                                                \
+        if (++in_quarter == per_quarter) {                 /* end of a K quarter: fold the partial, restart the chain */ \
+            in_quarter = 0;                                                              \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                             \
+                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                         \
+                    _Pragma("unroll") for (int i = 0; i < 16; ++i) { tot[mi][ni][i] += acc[mi][ni][i]; acc[mi][ni][i] = 0.f; } \
+        }                                                                                \
+    }
+    // (slices past the last one re-load the last one: no control flow around the register staging)
+#define G128_KOFF(s_) ((c_first + min((s_), ns - 1)) * 64)
+    G128_GLOAD(0, G128_KOFF(0))
+    G128_ARRIVED(0, false)
+    G128_LWRITE(0, 0)
+    G128_GLOAD(1, G128_KOFF(1))
+    __syncthreads();
+    // (sched_barrier: the requests leave before the MFMAs and the LDS writes come after them)
+    for (int s = 0; s < ns; s += 2) {
+        if (DBG != 1) { G128_GLOAD(0, G128_KOFF(s + 2)) }
+        __builtin_amdgcn_sched_barrier(0);
+        G128_MMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        G128_ARRIVED(1, DBG != 1)
+        G128_LWRITE(1, 1)                                  // slice s + 1, requested one step ago
+        __syncthreads();
+        if (s + 1 >= ns) break;
+        if (DBG != 1) { G128_GLOAD(1, G128_KOFF(s + 3)) }
+        __builtin_amdgcn_sched_barrier(0);
+        G128_MMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+        G128_ARRIVED(0, DBG != 1)
+        G128_LWRITE(0, 0)                                  // slice s + 2
         __syncthreads();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the re-loaded last slices: nothing may still be landing in registers the epilogue reuses)
     // epilogue: acc register i of lane (r, h) is row 8 (i / 4) + 4 h + (i % 4), column r of its 32 x 32 tile
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -157,4 +186,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const GemvArgs a, const int 
     }
 }
 #undef G128_GLOAD
+#undef G128_ARRIVED
 #undef G128_LWRITE
+#undef G128_MMA
+#undef G128_KOFF
