@@ -285,36 +285,47 @@ static hipError_t launch_mmq(int K, const GemvArgs& a, hipStream_t st, bool xp =
 // long prompts / batched prefill: LDS-tiled 128 x 128 kernel (gemm128.cuh); weights UNPACKED [N][K]
 // rows from which prefill takes the LDS-tiled kernels (measured: 190 rows 5.8 vs 6.7 ms with them, 380 rows 8.4 vs 7.8)
 static const int G128_MIN_ROWS = getenv("CSM_G128_MIN_ROWS") ? atoi(getenv("CSM_G128_MIN_ROWS")) : 256;
-template <int EPI, int HD>
+// rows from which a block is 256 x 128 (4 row tiles per wave, one block per CU) instead of 128 x 128 (gemm128.cuh, round 3).  OFF: measured
+// SLOWER (1,334 rows: gate/up 186 vs 136 us, q|k|v 101 vs 60; 32 x 190 rows: prefill + frame 0 29.8 vs 23.0 ms) -- its 256 accumulators
+// leave room for one K slice in flight and one block per CU, so every 64-deep slice waits out a memory round trip that the
+// 128 x 128 form hides behind its second block and its second register set.  Kept (bit-identical, tested) as the starting point of an
+// LDS-DMA version with three LDS buffers.
+static const int G256_MIN_ROWS = getenv("CSM_G256_MIN_ROWS") ? atoi(getenv("CSM_G256_MIN_ROWS")) : (1 << 30);
+template <int EPI, int HD, int MI>
 static hipError_t launch_g128_t(const GemvArgs& a, int K, hipStream_t st) {
+    constexpr int SMEM = MI == 2 ? G128_SMEM : G256_SMEM, BM = 64 * MI;
     static bool attr_set_dev[64] = {false};              // hipFuncSetAttribute is per device
     int dev_ = 0; (void)hipGetDevice(&dev_);
     bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
         (void)hipGetLastError();
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm128<EPI, HD>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G128_SMEM);
-        if (e != hipSuccess) { fprintf(stderr, "k_gemm128: hipFuncSetAttribute(%d B LDS): %s\n", G128_SMEM, hipGetErrorString(e)); return e; }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm128<EPI, HD, 0, MI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) { fprintf(stderr, "k_gemm128: hipFuncSetAttribute(%d B LDS): %s\n", SMEM, hipGetErrorString(e)); return e; }
         attr_set = true;
     }
     const int nout = EPI == EPI_SWIGLU ? 64 : 128;
-    const int mtiles = (a.M + 127) / 128, ntiles = (a.N + nout - 1) / nout;
+    const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.N + nout - 1) / nout;
     static const int switch_tiles = getenv("CSM_G128_ROWTILES") ? atoi(getenv("CSM_G128_ROWTILES")) : 32;
     int mt8; unsigned blocks;
-    if (mtiles >= switch_tiles) { mt8 = (mtiles + 7) / 8; blocks = (unsigned)(8L * ntiles * mt8); }          // row tiles per XCD
+    if (mtiles * (BM / 128) >= switch_tiles) { mt8 = (mtiles + 7) / 8; blocks = (unsigned)(8L * ntiles * mt8); }   // row tiles per XCD
     else { mt8 = -mtiles; blocks = (unsigned)(8L * ((ntiles + 7) / 8) * mtiles); }                            // column tiles per XCD
     if (EPI == EPI_SLAB) blocks *= 4;                                                                         // one block per K quarter
-    hipLaunchKernelGGL((k_gemm128<EPI, HD>), dim3(blocks), dim3(256), G128_SMEM, st, a, K, mt8, (long)K);
+    hipLaunchKernelGGL((k_gemm128<EPI, HD, 0, MI>), dim3(blocks), dim3(256), SMEM, st, a, K, mt8, (long)K);
     return hipGetLastError();
+}
+template <int EPI, int HD>
+static hipError_t launch_g128_mi(const GemvArgs& a, int K, hipStream_t st) {
+    return a.M >= G256_MIN_ROWS ? launch_g128_t<EPI, HD, 4>(a, K, st) : launch_g128_t<EPI, HD, 2>(a, K, st);
 }
 static hipError_t launch_g128(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
     if (K % 256 != 0) return hipErrorInvalidValue;
     switch (kind) {
-        case 0: return launch_g128_t<EPI_STORE, 64>(a, K, st);
-        case 1: return launch_g128_t<EPI_RESID, 64>(a, K, st);
-        case 5: return launch_g128_t<EPI_SLAB, 64>(a, K, st);
-        case 3: return hd == 64 ? launch_g128_t<EPI_QKV_ROPE, 64>(a, K, st) : launch_g128_t<EPI_QKV_ROPE, 128>(a, K, st);
-        case 4: return launch_g128_t<EPI_SWIGLU, 64>(a, K, st);
+        case 0: return launch_g128_mi<EPI_STORE, 64>(a, K, st);
+        case 1: return launch_g128_mi<EPI_RESID, 64>(a, K, st);
+        case 5: return launch_g128_mi<EPI_SLAB, 64>(a, K, st);
+        case 3: return hd == 64 ? launch_g128_mi<EPI_QKV_ROPE, 64>(a, K, st) : launch_g128_mi<EPI_QKV_ROPE, 128>(a, K, st);
+        case 4: return launch_g128_mi<EPI_SWIGLU, 64>(a, K, st);
     }
     return hipErrorInvalidValue;
 }

@@ -27,9 +27,18 @@ __device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4_t& v) { return __built
 
 #define G128_LD 64                        // LDS row = one 64-deep K slice (128 B); 16-byte segments XOR-swizzled
 #define G128_SMEM (2 * 256 * G128_LD * 2) // two buffers of (128 A rows + 128 B rows) = 64 KB
+#define G256_SMEM (2 * 384 * G128_LD * 2) // MI = 4: two buffers of (256 A rows + 128 B rows) = 96 KB
 
-template <int EPI, int HD, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void k_gemm128(const GemvArgs a, const int K, const int mt8, const long ldw) {
+// MI = 32-row tiles per wave along M: 2 -> the 128 x 128 block (two blocks per CU), 4 -> a 256 x 128 block (round 3; one block per CU;
+// NOT used by default: measured slower, see csm_engine.hip G256_MIN_ROWS).  The bigger block's bytes per flop fall from 1/64 to 1/85 --
+// these kernels need 64 KB per CU and slice pair from the L2s, whose ~70 GB/s per CU (MI355X_MICROARCH.md) caps them near 46 % of the
+// matrix cores' peak -- but with its accumulators in all 512 registers it keeps only one slice in flight.  Same per-tile MFMA chains
+// and the same K-quarter fold in both: same bits.
+template <int EPI, int HD, int DBG = 0, int MI = 2>
+__global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void k_gemm128(const GemvArgs a, const int K, const int mt8, const long ldw) {
+    constexpr int BM = 64 * MI;                             // rows per block
+    constexpr int NA = MI * 2;                              // 16-byte A pieces per thread and slice (rows row0 + 32 i)
+    constexpr int LROWS = BM + 128;                         // LDS rows per buffer
     extern __shared__ __align__(16) unsigned char g128_smem[];
     bf16_t* lds = reinterpret_cast<bf16_t*>(g128_smem);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -48,19 +57,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const GemvArgs a, const int 
     int mt, nt;
     if (mt8 > 0) { mt = (j % mt8) * 8 + xcd; nt = j / mt8; }
     else { mt = j % (-mt8); nt = (j / (-mt8)) * 8 + xcd; }
-    if (mt * 128 >= a.M) return;
+    if (mt * BM >= a.M) return;
     constexpr int NOUT = EPI == EPI_SWIGLU ? 64 : 128;      // output columns per block
-    const int m0 = mt * 128, n0 = nt * NOUT;
+    const int m0 = mt * BM, n0 = nt * NOUT;
     if (n0 >= a.N) return;
 
     // this thread's four 16-byte pieces of each operand slice: rows (tid >> 3) + 32 i, segment tid & 7
     const int seg = tid & 7, row0 = tid >> 3;
-    const bf16_t* pa[4];
+    const bf16_t* pa[NA];
     const bf16_t* pb[4];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) pa[i] = a.x + (long)min(m0 + row0 + 32 * i, a.M - 1) * a.x_row_stride + a.x_row_offset + seg * 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int tr = row0 + 32 * i;
-        pa[i] = a.x + (long)min(m0 + tr, a.M - 1) * a.x_row_stride + a.x_row_offset + seg * 8;
         const bf16_t* wsrc;
         int n;
         if (EPI == EPI_SWIGLU) {                            // B rows: [wave column][gate 32 | up 32]
@@ -81,34 +91,39 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const GemvArgs a, const int 
     // iteration ago) is written to the idle LDS buffer.  With one slice in flight a block paid one memory round trip per 64-deep
     // slice (32 slices x ~2 us at K = 2048: q|k|v 67 us for 17 GFLOP) -- latency, neither LDS nor matrix-core time.  The loop is
     // unrolled by two so that the register set of a slice is a compile-time choice (a runtime index would put them in scratch).
-    u32x4_t ra[2][4], rb[2][4];           // compiler vector type: HIP's uint4 struct kept these in scratch memory
+    constexpr int NSETS = MI == 2 ? 2 : 1;                // MI = 4: one slice in flight (its 512 registers hold 256 accumulators)
+    u32x4_t ra[NSETS][NA], rb[NSETS][4];  // compiler vector type: HIP's uint4 struct kept these in scratch memory
     // (asm loads + hand-written waits: with plain loads hipcc's wait-count pass put vmcnt(0) at the loop header -- it waited for the
     //  OLDER slice before requesting the next one, i.e. one slice in flight again.  Requests return in order, so "all but the 8
     //  youngest" is exactly the older register set.  No scratch in these kernels (tools/kres.sh): an asm-loaded register that is
     //  spilled before its wait would be saved with stale contents.)
 #define G128_GLOAD(set, kc)                                                              \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i)                                       \
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[set][i]) : "v"(pa[i] + (kc)) : "memory"); \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[set][i]) : "v"(pb[i] + (kc)) : "memory"); \
-    }
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[set][i]) : "v"(pb[i] + (kc)) : "memory");
+    // (NA + 4 requests per slice: "all but the NA + 4 youngest" have arrived)
 #define G128_ARRIVED(set, younger)                                                       \
     {                                                                                    \
-        if (younger) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ra[set][i]), "+v"(rb[set][i])); \
+        if (!(younger)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+        else if (NA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               \
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                           \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(ra[set][i])); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(rb[set][i])); \
     }
     // rows row0 + 32 i share (row >> 1) & 7, so one swizzled segment serves all four pieces
     const int wseg = seg ^ ((row0 >> 1) & 7);
     bf16_t* const wbase = lds + row0 * G128_LD + wseg * 8;
 #define G128_LWRITE(set, buf)                                                            \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
-        *reinterpret_cast<u32x4_t*>(wbase + (buf) * (256 * G128_LD) + (32 * i) * G128_LD) = ra[set][i];      \
-        *reinterpret_cast<u32x4_t*>(wbase + (buf) * (256 * G128_LD) + (128 + 32 * i) * G128_LD) = rb[set][i];  \
-    }
-    const int sw = (r >> 1) & 7;              // fragment rows are wm*64 + mi*32 + r: (row >> 1) & 7 == (r >> 1) & 7
+    _Pragma("unroll") for (int i = 0; i < NA; ++i)                                       \
+        *reinterpret_cast<u32x4_t*>(wbase + (buf) * (LROWS * G128_LD) + (32 * i) * G128_LD) = ra[set][i];      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+        *reinterpret_cast<u32x4_t*>(wbase + (buf) * (LROWS * G128_LD) + (BM + 32 * i) * G128_LD) = rb[set][i];
+    const int sw = (r >> 1) & 7;              // fragment rows are wm*32*MI + mi*32 + r: (row >> 1) & 7 == (r >> 1) & 7
 
-    f32x16_t tot[2][2], acc[2][2];
+    f32x16_t tot[MI][2], acc[MI][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -120,22 +135,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const GemvArgs a, const int 
     // one slice from LDS buffer `buf`: the same MFMA chain per K quarter as before (k ascending; fold at the quarter's end)
 #define G128_MMA(buf)                                                                    \
     {                                                                                    \
-        const bf16_t* A = lds + (buf) * (256 * G128_LD) + (wm * 64 + r) * G128_LD;       \
-        const bf16_t* B = lds + (buf) * (256 * G128_LD) + (128 + wn * 64 + r) * G128_LD; \
+        const bf16_t* A = lds + (buf) * (LROWS * G128_LD) + (wm * 32 * MI + r) * G128_LD; \
+        const bf16_t* B = lds + (buf) * (LROWS * G128_LD) + (BM + wn * 64 + r) * G128_LD; \
         _Pragma("unroll") for (int q = 0; q < (DBG == 2 ? 0 : 4); ++q) {                 \
             const int so = ((4 * h + q) ^ sw) * 8;                                       \
-            const u32x4_t a0 = *reinterpret_cast<const u32x4_t*>(A + so);                \
-            const u32x4_t a1 = *reinterpret_cast<const u32x4_t*>(A + 32 * G128_LD + so); \
             const u32x4_t b0 = *reinterpret_cast<const u32x4_t*>(B + so);                \
             const u32x4_t b1 = *reinterpret_cast<const u32x4_t*>(B + 32 * G128_LD + so); \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(b0), acc[0][0], 0, 0, 0); \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(b1), acc[0][1], 0, 0, 0); \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(b0), acc[1][0], 0, 0, 0); \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(b1), acc[1][1], 0, 0, 0); \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                          \
+                const u32x4_t am = *reinterpret_cast<const u32x4_t*>(A + mi * 32 * G128_LD + so); \
+                acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(am), as_bf16x8(b0), acc[mi][0], 0, 0, 0); \
+                acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(am), as_bf16x8(b1), acc[mi][1], 0, 0, 0); \
+            }                                                                            \
         }                                                                                \
         if (++in_quarter == per_quarter) {                 /* end of a K quarter: fold the partial, restart the chain */ \
             in_quarter = 0;                                                              \
-            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                             \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                            \
                 _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                         \
                     _Pragma("unroll") for (int i = 0; i < 16; ++i) { tot[mi][ni][i] += acc[mi][ni][i]; acc[mi][ni][i] = 0.f; } \
         }                                                                                \
@@ -145,35 +159,48 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(const GemvArgs a, const int 
     G128_GLOAD(0, G128_KOFF(0))
     G128_ARRIVED(0, false)
     G128_LWRITE(0, 0)
-    G128_GLOAD(1, G128_KOFF(1))
-    __syncthreads();
-    // (sched_barrier: the requests leave before the MFMAs and the LDS writes come after them)
-    for (int s = 0; s < ns; s += 2) {
-        if (DBG != 1) { G128_GLOAD(0, G128_KOFF(s + 2)) }
-        __builtin_amdgcn_sched_barrier(0);
-        G128_MMA(0)
-        __builtin_amdgcn_sched_barrier(0);
-        G128_ARRIVED(1, DBG != 1)
-        G128_LWRITE(1, 1)                                  // slice s + 1, requested one step ago
+    if constexpr (NSETS == 2) {
+        G128_GLOAD(1, G128_KOFF(1))
         __syncthreads();
-        if (s + 1 >= ns) break;
-        if (DBG != 1) { G128_GLOAD(1, G128_KOFF(s + 3)) }
-        __builtin_amdgcn_sched_barrier(0);
-        G128_MMA(1)
-        __builtin_amdgcn_sched_barrier(0);
-        G128_ARRIVED(0, DBG != 1)
-        G128_LWRITE(0, 0)                                  // slice s + 2
+        // (sched_barrier: the requests leave before the MFMAs and the LDS writes come after them)
+        for (int s = 0; s < ns; s += 2) {
+            if (DBG != 1) { G128_GLOAD(0, G128_KOFF(s + 2)) }
+            __builtin_amdgcn_sched_barrier(0);
+            G128_MMA(0)
+            __builtin_amdgcn_sched_barrier(0);
+            G128_ARRIVED(1, DBG != 1)
+            G128_LWRITE(1, 1)                                  // slice s + 1, requested one step ago
+            __syncthreads();
+            if (s + 1 >= ns) break;
+            if (DBG != 1) { G128_GLOAD(1, G128_KOFF(s + 3)) }
+            __builtin_amdgcn_sched_barrier(0);
+            G128_MMA(1)
+            __builtin_amdgcn_sched_barrier(0);
+            G128_ARRIVED(0, DBG != 1)
+            G128_LWRITE(0, 0)                                  // slice s + 2
+            __syncthreads();
+        }
+    } else {
         __syncthreads();
+        for (int s = 0; s < ns; ++s) {
+            if (DBG != 1) { G128_GLOAD(0, G128_KOFF(s + 1)) }
+            __builtin_amdgcn_sched_barrier(0);
+            G128_MMA(s & 1)
+            __builtin_amdgcn_sched_barrier(0);
+            G128_ARRIVED(0, false)
+            G128_LWRITE(0, (s + 1) & 1)
+            __syncthreads();
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the re-loaded last slices: nothing may still be landing in registers the epilogue reuses)
     // epilogue: acc register i of lane (r, h) is row 8 (i / 4) + 4 h + (i % 4), column r of its 32 x 32 tile
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < (EPI == EPI_SWIGLU ? 1 : 2); ++ni) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int m = m0 + wm * 64 + mi * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+                const int m = m0 + wm * 32 * MI + mi * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
                 if (EPI == EPI_SLAB) {
                     const int n = n0 + wn * 64 + ni * 32 + r;
                     if (m < a.M && n < a.N) a.slab[((long)kq * a.M + m) * a.N + n] = tot[mi][ni][i];
