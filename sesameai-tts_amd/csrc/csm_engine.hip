@@ -285,11 +285,9 @@ static hipError_t launch_mmq(int K, const GemvArgs& a, hipStream_t st, bool xp =
 // long prompts / batched prefill: LDS-tiled 128 x 128 kernel (gemm128.cuh); weights UNPACKED [N][K]
 // rows from which prefill takes the LDS-tiled kernels (measured: 190 rows 5.8 vs 6.7 ms with them, 380 rows 8.4 vs 7.8)
 static const int G128_MIN_ROWS = getenv("CSM_G128_MIN_ROWS") ? atoi(getenv("CSM_G128_MIN_ROWS")) : 256;
-// rows from which a block is 256 x 128 (4 row tiles per wave, one block per CU) instead of 128 x 128 (gemm128.cuh, round 3).  OFF: measured
-// SLOWER (1,334 rows: gate/up 186 vs 136 us, q|k|v 101 vs 60; 32 x 190 rows: prefill + frame 0 29.8 vs 23.0 ms) -- its 256 accumulators
-// leave room for one K slice in flight and one block per CU, so every 64-deep slice waits out a memory round trip that the
-// 128 x 128 form hides behind its second block and its second register set.  Kept (bit-identical, tested) as the starting point of an
-// LDS-DMA version with three LDS buffers.
+// rows from which a block is 256 x 128 (4 row tiles per wave, one block per CU, operands by LDS-DMA into three LDS buffers; gemm128.cuh,
+// round 3).  OFF: measured SLOWER at every size (1,334 rows: gate/up 161 vs 136 us, q|k|v 92 vs 60; 32 x 190 rows: prefill + frame 0
+// 26.4 vs 23.0 ms) -- one wave per SIMD leaves the slice barrier and the fragment reads uncovered.  Bit-identical, kept for the A/B.
 static const int G256_MIN_ROWS = getenv("CSM_G256_MIN_ROWS") ? atoi(getenv("CSM_G256_MIN_ROWS")) : (1 << 30);
 template <int EPI, int HD, int MI>
 static hipError_t launch_g128_t(const GemvArgs& a, int K, hipStream_t st) {

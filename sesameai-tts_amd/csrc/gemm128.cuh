@@ -27,13 +27,13 @@ __device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4_t& v) { return __built
 
 #define G128_LD 64                        // LDS row = one 64-deep K slice (128 B); 16-byte segments XOR-swizzled
 #define G128_SMEM (2 * 256 * G128_LD * 2) // two buffers of (128 A rows + 128 B rows) = 64 KB
-#define G256_SMEM (2 * 384 * G128_LD * 2) // MI = 4: two buffers of (256 A rows + 128 B rows) = 96 KB
+#define G256_SMEM (3 * 384 * G128_LD * 2) // MI = 4: THREE buffers of (256 A rows + 128 B rows) = 144 KB, filled by LDS-DMA
 
 // MI = 32-row tiles per wave along M: 2 -> the 128 x 128 block (two blocks per CU), 4 -> a 256 x 128 block (round 3; one block per CU;
 // NOT used by default: measured slower, see csm_engine.hip G256_MIN_ROWS).  The bigger block's bytes per flop fall from 1/64 to 1/85 --
 // these kernels need 64 KB per CU and slice pair from the L2s, whose ~70 GB/s per CU (MI355X_MICROARCH.md) caps them near 46 % of the
-// matrix cores' peak -- but with its accumulators in all 512 registers it keeps only one slice in flight.  Same per-tile MFMA chains
-// and the same K-quarter fold in both: same bits.
+// matrix cores' peak -- but its accumulators take the register file: one block per CU, one wave per SIMD, and that costs more than the
+// bytes save.  Same per-tile MFMA chains and the same K-quarter fold in both: same bits.
 template <int EPI, int HD, int DBG = 0, int MI = 2>
 __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void k_gemm128(const GemvArgs a, const int K, const int mt8, const long ldw) {
     constexpr int BM = 64 * MI;                             // rows per block
@@ -91,8 +91,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void k_gemm128(const GemvArgs
     // iteration ago) is written to the idle LDS buffer.  With one slice in flight a block paid one memory round trip per 64-deep
     // slice (32 slices x ~2 us at K = 2048: q|k|v 67 us for 17 GFLOP) -- latency, neither LDS nor matrix-core time.  The loop is
     // unrolled by two so that the register set of a slice is a compile-time choice (a runtime index would put them in scratch).
-    constexpr int NSETS = MI == 2 ? 2 : 1;                // MI = 4: one slice in flight (its 512 registers hold 256 accumulators)
-    u32x4_t ra[NSETS][NA], rb[NSETS][4];  // compiler vector type: HIP's uint4 struct kept these in scratch memory
+    u32x4_t ra[2][NA], rb[2][4];          // (MI = 2 only) compiler vector type: HIP's uint4 struct kept these in scratch memory
     // (asm loads + hand-written waits: with plain loads hipcc's wait-count pass put vmcnt(0) at the loop header -- it waited for the
     //  OLDER slice before requesting the next one, i.e. one slice in flight again.  Requests return in order, so "all but the 8
     //  youngest" is exactly the older register set.  No scratch in these kernels (tools/kres.sh): an asm-loaded register that is
@@ -156,10 +155,10 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void k_gemm128(const GemvArgs
     }
     // (slices past the last one re-load the last one: no control flow around the register staging)
 #define G128_KOFF(s_) ((c_first + min((s_), ns - 1)) * 64)
-    G128_GLOAD(0, G128_KOFF(0))
-    G128_ARRIVED(0, false)
-    G128_LWRITE(0, 0)
-    if constexpr (NSETS == 2) {
+    if constexpr (MI == 2) {
+        G128_GLOAD(0, G128_KOFF(0))
+        G128_ARRIVED(0, false)
+        G128_LWRITE(0, 0)
         G128_GLOAD(1, G128_KOFF(1))
         __syncthreads();
         // (sched_barrier: the requests leave before the MFMAs and the LDS writes come after them)
@@ -181,16 +180,57 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void k_gemm128(const GemvArgs
             __syncthreads();
         }
     } else {
-        __syncthreads();
-        for (int s = 0; s < ns; ++s) {
-            if (DBG != 1) { G128_GLOAD(0, G128_KOFF(s + 1)) }
-            __builtin_amdgcn_sched_barrier(0);
-            G128_MMA(s & 1)
-            __builtin_amdgcn_sched_barrier(0);
-            G128_ARRIVED(0, false)
-            G128_LWRITE(0, (s + 1) & 1)
-            __syncthreads();
+        // MI = 4: the accumulators take the register file, so the operands go global -> LDS directly (global_load_lds_dwordx4: lane l's
+        // 16 bytes land at base + 16 l, no staging registers) into THREE buffers: slices s + 1 and s + 2 are in flight while slice s
+        // feeds the MFMAs.  A wave instruction fills one 8-row group (1 KB); the conflict-free image (segment g of row t at position
+        // g ^ ((t >> 1) & 7)) is produced by letting lane (row, position p) FETCH segment p ^ ((t >> 1) & 7) of its row.  Wave w owns
+        // the A groups w, w + 4, .. (8 of 32) and the B groups w, w + 4, .. (4 of 16): 12 requests per wave and slice, so "all but
+        // the 12 youngest" (vmcnt) are the older slice; the barrier then makes every wave's groups visible to all.
+        typedef __attribute__((address_space(3))) unsigned char g128_lb;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(g128_lb*)g128_smem;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int grow = lane >> 3, pos = lane & 7;
+        const bf16_t* qa[8];
+        const bf16_t* qb[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = (wv + 4 * i) * 8 + grow;
+            qa[i] = a.x + (long)min(m0 + t, a.M - 1) * a.x_row_stride + a.x_row_offset + (pos ^ ((t >> 1) & 7)) * 8;
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tr = (wv + 4 * i) * 8 + grow;
+            const bf16_t* wsrc;
+            int n;
+            if (EPI == EPI_SWIGLU) { n = min(n0 + (tr >> 6) * 32 + (tr & 31), a.N - 1); wsrc = ((tr >> 5) & 1) ? a.w1 : a.w0; }
+            else if (EPI == EPI_QKV_ROPE) {
+                n = min(n0 + tr, a.N - 1);
+                if (n < a.nq) wsrc = a.w0;
+                else if (n < a.nq + a.nkv) { wsrc = a.w1; n -= a.nq; }
+                else { wsrc = a.w2; n -= a.nq + a.nkv; }
+            } else { n = min(n0 + tr, a.N - 1); wsrc = a.w0; }
+            qb[i] = wsrc + (long)n * ldw + (pos ^ ((tr >> 1) & 7)) * 8;
+        }
+#define G256_DMA(buf, kc)                                                                \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                    \
+            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(qa[i] + (kc)), "s"(lds0 + (uint32_t)((buf) * (LROWS * 128) + (wv + 4 * i) * 1024)) : "memory", "m0"); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                    \
+            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(qb[i] + (kc)), "s"(lds0 + (uint32_t)((buf) * (LROWS * 128) + BM * 128 + (wv + 4 * i) * 1024)) : "memory", "m0");
+        G256_DMA(0, G128_KOFF(0))
+        G256_DMA(1, G128_KOFF(1))
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __syncthreads();
+        int b0 = 0, b2 = 2;                                    // buffer of slice s / of slice s + 2
+        for (int s = 0; s < ns; ++s) {
+            if (DBG != 1) { G256_DMA(b2, G128_KOFF(s + 2)) }
+            __builtin_amdgcn_sched_barrier(0);
+            G128_MMA(b0)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // slice s + 1 has landed (this wave's groups; the barrier covers the others')
+            __syncthreads();
+            b0 = b0 == 2 ? 0 : b0 + 1; b2 = b2 == 2 ? 0 : b2 + 1;
+        }
+#undef G256_DMA
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the re-loaded last slices: nothing may still be landing in registers the epilogue reuses)
     // epilogue: acc register i of lane (r, h) is row 8 (i / 4) + 4 h + (i % 4), column r of its 32 x 32 tile
