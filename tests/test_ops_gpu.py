@@ -196,6 +196,18 @@ def test_gemm128_equals_mm32_bitwise(abi, M, K, hd):
     assert outs[1][1].abs().sum() > 0
 
 
+def test_gemm128_with_256_row_blocks_and_lds_dma_operands_equals_mm32_bitwise():
+    """The opt-in 256 x 128 form of k_gemm128 (operands by global_load_lds_dwordx4 into three LDS buffers; off by default because it
+    measured slower) must stay bit-identical too.  Its row threshold is read when the library is loaded, so the bitwise test above
+    is re-run in a child process with CSM_G256_MIN_ROWS=128: all four shapes then take the 256-row blocks (row tails 200, 513, 130, 129)."""
+    import os, subprocess, sys
+    env = dict(os.environ, CSM_G256_MIN_ROWS="128")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_ops_gpu.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "test_gemm128_equals_mm32_bitwise", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "4 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("M,K,hd", [(64, 2048, 64), (96, 2048, 64), (190, 2048, 64), (190, 8192, 64), (131, 1024, 128), (256, 2048, 64)])
 def test_prompt_kernels_give_the_same_bits_at_every_row_count(abi, M, K, hd):
     """Prompts of 64..256 rows run k_mmt / k_mmq (several 32 x 32 output tiles per wave, residual projections as four
