@@ -87,8 +87,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void k_gemm128(const GemvArgs
         }
         pb[i] = wsrc + (long)n * ldw + seg * 8;
     }
-    // TWO K slices in flight in registers (round 3): slice s + 2 is requested while slice s feeds the MFMAs and slice s + 1 (requested an
-    // iteration ago) is written to the idle LDS buffer.  With one slice in flight a block paid one memory round trip per 64-deep
+    // TWO K slices in flight in registers (round 3): slices s + 1 and s + 2 are requested while slice s feeds the MFMAs.  With one slice in flight a block paid one memory round trip per 64-deep
     // slice (32 slices x ~2 us at K = 2048: q|k|v 67 us for 17 GFLOP) -- latency, neither LDS nor matrix-core time.  The loop is
     // unrolled by two so that the register set of a slice is a compile-time choice (a runtime index would put them in scratch).
     u32x4_t ra[2][NA], rb[2][4];          // (MI = 2 only) compiler vector type: HIP's uint4 struct kept these in scratch memory
@@ -156,27 +155,26 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void k_gemm128(const GemvArgs
     // (slices past the last one re-load the last one: no control flow around the register staging)
 #define G128_KOFF(s_) ((c_first + min((s_), ns - 1)) * 64)
     if constexpr (MI == 2) {
+        // Every asm-loaded register set is requested AND consumed inside one loop iteration (two slices per iteration): no such value is
+        // live across the loop's back edge or its entry, where the register allocator may insert copies -- a copy of a register whose
+        // load is still in flight copies stale bits (seen in a first version of a 4-deep ring for k_attn_flash: v_mov at the back edge).
         G128_GLOAD(0, G128_KOFF(0))
         G128_ARRIVED(0, false)
         G128_LWRITE(0, 0)
-        G128_GLOAD(1, G128_KOFF(1))
         __syncthreads();
         // (sched_barrier: the requests leave before the MFMAs and the LDS writes come after them)
         for (int s = 0; s < ns; s += 2) {
-            if (DBG != 1) { G128_GLOAD(0, G128_KOFF(s + 2)) }
+            if (DBG != 1) { G128_GLOAD(1, G128_KOFF(s + 1)) G128_GLOAD(0, G128_KOFF(s + 2)) }   // slices s + 1 and s + 2
             __builtin_amdgcn_sched_barrier(0);
             G128_MMA(0)
             __builtin_amdgcn_sched_barrier(0);
-            G128_ARRIVED(1, DBG != 1)
-            G128_LWRITE(1, 1)                                  // slice s + 1, requested one step ago
+            G128_ARRIVED(1, DBG != 1)                         // slice s + 1 (the older eight requests)
+            G128_LWRITE(1, 1)
             __syncthreads();
-            if (s + 1 >= ns) break;
-            if (DBG != 1) { G128_GLOAD(1, G128_KOFF(s + 3)) }
+            if (s + 1 < ns) { G128_MMA(1) }
             __builtin_amdgcn_sched_barrier(0);
-            G128_MMA(1)
-            __builtin_amdgcn_sched_barrier(0);
-            G128_ARRIVED(0, DBG != 1)
-            G128_LWRITE(0, 0)                                  // slice s + 2
+            G128_ARRIVED(0, false)                            // slice s + 2
+            G128_LWRITE(0, 0)
             __syncthreads();
         }
     } else {

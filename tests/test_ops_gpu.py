@@ -352,7 +352,8 @@ def test_prompt_flash_attention_over_long_prompts(abi, S, start):
     assert (got - want.double()).abs().max().item() <= err_ref + err_hip + 1e-6
 
 
-@pytest.mark.parametrize("H,KV,S,start", [(32, 8, 77, (0, 5, 100)), (8, 2, 33, (0, 0, 190)), (16, 4, 1, (0, 63, 64))])
+@pytest.mark.parametrize("H,KV,S,start", [(32, 8, 77, (0, 5, 100)), (8, 2, 33, (0, 0, 190)), (16, 4, 1, (0, 63, 64)),
+                                          (32, 8, 190, (0,) * 32)])        # (config 3's prefill: 1,536 blocks, several per CU)
 def test_prompt_flash_attention_vs_exact_and_oracle(abi, H, KV, S, start):
     """attn_flash.cuh (prompt rows, hd 64): S^T = K.Q^T and O^T += V^T.P^T on the matrix cores, fp32 softmax, P rounded
     to bf16 like torch's CPU flash kernel.  Graded like test_attention: against exact fp64 attention of the same bf16

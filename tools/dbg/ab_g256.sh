@@ -1,7 +1,7 @@
-# 256 x 128 blocks (CSM_G256_MIN_ROWS=rows from which they are used) against 128 x 128 for prompt prefills: per-kernel times at 1,334 rows
-# (rocprofv3), prefill + frame 0 of 32 x 190 rows, and the bit-identity tests
+# k_gemm128 at 1,334 rows (rocprofv3 per-kernel times) with 128 x 128 blocks and, with CSM_G256_MIN_ROWS=1024, the opt-in 256 x 128 form;
+# prefill + frame 0 of 32 x 190 rows; the bit-identity tests
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for thr in 1000000 1024 1000000 1024; do
+for thr in ${1:-1000000 1024}; do
   export CSM_G256_MIN_ROWS=$thr
   echo "== CSM_G256_MIN_ROWS=$thr"
   rm -rf /tmp/pfs; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pfs -- python3 tools/prefill_prof.py 1334 10 > /tmp/pf_out.txt 2>&1
@@ -16,5 +16,4 @@ for r in csv.DictReader(open('$f')):
 done
 unset CSM_G256_MIN_ROWS
 python -m pytest tests/test_ops_gpu.py -m gpu -x -q 2>&1 | tail -2
-CSM_G256_MIN_ROWS=256 python -m pytest tests/test_ops_gpu.py -m gpu -x -q 2>&1 | tail -2
 python -m pytest tests/test_frame_gpu.py -m gpu -x -q -k "prefill or prefix or prompt or golden or config5" 2>&1 | tail -2
