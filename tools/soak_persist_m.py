@@ -3,7 +3,7 @@
 seed must give the same frames bit for bit, run after run; a race in the exchange protocol (a stale buffer accepted, an LDS buffer
 overwritten early) shows up as a difference, a give-up as an exception from read_frames.  Half of the runs have a second stream hammering
 HBM next to the frame loop (uneven load: hand-offs that only work on an idle chip fail here).
-    python tools/soak_persist_m.py [frames per run] [runs per batch size]"""
+    python tools/soak_persist_m.py [frames per run] [runs per batch size] [batch sizes, comma-separated]"""
 import os
 import sys
 import time
@@ -23,13 +23,15 @@ args = SimpleNamespace(ctx_text=40, ctx_frames=125, gen_text=24)
 side = torch.cuda.Stream()
 junk = torch.empty(256 * 1024 * 1024, dtype=torch.uint8, device="cuda")
 t_all = time.time()
-for B in (2, 5, 9, 16, 17, 24, 32):
+batches = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [2, 5, 9, 16, 17, 24, 32]      # (1: the batch-1 persistent launches)
+for B in batches:
     tok, msk = bench.synthetic_prompt(args, B, margs.text_vocab_size, seed0=9000 + B)
     tok, msk = tok[:, :40], msk[:, :40]
     S = tok.shape[1]
     m = Model(margs, sd, max_frames=n_frames + 8, max_prefill_rows=B * S)
     m.setup_caches(B)
-    assert m.fast_paths() & 2
+    assert m.fast_paths() & (2 if B > 1 else 1), "the persistent decoder launch is not in use"
+    if B == 1: assert m.fast_paths() & 8, "the one-launch backbone layer is not in use"
     ref = None
     for run in range(n_runs):
         m.reset_caches(); m.seed(4321)
