@@ -95,7 +95,9 @@ const char* csm_last_error(csm_handle h);   /* h may be NULL: last create() erro
  * caches need no zeroing: attention is bounded by position, never by a 2048-wide mask.     */
 int csm_reset(csm_handle h, void* stream);
 
-/* Seeds the on-device Philox sampler (the reference uses the global torch RNG, models.py:73). */
+/* Seeds the on-device Philox sampler (the reference uses the global torch RNG, models.py:73).  Frame steps draw at
+ * (seed, frame counter, sequence, codebook); the frame 0 of a slot refill (csm_prefill_slot) draws from a second key domain
+ * (seed ^ salt, refill counter), so neither two refills nor a refill and a frame step ever share a noise stream.            */
 int csm_seed(csm_handle h, uint64_t seed, void* stream);
 
 /* The backbone half of Model.generate_frame (models.py:153-160) on B sequences x S rows:
@@ -139,6 +141,14 @@ int csm_copy_frame(csm_handle h, int B, int32_t* out_frame, void* stream);
 int csm_set_step_inputs(csm_handle h, const int32_t* tokens, const uint8_t* mask, const int32_t* pos,
                         int B, void* stream);
 
+/* Model.generate_frame for every frame AFTER the prompt, with the reference's own tensors (models.py:132-139 as called from
+ * tts_service.py:224-241 and generator.py:283-294): tokens [B][1][33] int64, mask [B][1][33] bool (one byte each), pos [B][1]
+ * int64, all dev and contiguous -> out_frame [B][32] int32 (dev).  = csm_set_step_inputs + csm_frame_step (hipGraph replay) +
+ * csm_copy_frame in ONE call: the staging kernel reads the reference's dtypes (no conversion kernels on the host side), the
+ * frame carries -1 if an all-CU launch gave up, and the handle's device is made current inside the call.  No host sync.       */
+int csm_generate_frame_s1(csm_handle h, const int64_t* tokens, const uint8_t* mask, const int64_t* pos, int B,
+                          float temperature, int topk, int32_t* out_frame, void* stream);
+
 /* Per-slot reset and refill of a live batch (SURVEY.md 8b `csm_reset(handle, batch_slots, n)`; the reference is batch-1 and resets
  * its one cache set per utterance, generator.py:255).  Utterances of a batch end at different frames (generator.py:285): a finished
  * one is retired and its slot given to the next prompt while the other slots keep generating.
@@ -146,7 +156,8 @@ int csm_set_step_inputs(csm_handle h, const int32_t* tokens, const uint8_t* mask
  * csm_prefill_slot: the prompt rows tokens [S][33] / mask [S][33] / pos [S] (dev) run through the backbone into slot `slot`'s
  * caches, the depth pass produces the new utterance's frame 0 (written to out_frame [32] dev if given, and into the history at the
  * NEWEST global frame index, replacing that slot's entry there), and the frame is staged as the slot's input of the next
- * csm_frame_step.  The other slots' state is untouched: their frames are bit-identical to an undisturbed run.  Call between
+ * csm_frame_step.  The other slots' state is untouched: their frames are bit-identical to an undisturbed run, and
+ * csm_copy_frame keeps returning every slot's own newest frame (the refilled slot's: its frame 0).  Call between
  * frame steps, on the stream that runs them.  A batch may also be FILLED slot by slot this way after csm_reset (prompts of
  * different lengths): the first call opens global frame 0.                                                                       */
 int csm_reset_slots(csm_handle h, const int32_t* slots /*host*/, int n, void* stream);
@@ -159,12 +170,14 @@ int csm_prefill_slot(csm_handle h, int slot, const int32_t* tokens, const uint8_
  * second communicator created by this library from its own copy of librccl would duplicate the bootstrap and the xGMI rings for
  * one collective that is not on the hot path.  The C ABI therefore takes device pointers that are already populated.            */
 
-/* History readback: frames [n][B][32] i32 into host memory (synchronises the stream);
- * eos_at[b] = index of the first all-zero frame of sequence b, or -1.                        */
+/* History readback: frames [first, first + n) as [n][B][32] i32 into host memory (synchronises the stream);
+ * eos_at[b] = global index of the first all-zero frame of sequence b, or -1.  The history is a RING of max_frames frames
+ * (global frame g lives in row g % max_frames), so a frame loop may run for any number of frames as long as every frame is
+ * read before max_frames newer ones exist; a range that has been overwritten is CSM_E_INVALID.                                */
 int csm_num_frames(csm_handle h);
 int csm_read_frames(csm_handle h, int B, int first, int n, int32_t* host_frames, int32_t* host_eos_at,
                     void* stream);
-/* Device pointer to the history [max_frames][B_stride=max_batch][32] i32 (for Mimi decode). */
+/* Device pointer to the history ring [max_frames][B_stride=max_batch][32] i32 (row = global frame % max_frames).           */
 const int32_t* csm_frames_dev(csm_handle h);
 /* Device pointer to last_h [max_batch][d_bb] bf16 (tests). */
 const void* csm_last_h_dev(csm_handle h);

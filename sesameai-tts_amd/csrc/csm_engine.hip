@@ -30,6 +30,8 @@
 #define PART_ROWS 32
 #define WIDE_MIN_ROWS 3       // M >= this: MFMA path (mm.cuh) instead of the weight-stationary GEMV (measured: B=3 6.0 vs 6.5 ms, B=2 narrow wins)
 
+#define CSM_REFILL_SALT 0x9E3779B97F4A7C15ull      /* Philox key domain of slot refills (csm_seed) */
+
 static thread_local std::string g_create_err;
 
 struct Stack {
@@ -72,8 +74,11 @@ struct CsmModel {
     bf16_t* logits;                     // [B][ldl]
     int *frame, *cur_tokens, *cur_pos, *history, *n_frames, *eos_at, *dec_pos, *slot_scratch;
     uint8_t* cur_mask;
-    uint64_t* rng;
-    int host_frames;                    // frames launched since reset (host mirror)
+    uint64_t* rng;                      // [0..1] {seed, frame-step counter}; [2..3] the refill domain {seed ^ REFILL_SALT, refill counter} (rng_slot)
+    uint64_t* rng_slot;
+    int* frame_save;                    // [ncb] slot 0's newest frame while a slot refill's depth pass uses scratch row 0
+    int device;                         // the GPU this handle lives on (csm_generate_frame_s1 makes it current itself)
+    int host_frames;                    // frames launched since reset (host mirror); the history is a ring of max_frames rows
     int wide_path;                      // MFMA path for M >= wide_min (env CSM_WIDE=0 disables)
     int wide_min;                       // WIDE_MIN_ROWS unless env CSM_WIDE_MIN overrides (tuning knob)
     int xpack;                          // batched decode steps keep activations in operand order (env CSM_XPACK=0 disables)
@@ -744,7 +749,9 @@ static bool persist_usable(const CsmModel* m, int B) {
     if (m->persist_disabled) return false;
     return B == 1 ? m->persist : (B >= 2 && B <= m->pm_max_rows && m->persist_m);
 }
-static hipError_t launch_dec_persist(CsmModel* m, int B, float temperature, int topk, const int* forced, void* logits_out, const void* noise, hipStream_t st) {
+static hipError_t launch_dec_persist(CsmModel* m, int B, float temperature, int topk, const int* forced, void* logits_out, const void* noise, hipStream_t st,
+                                     const uint64_t* rng = nullptr) {
+    if (rng == nullptr) rng = m->rng;
     const CsmConfig& c = m->cfg;
     const int V = c.audio_vocab, ncb = c.n_codebooks;
     if (B == 1) {
@@ -754,7 +761,7 @@ static hipError_t launch_dec_persist(CsmModel* m, int B, float temperature, int 
         p.dec_norm = (const bf16_t*)m->w.dec_norm; p.head_t = (const bf16_t*)m->w.audio_head_t; p.rope = m->dec.rope;
         p.proj_emb = m->proj_emb; p.qkv0_tab = m->qkv0_tab; p.hdec = m->hdec; p.qd = m->qd;
         p.kc = m->dec.kc; p.vc = m->dec.vc; p.kv_layer_stride = m->dec.layer_stride;
-        p.temperature = temperature; p.topk = topk; p.noise = (const bf16_t*)noise; p.rng = m->rng; p.forced = forced;
+        p.temperature = temperature; p.topk = topk; p.noise = (const bf16_t*)noise; p.rng = rng; p.forced = forced;
         p.V = V; p.ncb = ncb; p.frame = m->frame; p.logits_out = (bf16_t*)logits_out; p.cb_first = 2; p.cb_last = ncb - 1;
         p.gQ = m->pg_q; p.gH1 = m->pg_h1; p.gH2 = m->pg_h2; p.gL = m->pg_l; p.gP = m->pg_p;
         p.err = m->p_state + 1; p.epoch = m->p_state; p.eps = c.decoder.norm_eps; p.trickle_sleep = m->p_trickle; p.poll_sleep = m->p_poll;
@@ -769,7 +776,7 @@ static hipError_t launch_dec_persist(CsmModel* m, int B, float temperature, int 
     p.dec_norm = (const bf16_t*)m->w.dec_norm; p.head_t = (const bf16_t*)m->w.audio_head_t; p.rope = m->dec.rope;
     p.proj_emb = m->proj_emb; p.qkv0_tab = m->qkv0_tab; p.hdec = m->hdec; p.qd = m->qd;
     p.kc = m->dec.kc; p.vc = m->dec.vc; p.kv_layer_stride = m->dec.layer_stride;
-    p.temperature = temperature; p.topk = topk; p.noise = (const bf16_t*)noise; p.rng = m->rng; p.forced = forced;
+    p.temperature = temperature; p.topk = topk; p.noise = (const bf16_t*)noise; p.rng = rng; p.forced = forced;
     p.V = V; p.ncb = ncb; p.M = B; p.frame = m->frame; p.logits_out = (bf16_t*)logits_out; p.cb_first = 2; p.cb_last = ncb - 1;
     p.xchg = m->pm_xchg; p.stamps = m->p_stamps; p.err = m->p_state + 1; p.eps = c.decoder.norm_eps; p.trickle_sleep = m->pm_trickle; p.poll_sleep = m->p_poll;
     hipError_t e = hipMemsetAsync(m->pm_xchg, 0xFF, DM_XCHG_BYTES, st);      // every exchange dword starts as the poison (dec_persist_m.cuh)
@@ -780,14 +787,16 @@ static hipError_t launch_dec_persist(CsmModel* m, int B, float temperature, int 
 }
 
 // c0 head + 31 depth-decoder steps (models.py:160-184); h rows = [B][S][d_bb], last row used
+// rng: the Philox words the samplers draw from -- the frame loop's {seed, step} unless a slot refill passes its own domain
 static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int topk, const int* forced,
-                            void* logits_out, const void* noise, hipStream_t st) {
+                            void* logits_out, const void* noise, hipStream_t st, const uint64_t* rng = nullptr) {
+    if (rng == nullptr) rng = m->rng;
     const CsmConfig& c = m->cfg;
     const int dbb = c.backbone.dim, dd = c.decoder.dim, V = c.audio_vocab, ncb = c.n_codebooks;
     hipError_t e;
     for (int cb = 0; cb < ncb; ++cb) {
         GemvArgs a;
-        if (cb == 2 && persist_usable(m, B)) return launch_dec_persist(m, B, temperature, topk, forced, logits_out, noise, st);
+        if (cb == 2 && persist_usable(m, B)) return launch_dec_persist(m, B, temperature, topk, forced, logits_out, noise, st, rng);
         if (cb >= 1) {
             const int rows = cb == 1 ? 2 * B : B;
             if (cb == 1) {
@@ -851,7 +860,7 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
         memset(&s, 0, sizeof s);
         s.logits = m->logits; s.ldl = m->ldl; s.V = V; s.temperature = temperature; s.topk = topk;
         s.noise = noise ? (const bf16_t*)noise + (size_t)cb * B * V : nullptr;
-        s.rng = m->rng; s.codebook = cb; s.forced = forced; s.ncb = ncb; s.frame = m->frame;
+        s.rng = rng; s.codebook = cb; s.forced = forced; s.ncb = ncb; s.frame = m->frame;
         // next decoder input = projection(embedding of the fed code) = one row of the table
         s.audio_emb = m->proj_emb; s.audio_vocab = V; s.d = dd;
         if (cb == 0) { s.emb_out = m->hdec + dd; s.emb_stride = 2L * dd; }
@@ -1256,7 +1265,9 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     ALLOC(m->history, (size_t)max_frames * max_batch * ncb * 4);
     ALLOC(m->n_frames, 16);
     ALLOC(m->eos_at, (size_t)max_batch * 4);
-    ALLOC(m->rng, 16);
+    ALLOC(m->rng, 32);
+    m->rng_slot = m->rng + 2;
+    ALLOC(m->frame_save, (size_t)ncb * 4);
     ALLOC(m->dec_pos, (size_t)(ncb + 1) * 2 * max_batch * 4);
     ALLOC(m->slot_scratch, (size_t)max_batch * 4);
     ALLOC(m->p_state, 16);
@@ -1268,7 +1279,11 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
         for (int i = 0; i < 2 * max_batch; ++i) dp[(size_t)k * 2 * max_batch + i] = k == 0 ? (i & 1) : k;
     HIPCHK((CsmModel*)nullptr, hipMemcpy(m->dec_pos, dp.data(), dp.size() * 4, hipMemcpyHostToDevice));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->logits, 0, (size_t)max_batch * m->ldl * 2));
-    HIPCHK((CsmModel*)nullptr, hipMemset(m->rng, 0, 16));
+    {   // unseeded handle: seed 0 in both Philox domains
+        const uint64_t v[4] = {0, 0, CSM_REFILL_SALT, 0};
+        HIPCHK((CsmModel*)nullptr, hipMemcpy(m->rng, v, 32, hipMemcpyHostToDevice));
+    }
+    m->device = 0; (void)hipGetDevice(&m->device);
     HIPCHK((CsmModel*)nullptr, hipMemset(m->p_state, 0, 16));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->b_state, 0, 16));
     HIPCHK((CsmModel*)nullptr, hipMemset(m->n_frames, 0, 16));
@@ -1350,7 +1365,7 @@ extern "C" void csm_destroy(csm_handle m) {
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     void* ptrs[] = {m->bb.kc, m->bb.vc, m->dec.kc, m->dec.vc, m->h, m->q, m->att, m->act, m->part, m->attn_ctr, m->dec_in, m->proj_emb, m->slab,
                     m->hdec, m->qd, m->attd, m->actd, m->logits, m->frame, m->cur_tokens, m->cur_mask, m->cur_pos,
-                    m->history, m->n_frames, m->eos_at, m->rng, m->dec_pos, m->slot_scratch, m->p_state, m->b_state, m->qkv0_tab};
+                    m->history, m->n_frames, m->eos_at, m->rng, m->frame_save, m->dec_pos, m->slot_scratch, m->p_state, m->b_state, m->qkv0_tab};
     for (void* p : ptrs) (void)hipFree(p);
     for (void* p : m->pk_allocs) (void)hipFree(p);
     if (m->xslab) (void)hipFree(m->xslab);
@@ -1384,8 +1399,10 @@ extern "C" int csm_reset(csm_handle m, void* stream) {
 
 extern "C" int csm_seed(csm_handle m, uint64_t seed, void* stream) {
     if (!m) return CSM_E_INVALID;
-    uint64_t v[2] = {seed, 0};
-    HIPCHK(m, hipMemcpyAsync(m->rng, v, 16, hipMemcpyHostToDevice, (hipStream_t)stream));
+    // two Philox domains: frame steps draw at (seed, step, sequence, codebook); the frame 0 of a slot refill (csm_prefill_slot) at
+    // (seed ^ salt, refill counter, slot, codebook), which no frame step can coincide with
+    uint64_t v[4] = {seed, 0, seed ^ CSM_REFILL_SALT, 0};
+    HIPCHK(m, hipMemcpyAsync(m->rng, v, 32, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIPCHK(m, hipStreamSynchronize((hipStream_t)stream));   // v is a stack temporary
     return CSM_OK;
 }
@@ -1419,7 +1436,6 @@ extern "C" int csm_depth(csm_handle m, int B, float temperature, int topk, const
         }
     }
     if (commit) {
-        if (m->host_frames >= m->max_frames) return fail(m, CSM_E_TOO_LONG, "csm_depth: frame history full (max_frames)");
         HIPCHK(m, launch_advance(m, B, forced, 0, st));
         m->host_frames += 1;
     }
@@ -1447,7 +1463,6 @@ static hipError_t enqueue_frame(CsmModel* m, int B, float temperature, int topk,
 extern "C" int csm_frame_step(csm_handle m, int B, float temperature, int topk, int use_graph, void* stream) {
     if (!m || B < 1 || B > m->max_batch) return fail(m, CSM_E_INVALID, "csm_frame_step: bad batch");
     if (!(temperature > 0.f) || topk < 1) return fail(m, CSM_E_INVALID, "csm_frame_step: temperature must be > 0 and topk >= 1");
-    if (m->host_frames >= m->max_frames) return fail(m, CSM_E_TOO_LONG, "csm_frame_step: frame history full (max_frames)");
     hipStream_t st = (hipStream_t)stream;
     if (!use_graph) {
         HIPCHK(m, enqueue_frame(m, B, temperature, topk, st));
@@ -1479,6 +1494,44 @@ extern "C" int csm_set_step_inputs(csm_handle m, const int32_t* tokens, const ui
     return CSM_OK;
 }
 
+// Model.generate_frame(tokens (B,1,33) int64, tokens_mask (B,1,33) bool, input_pos (B,1) int64, temperature, topk) -> (B,32) int32
+// exactly as the reference's loops call it for every frame after the prompt (tts_service.py:224-241, generator.py:283-294;
+// signature models.py:132-139): the caller's tensors are read in THEIR dtypes by the staging kernel (no conversion kernels on the
+// host side), the captured frame step is replayed, and the frame -- with -1 folded in if an all-CU launch gave up -- lands in
+// out_frame.  One call, three enqueues (stage, graph, copy-out); the handle's device is made current here, so the binding needs
+// no device context either.
+__global__ void k_stage_s1(const long long* tokens, const uint8_t* mask, const long long* pos, int n_tok, int B,
+                           int* cur_tokens, uint8_t* cur_mask, int* cur_pos, int max_seq, int* overflow) {
+    for (int i = threadIdx.x; i < n_tok; i += blockDim.x) { cur_tokens[i] = (int)tokens[i]; cur_mask[i] = mask[i] ? 1 : 0; }
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const long long p = pos[b];
+        cur_pos[b] = (int)p;
+        if (p < 0 || p >= max_seq) *overflow = 1;
+    }
+}
+__global__ void k_copy_i32(const int* __restrict__ src, int* __restrict__ dst, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int csm_generate_frame_s1(csm_handle m, const int64_t* tokens, const uint8_t* mask, const int64_t* pos, int B,
+                                     float temperature, int topk, int32_t* out_frame, void* stream) {
+    if (!m || !tokens || !mask || !pos || !out_frame || B < 1 || B > m->max_batch) return fail(m, CSM_E_INVALID, "csm_generate_frame_s1: bad argument");
+    int dev = m->device;
+    (void)hipGetDevice(&dev);
+    if (dev != m->device) HIPCHK(m, hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_stage_s1, dim3(1), dim3(256), 0, st, (const long long*)tokens, mask, (const long long*)pos,
+                       B * (m->cfg.n_codebooks + 1), B, m->cur_tokens, m->cur_mask, m->cur_pos, m->cfg.backbone.max_seq, m->n_frames + 1);
+    int rc = csm_frame_step(m, B, temperature, topk, 1, stream);
+    if (rc == CSM_OK) {
+        // (k_advance, the graph's last node, has already turned the codes of a launch that gave up into -1 in m->frame)
+        hipLaunchKernelGGL(k_copy_i32, dim3(1), dim3(256), 0, st, m->frame, out_frame, B * m->cfg.n_codebooks);
+        if (hipGetLastError() != hipSuccess) rc = fail(m, CSM_E_HIP, "csm_generate_frame_s1: copy-out launch failed");
+    }
+    if (dev != m->device) (void)hipSetDevice(dev);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------
 // per-slot reset / refill of a live batch (csm_reset(handle, batch_slots, n))
 // ---------------------------------------------------------------------------------------
@@ -1490,8 +1543,9 @@ __global__ void k_reset_slots(const int* slots, int n, int max_batch, int* cur_p
 }
 // frame 0 of a refilled slot (frame row 0 = the scratch row the slot's depth pass ran on) -> the slot's step inputs, its EOS word, the
 // history entry of the newest global frame, the caller's copy
-__global__ void k_stage_slot(const int* frame, int ncb, int slot, int bstride, int* history, int* n_frames, int max_frames, int* eos_at,
-                             int* cur_tokens, uint8_t* cur_mask, int* out_frame, const uint32_t* e0, const uint32_t* e1) {
+// ... and puts slot 0's own newest frame back into row 0 (csm_copy_frame keeps returning the batch's last frame), bumps the refill counter
+__global__ void k_stage_slot(int* frame, const int* frame_save, int ncb, int slot, int bstride, int* history, int* n_frames, int max_frames, int* eos_at,
+                             int* cur_tokens, uint8_t* cur_mask, int* out_frame, const uint32_t* e0, const uint32_t* e1, uint64_t* rng_slot) {
     __shared__ int nz;
     const bool bad = (e0 != nullptr && *e0 != 0u) || (e1 != nullptr && *e1 != 0u);
     const int n = *n_frames, g = n > 0 ? n - 1 : 0;
@@ -1500,16 +1554,18 @@ __global__ void k_stage_slot(const int* frame, int ncb, int slot, int bstride, i
     for (int c = threadIdx.x; c < ncb; c += blockDim.x) {
         const int v = bad ? -1 : frame[c];
         if (v != 0) atomicAdd(&nz, 1);
-        if (g < max_frames) history[((long)g * bstride + slot) * ncb + c] = v;
+        history[((long)(g % max_frames) * bstride + slot) * ncb + c] = v;
         cur_tokens[slot * (ncb + 1) + c] = v < 0 ? 0 : v;
         cur_mask[slot * (ncb + 1) + c] = 1;
         if (out_frame) out_frame[c] = v;
+        frame[c] = slot == 0 ? v : frame_save[c];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         cur_tokens[slot * (ncb + 1) + ncb] = 0; cur_mask[slot * (ncb + 1) + ncb] = 0;
         eos_at[slot] = nz == 0 ? g : -1;
         if (n == 0) *n_frames = 1;                    // the first slots of a batch that is being filled slot by slot open global frame 0
+        rng_slot[1] += 1;                             // every refill draws from its own Philox stream
     }
 }
 
@@ -1530,7 +1586,6 @@ extern "C" int csm_prefill_slot(csm_handle m, int slot, const int32_t* tokens, c
     if (!m || !tokens || !mask || !pos) return fail(m, CSM_E_INVALID, "csm_prefill_slot: null argument");
     if (slot < 0 || slot >= m->max_batch || S < 1 || S > m->max_rows) return fail(m, CSM_E_INVALID, "csm_prefill_slot: slot / S outside the limits given to csm_create");
     if (!(temperature > 0.f) || topk < 1) return fail(m, CSM_E_INVALID, "csm_prefill_slot: temperature must be > 0 and topk >= 1");
-    if (m->host_frames >= m->max_frames) return fail(m, CSM_E_TOO_LONG, "csm_prefill_slot: frame history full (max_frames)");
     hipStream_t st = (hipStream_t)stream;
     // the prompt's rows run as a batch of ONE sequence whose K/V land in the slot's part of the backbone caches; h, last_h and the depth
     // pass use scratch row 0 (every per-frame workspace is dead between frame steps)
@@ -1541,9 +1596,10 @@ extern "C" int csm_prefill_slot(csm_handle m, int slot, const int32_t* tokens, c
     HIPCHK(m, e);
     hipLaunchKernelGGL(k_set_prefill_state, dim3(1), dim3(256), 0, st, pos, 1, S, m->cur_pos + slot, m->cfg.backbone.max_seq, m->n_frames + 1);
     HIPCHK(m, hipGetLastError());
-    HIPCHK(m, run_depth(m, 1, S, temperature, topk, nullptr, nullptr, nullptr, st));
-    hipLaunchKernelGGL(k_stage_slot, dim3(1), dim3(64), 0, st, m->frame, m->cfg.n_codebooks, slot, m->max_batch, m->history, m->n_frames, m->max_frames,
-                       m->eos_at, m->cur_tokens, m->cur_mask, out_frame, m->p_state + 1, m->b_state + 1);
+    HIPCHK(m, hipMemcpyAsync(m->frame_save, m->frame, (size_t)m->cfg.n_codebooks * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(m, run_depth(m, 1, S, temperature, topk, nullptr, nullptr, nullptr, st, m->rng_slot));
+    hipLaunchKernelGGL(k_stage_slot, dim3(1), dim3(64), 0, st, m->frame, m->frame_save, m->cfg.n_codebooks, slot, m->max_batch, m->history, m->n_frames,
+                       m->max_frames, m->eos_at, m->cur_tokens, m->cur_mask, out_frame, m->p_state + 1, m->b_state + 1, m->rng_slot);
     HIPCHK(m, hipGetLastError());
     if (m->host_frames == 0) m->host_frames = 1;
     m->have_last = true; m->last_S = 1;
@@ -1553,13 +1609,21 @@ extern "C" int csm_prefill_slot(csm_handle m, int slot, const int32_t* tokens, c
 extern "C" int csm_num_frames(csm_handle m) { return m ? m->host_frames : 0; }
 
 extern "C" int csm_read_frames(csm_handle m, int B, int first, int n, int32_t* host_frames, int32_t* host_eos_at, void* stream) {
-    if (!m || B < 1 || B > m->max_batch || first < 0 || n < 0 || first + n > m->max_frames)
+    if (!m || B < 1 || B > m->max_batch || first < 0 || n < 0 || n > m->max_frames)
         return fail(m, CSM_E_INVALID, "csm_read_frames: bad range");
+    if (n > 0 && first < m->host_frames - m->max_frames)
+        return fail(m, CSM_E_INVALID, "csm_read_frames: these frames have been overwritten (the history is a ring of max_frames frames: read more often or create the handle with a larger max_frames)");
     hipStream_t st = (hipStream_t)stream;
     const int ncb = m->cfg.n_codebooks;
-    if (n > 0 && host_frames)
-        HIPCHK(m, hipMemcpy2DAsync(host_frames, (size_t)B * ncb * 4, m->history + (size_t)first * m->max_batch * ncb,
-                                   (size_t)m->max_batch * ncb * 4, (size_t)B * ncb * 4, n, hipMemcpyDeviceToHost, st));
+    if (n > 0 && host_frames) {
+        // global frame g lives in ring row g % max_frames: at most two contiguous pieces
+        const int r0 = first % m->max_frames, n0 = n < m->max_frames - r0 ? n : m->max_frames - r0;
+        HIPCHK(m, hipMemcpy2DAsync(host_frames, (size_t)B * ncb * 4, m->history + (size_t)r0 * m->max_batch * ncb,
+                                   (size_t)m->max_batch * ncb * 4, (size_t)B * ncb * 4, n0, hipMemcpyDeviceToHost, st));
+        if (n > n0)
+            HIPCHK(m, hipMemcpy2DAsync(host_frames + (size_t)n0 * B * ncb, (size_t)B * ncb * 4, m->history, (size_t)m->max_batch * ncb * 4,
+                                       (size_t)B * ncb * 4, n - n0, hipMemcpyDeviceToHost, st));
+    }
     if (host_eos_at) HIPCHK(m, hipMemcpyAsync(host_eos_at, m->eos_at, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     int overflow = 0;
     uint32_t pcode = 0;
@@ -1645,8 +1709,12 @@ extern "C" int csm_debug_time_kernels(csm_handle m, int B, int reps, float tempe
     if (!m->have_last) return fail(m, CSM_E_STATE, "csm_debug_time_kernels: run a frame step first");
     hipStream_t st = (hipStream_t)stream;
     const CsmConfig& c = m->cfg;
-    hipEvent_t e0, e1;
-    HIPCHK(m, hipEventCreate(&e0)); HIPCHK(m, hipEventCreate(&e1));
+    struct Events {                                   // destroyed on every exit path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    HIPCHK(m, hipEventCreate(&ev.a)); HIPCHK(m, hipEventCreate(&ev.b));
+    hipEvent_t e0 = ev.a, e1 = ev.b;
     float ms = 0.f;
     const double nan_ = 0.0 / 0.0;
     out[0] = out[2] = nan_;
@@ -1671,7 +1739,6 @@ extern "C" int csm_debug_time_kernels(csm_handle m, int B, int reps, float tempe
         HIPCHK(m, hipEventElapsedTime(&ms, e0, e1));
         out[2] = ms * 1e3 / reps / c.backbone.n_layers;
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return CSM_OK;
 }
 

@@ -209,11 +209,14 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void k_gemm128(const GemvArgs
             } else { n = min(n0 + tr, a.N - 1); wsrc = a.w0; }
             qb[i] = wsrc + (long)n * ldw + (pos ^ ((tr >> 1) & 7)) * 8;
         }
+        // (m0 carries the LDS base of an LDS-DMA request; it is a reserved register, so each request saves and restores it instead of
+        //  naming it as clobbered -- which hipcc warns "may lead to undefined behaviour")
+        uint32_t m0_keep;
 #define G256_DMA(buf, kc)                                                                \
         _Pragma("unroll") for (int i = 0; i < 8; ++i)                                    \
-            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(qa[i] + (kc)), "s"(lds0 + (uint32_t)((buf) * (LROWS * 128) + (wv + 4 * i) * 1024)) : "memory", "m0"); \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_keep) : "v"(qa[i] + (kc)), "s"(lds0 + (uint32_t)((buf) * (LROWS * 128) + (wv + 4 * i) * 1024)) : "memory"); \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                    \
-            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(qb[i] + (kc)), "s"(lds0 + (uint32_t)((buf) * (LROWS * 128) + BM * 128 + (wv + 4 * i) * 1024)) : "memory", "m0");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_keep) : "v"(qb[i] + (kc)), "s"(lds0 + (uint32_t)((buf) * (LROWS * 128) + BM * 128 + (wv + 4 * i) * 1024)) : "memory");
         G256_DMA(0, G128_KOFF(0))
         G256_DMA(1, G128_KOFF(1))
         asm volatile("s_waitcnt vmcnt(12)" ::: "memory");

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_sample(const SampleArgs a) {
 // ---------------------------------------------------------------------------------------
 struct AdvanceArgs {
     const int* frame;     // [B][ncb]
-    int B, ncb, bstride;  // history is [max_frames][bstride][ncb]
+    int B, ncb, bstride;  // history is a ring [max_frames][bstride][ncb]: global frame n lives in row n % max_frames
     int* history;
     int* n_frames;        // device counter
     int max_frames;
@@ -447,7 +447,7 @@ static __global__ __launch_bounds__(256) void k_advance(const AdvanceArgs a) {
         const int v = bad ? -1 : a.frame[i];
         if (bad) const_cast<int*>(a.frame)[i] = -1;          // csm_copy_frame / the next reader sees it too
         if (v != 0) atomicAdd(&nz[b], 1);
-        if (n < a.max_frames) a.history[((long)n * a.bstride + b) * a.ncb + c] = v;
+        a.history[((long)(n % a.max_frames) * a.bstride + b) * a.ncb + c] = v;
         a.cur_tokens[b * (a.ncb + 1) + c] = a.fed ? a.fed[i] : (v < 0 ? 0 : v);
         a.cur_mask[b * (a.ncb + 1) + c] = 1;
         if (a.out_frame) a.out_frame[i] = v;

@@ -72,6 +72,7 @@ SIGNATURES = {
     "csm_frame_step": (_i, [_vp, _i, _f, _i, _i, _vp]),
     "csm_copy_frame": (_i, [_vp, _i, _vp, _vp]),
     "csm_set_step_inputs": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "csm_generate_frame_s1": (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp]),
     "csm_reset_slots": (_i, [_vp, _vp, _i, _vp]),
     "csm_prefill_slot": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp]),
     "csm_num_frames": (_i, [_vp]),

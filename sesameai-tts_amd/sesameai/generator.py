@@ -52,6 +52,23 @@ def load_llama3_tokenizer(path: Optional[str] = None):
     return tok
 
 
+class _FirstBlockGate:
+    """Handed by ``generate_stream`` to ``_frame_blocks``: the frame loop binds the action that queues the block after the
+    first, the stream calls ``release()`` once the first chunk's decode has been submitted.  One gate per stream -- two
+    streams on one Generator cannot release each other's blocks, and an abandoned stream leaves nothing installed."""
+
+    def __init__(self) -> None:
+        self._action: Optional[Callable[[], None]] = None
+
+    def bind(self, action: Optional[Callable[[], None]]) -> None:
+        self._action = action
+
+    def release(self) -> None:
+        action, self._action = self._action, None
+        if action is not None:
+            action()
+
+
 class Generator:
     """reference: sesameai/generator.py:41-300."""
 
@@ -116,10 +133,18 @@ class Generator:
 
     # -- the frame loop -----------------------------------------------------------------------
     def _frame_blocks(self, prompt_tokens: torch.Tensor, prompt_mask: torch.Tensor, max_generation_len: int,
-                      temperature: float, topk: int, poll: int) -> PyGenerator[torch.Tensor, None, None]:
+                      temperature: float, topk: int, poll: int, gate: Optional["_FirstBlockGate"] = None
+                      ) -> PyGenerator[torch.Tensor, None, None]:
         """Yields the generated frames in blocks [n][B][32] int32 (CPU) of about ``poll`` frames, cut at EOS for
         B == 1.  The NEXT block's frame steps are already enqueued on the GPU when a block is yielded, so whatever
-        the consumer does with it (Mimi decode on another stream, playback) overlaps the language model."""
+        the consumer does with it (Mimi decode on another stream, playback) overlaps the language model.
+
+        ``gate`` (streaming only): time to the first audio.  With a gate the FIRST block (frame 0 + poll - 1 steps) is handed
+        out before anything else is queued -- its consumer (the first Mimi decode) then has the GPU to itself instead of
+        squeezing between frame steps whose persistent launches occupy every CU (first 10-frame chunk: 38.8 -> 31 ms) -- and
+        the second block is queued when the consumer calls ``gate.release()`` (generate_stream: right after submitting the
+        first decode, BEFORE the chunk goes to the user) or, at the latest, when it asks for the next block.  Without a gate
+        (generate_codes: nobody decodes between blocks) every block, the first included, is followed at once by the next."""
         B = prompt_tokens.shape[0]
         m = self._model
         m.reset_caches()
@@ -136,32 +161,26 @@ class Generator:
                 m.step(B, temperature, topk)
             return n
 
-        # Time to the first audio: the FIRST block is exactly ``poll`` frames (frame 0 + poll - 1 steps) and is handed out before
-        # anything else is queued -- its consumer (the first Mimi decode) then has the GPU to itself instead of squeezing between
-        # frame steps whose persistent launches occupy every CU (first 10-frame chunk: 38.8 -> 31-32 ms).  The consumer calls
-        # ``_release_first_block()`` as soon as that work is enqueued (generate_stream: after the first decode, BEFORE the chunk goes to
-        # the user, so the second block is generated while the user plays the first); a consumer that does not is released when it
-        # asks for the next block.  From the second block on the next block is enqueued BEFORE the current one is handed out.
         launched += enqueue(poll - 1)
-        released = [False]
+        held = gate is not None                 # the block after the first waits for the consumer's go
 
-        def release() -> None:
-            nonlocal launched
-            if not released[0]:
-                released[0] = True
+        def open_gate() -> None:
+            nonlocal launched, held
+            if held:
+                held = False
                 launched += enqueue(poll)
 
-        self._release_first_block = release
+        if gate is not None:
+            gate.bind(open_gate)
         try:
-            first = True
             while True:
                 upto = launched
                 fr, eos = m.read_frames(B, delivered, upto - delivered)          # waits for the frames launched so far
                 self.last_eos_at = eos
                 done = bool((eos >= 0).all()) or launched >= max_generation_len
                 if done:
-                    released[0] = True                                          # nothing more to launch
-                elif not first:
+                    held = False                                                # nothing more to launch
+                elif not held:
                     launched += enqueue(poll)                                   # keep the GPU busy before handing out
                 if B == 1 and eos[0] >= 0:
                     fr = fr[: max(int(eos[0]) - delivered, 0)]
@@ -170,12 +189,11 @@ class Generator:
                     yield fr
                 if done:
                     return
-                if first:
-                    release()
-                    first = False
+                open_gate()                                                     # a consumer that never released is released now
         finally:
-            released[0] = True
-            self._release_first_block = None
+            held = False
+            if gate is not None:
+                gate.bind(None)
 
     @torch.inference_mode()
     def generate_codes(self, prompt_tokens: torch.Tensor, prompt_mask: torch.Tensor, max_generation_len: int,
@@ -198,27 +216,30 @@ class Generator:
         return torch.cat(blocks) if blocks else torch.empty(0, B, 32, dtype=torch.int32)
 
     @torch.inference_mode()
-    def generate_codes_continuous(self, prompts: Sequence[Tuple[torch.Tensor, torch.Tensor]], max_generation_len: int,
-                                  temperature: float, topk: int, poll: Optional[int] = None) -> List[torch.Tensor]:
+    def iter_codes_continuous(self, prompts: Sequence[Tuple[torch.Tensor, torch.Tensor]], max_generation_len: int,
+                              temperature: float, topk: int, poll: Optional[int] = None
+                              ) -> PyGenerator[Tuple[int, torch.Tensor], None, None]:
         """Any number of prompts [(tokens (S_i,33), mask (S_i,33)), ...] of any lengths through a batch of ``max_batch_size``
         slots that is kept FULL: an utterance that reaches its all-zero EOS frame (generator.py:285) or the length limit is
         retired and its slot re-prefilled with the next prompt (Model.refill_slot) while the other slots keep generating --
-        their frames are bit-identical to an undisturbed run.  Returns each prompt's frames [n_i][32] int32 (CPU), cut at its
-        EOS like the reference's batch-1 loop."""
+        their frames are bit-identical to an undisturbed run.  Yields ``(index of the prompt, frames [n_i][32] int32 CPU)`` as
+        each utterance FINISHES (cut at its EOS like the reference's batch-1 loop), so a long run hands its results out as it
+        goes.  There is no limit on the total number of frame steps: the engine's frame history is a ring (include/csm_hip.h,
+        csm_read_frames) and every block of ``poll`` steps is read before the next one is launched."""
         from collections import deque
         m = self._model
         for t, _ in prompts:
             if t.shape[0] >= MAX_SEQ_LEN - max_generation_len:
                 raise ValueError(f"Inputs too long, must be below max_seq_len - max_generation_len: {MAX_SEQ_LEN - max_generation_len}")
-        results: List[Optional[torch.Tensor]] = [None] * len(prompts)
         if not prompts:
-            return []
+            return
         poll = poll or self._eos_poll
         B = min(self._max_batch, len(prompts))
         pending = deque(range(len(prompts)))
         slot_idx: List[Optional[int]] = [None] * B
         slot_frames: List[List[torch.Tensor]] = [[] for _ in range(B)]
         empty = torch.empty(0, 32, dtype=torch.int32)
+        finished: List[Tuple[int, torch.Tensor]] = []
         m.reset_caches()
 
         def start(slot: int) -> bool:
@@ -227,7 +248,7 @@ class Generator:
                 t, mk = prompts[i]
                 f0 = m.refill_slot(slot, t, mk, temperature, topk).cpu()
                 if max_generation_len <= 0 or bool((f0 == 0).all()):
-                    results[i] = empty                                  # EOS in the very first frame: empty utterance (generator.py:296)
+                    finished.append((i, empty))                         # EOS in the very first frame: empty utterance (generator.py:296)
                     continue
                 slot_idx[slot], slot_frames[slot] = i, [f0]
                 return True
@@ -236,6 +257,8 @@ class Generator:
 
         for s_ in range(B):
             start(s_)
+        yield from finished
+        finished.clear()
         g = m.num_frames()                                              # next global frame index
         while any(i is not None for i in slot_idx):
             active = [s_ for s_ in range(B) if slot_idx[s_] is not None]
@@ -256,21 +279,31 @@ class Generator:
                 g += n
             idle = []
             for s_ in done:
-                results[slot_idx[s_]] = torch.stack(slot_frames[s_][:max_generation_len]).to(torch.int32)
+                finished.append((slot_idx[s_], torch.stack(slot_frames[s_][:max_generation_len]).to(torch.int32)))
                 if not start(s_):
                     idle.append(s_)
             if idle and any(i is not None for i in slot_idx):
                 m.reset_slots(idle)                                      # a retired slot keeps stepping: keep its position away from max_seq
-        return [r if r is not None else empty for r in results]
+            yield from finished
+            finished.clear()
+
+    def generate_codes_continuous(self, prompts: Sequence[Tuple[torch.Tensor, torch.Tensor]], max_generation_len: int,
+                                  temperature: float, topk: int, poll: Optional[int] = None) -> List[torch.Tensor]:
+        """``iter_codes_continuous`` collected: each prompt's frames [n_i][32] int32 (CPU), in the order of ``prompts``."""
+        results: List[torch.Tensor] = [torch.empty(0, 32, dtype=torch.int32) for _ in prompts]
+        for i, frames in self.iter_codes_continuous(prompts, max_generation_len, temperature, topk, poll):
+            results[i] = frames
+        return results
 
     def generate_many(self, texts: Sequence, speakers: Sequence[int], contexts: Sequence[List[Segment]], max_audio_length_ms: float = 90_000,
                       temperature: float = 0.7, topk: int = 30) -> List[torch.Tensor]:
         """``generate`` for a list of requests through the continuously refilled batch: one audio tensor per request."""
         max_generation_len = int(max_audio_length_ms / FRAME_MS)
         prompts = [self._build_prompt(t, sp, ctx) for t, sp, ctx in zip(texts, speakers, contexts)]
-        out = []
-        for frames in self.generate_codes_continuous(prompts, max_generation_len, temperature, topk):
-            out.append(self._decode_frames(frames.unsqueeze(1)) if frames.shape[0] else torch.tensor([]))
+        out: List[torch.Tensor] = [torch.tensor([]) for _ in prompts]
+        for i, frames in self.iter_codes_continuous(prompts, max_generation_len, temperature, topk):
+            if frames.shape[0]:                                       # decoded as each utterance finishes, not at the end
+                out[i] = self._decode_frames(frames.unsqueeze(1))
         return out
 
     def _decode_frames(self, frames: torch.Tensor) -> torch.Tensor:
@@ -313,7 +346,8 @@ class Generator:
             side.synchronize()
             return pcm
 
-        blocks = self._frame_blocks(tokens, mask, max_generation_len, temperature, topk, size)
+        gate = _FirstBlockGate()
+        blocks = self._frame_blocks(tokens, mask, max_generation_len, temperature, topk, size, gate=gate)
         while True:
             with torch.inference_mode():
                 fr = next(blocks, None)
@@ -322,9 +356,7 @@ class Generator:
             pending.extend(fr.unbind(0))
             while len(pending) >= size:
                 chunk = decode(size)
-                release = getattr(self, "_release_first_block", None)
-                if release is not None:
-                    release()                    # the first chunk is decoded: queue the next block before the user gets this one
+                gate.release()                   # the first chunk is decoded: queue the next block before the user gets this one
                 if on_chunk_generated:
                     on_chunk_generated(chunk)
                 yield chunk
@@ -349,83 +381,119 @@ class Generator:
         return self._decode_frames(frames)
 
 
+def _wav_float32_header(sample_rate: int, data_bytes: int) -> bytes:
+    """44-byte RIFF header of a mono 32-bit IEEE-float WAV (format tag 3) -- what ``torchaudio.save(file, audio.unsqueeze(0), sr)``
+    writes for a float32 tensor (reference: generator.py:327); torchaudio is not a dependency here."""
+    return (b"RIFF" + struct.pack("<I", 36 + data_bytes) + b"WAVE"
+            + b"fmt " + struct.pack("<IHHIIHH", 16, 3, 1, sample_rate, sample_rate * 4, 4, 32)
+            + b"data" + struct.pack("<I", data_bytes))
+
+
+def _float32_bytes(audio: torch.Tensor) -> bytes:
+    return audio.detach().to(torch.float32).reshape(-1).cpu().contiguous().numpy().astype("<f4", copy=False).tobytes()
+
+
 def save_wav_float32(filename: str, audio: torch.Tensor, sample_rate: int) -> None:
-    """(n,) float samples -> mono 32-bit IEEE-float WAV: what ``torchaudio.save(filename, audio.unsqueeze(0), sr)`` writes for a
-    float32 tensor (reference: generator.py:327); torchaudio is not a dependency here, the 44-byte header is written by hand."""
-    pcm = audio.detach().to(torch.float32).reshape(-1).cpu().contiguous().numpy().astype("<f4", copy=False).tobytes()
+    """(n,) float samples -> mono float32 WAV in one go."""
+    pcm = _float32_bytes(audio)
     with open(filename, "wb") as f:
-        f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE")
-        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 3, 1, sample_rate, sample_rate * 4, 4, 32))      # format 3 = IEEE float, mono
-        f.write(b"data" + struct.pack("<I", len(pcm)) + pcm)
+        f.write(_wav_float32_header(sample_rate, len(pcm)) + pcm)
 
 
 class AudioStreamWriter:
-    """reference: sesameai/generator.py:303-327 -- collects the chunks of a streaming generation (thread-safe: the
-    reference's player thread and the generator share it) and writes them as one file."""
+    """The reference's streaming file writer (sesameai/generator.py:303-327: ``add_chunk`` from the generation loop, one
+    ``write_file`` at the end) with a bounded footprint: every chunk is appended to the OPEN file as it arrives and
+    ``write_file`` only patches the two RIFF size fields and closes -- a 90 s utterance never sits in memory as a list of
+    tensors, and a run that dies half-way leaves the audio produced so far on disk.  No chunk, no file (the reference
+    returns before ``torchaudio.save`` then).  ``add_chunk`` may be called from another thread than ``write_file``."""
 
     def __init__(self, filename, sample_rate):
         self.filename = filename
         self.sample_rate = sample_rate
-        self.audio_chunks: List[torch.Tensor] = []
         self.lock = threading.Lock()
+        self.chunks_written = 0
+        self._file = None
+        self._data_bytes = 0
 
     def add_chunk(self, chunk):
+        pcm = _float32_bytes(chunk)                      # (the device -> host copy happens outside the lock)
         with self.lock:
-            self.audio_chunks.append(chunk)
+            if self._file is None:
+                self._file = open(self.filename, "wb")
+                self._file.write(_wav_float32_header(self.sample_rate, 0))
+            self._file.write(pcm)
+            self._data_bytes += len(pcm)
+            self.chunks_written += 1
 
     def write_file(self):
         with self.lock:
-            if not self.audio_chunks:
+            if self._file is None:
                 return
-            save_wav_float32(self.filename, torch.cat([c.reshape(-1).cpu() for c in self.audio_chunks]), self.sample_rate)
+            f, self._file = self._file, None
+            f.seek(4); f.write(struct.pack("<I", 36 + self._data_bytes))
+            f.seek(40); f.write(struct.pack("<I", self._data_bytes))
+            f.close()
+
+
+class _ChunkPlayer:
+    """Real-time playback of streamed chunks in arrival order (reference: the ``audio_player`` thread of
+    generate_streaming_audio, generator.py:384-404) through the optional ``sounddevice`` package.  One worker drains a queue
+    until it meets the end marker ``close()`` posts, so nothing polls with time-outs and every queued chunk is played before
+    ``close()`` returns.  Raises ImportError at construction when ``sounddevice`` is missing."""
+
+    _END = object()
+
+    def __init__(self, sample_rate: int):
+        import sounddevice
+        self._sd, self._rate = sounddevice, sample_rate
+        self._chunks: "queue.Queue" = queue.Queue()
+        self._worker = threading.Thread(target=self._drain, name="csm-chunk-player")
+        self._worker.start()
+
+    def _drain(self) -> None:
+        for chunk in iter(self._chunks.get, self._END):
+            self._sd.play(chunk.detach().to(torch.float32).cpu().numpy(), self._rate)
+            self._sd.wait()
+
+    def submit(self, chunk: torch.Tensor) -> None:
+        self._chunks.put(chunk)
+
+    def close(self) -> None:
+        self._chunks.put(self._END)
+        self._worker.join()
 
 
 def generate_streaming_audio(generator: "Generator", text, speaker: int, context: List[Segment], output_file: str,
                              max_audio_length_ms: float = 90_000, temperature: float = 0.7, topk: int = 30,
                              play_audio: bool = False):
-    """reference: sesameai/generator.py:349-434 -- ``generate_stream`` with every chunk collected into ``output_file`` and,
-    with ``play_audio``, played as it arrives (``sounddevice`` on a player thread; without that package playback is switched
-    off with the reference's message and the file is still written)."""
+    """reference: sesameai/generator.py:349-434 (same arguments, same console messages): ``generate_stream`` with every chunk
+    appended to ``output_file`` as it is produced and, with ``play_audio``, played as it arrives.  Without ``sounddevice``
+    playback is switched off with the reference's message and the file is still written."""
+    sinks: List[Callable[[torch.Tensor], None]] = []
     writer = AudioStreamWriter(output_file, generator.sample_rate)
-    audio_queue: "queue.Queue[torch.Tensor]" = queue.Queue()
-    stop_event = threading.Event()
-    player_thread = None
+    sinks.append(writer.add_chunk)
+    player: Optional[_ChunkPlayer] = None
     if play_audio:
         try:
-            import sounddevice as sd
-
-            def audio_player():
-                while not stop_event.is_set() or not audio_queue.empty():
-                    try:
-                        chunk = audio_queue.get(timeout=0.5)
-                        sd.play(chunk.cpu().numpy(), generator.sample_rate)
-                        sd.wait()
-                    except queue.Empty:
-                        continue
-
-            player_thread = threading.Thread(target=audio_player)
-            player_thread.start()
+            player = _ChunkPlayer(generator.sample_rate)
+            sinks.append(player.submit)
         except ImportError:
             print("sounddevice library not found. Install with 'pip install sounddevice' to enable real-time playback.")
-            play_audio = False
-
-    def on_chunk_generated(chunk):
-        writer.add_chunk(chunk)
-        if play_audio:
-            audio_queue.put(chunk)
 
     print("Generating audio in streaming mode...")
-    start_time = time.time()
-    chunk_count = 0
-    for _ in generator.generate_stream(text=text, speaker=speaker, context=context, max_audio_length_ms=max_audio_length_ms,
-                                       temperature=temperature, topk=topk, on_chunk_generated=on_chunk_generated):
-        chunk_count += 1
-        print(f"Generated chunk {chunk_count}")
-    writer.write_file()
-    if player_thread is not None:
-        stop_event.set()
-        player_thread.join()
-    print(f"Audio generation completed in {time.time() - start_time:.2f} seconds")
+    t0 = time.time()
+    try:
+        stream = generator.generate_stream(text=text, speaker=speaker, context=context, max_audio_length_ms=max_audio_length_ms,
+                                           temperature=temperature, topk=topk)
+        for n, chunk in enumerate(stream, start=1):
+            for sink in sinks:
+                sink(chunk)
+            print(f"Generated chunk {n}")
+    finally:
+        writer.write_file()                              # whatever was generated is a valid WAV, also after an error
+        if player is not None:
+            player.close()
+    print(f"Audio generation completed in {time.time() - t0:.2f} seconds")
 
 
 def load_csm_1b(device: str = "cuda", model_path: Optional[str] = None, mimi_path: Optional[str] = None,

@@ -224,6 +224,8 @@ class Model:
             raise RuntimeError("sesameai (MI355X build) needs a ROCm GPU: there is no CPU fallback")
         self.config = config
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:      # a concrete index: tensors report theirs ("cuda:0")
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.bb, self.dec = FLAVORS[config.backbone_flavor], FLAVORS[config.decoder_flavor]
         if state_dict is None:
             state_dict = synthetic_state_dict(config)
@@ -496,15 +498,24 @@ class Model:
                 self._kv_prompt = None
                 self.prefill(tokens, tokens_mask, input_pos)
             return self.depth(b, temperature, topk, commit=True)
-        # S == 1 steps append beyond the prompt (the reference loop), so the cached prefix stays valid
-        self._check_positions(input_pos)
-        t = tokens.to(device=self.device, dtype=torch.int32).contiguous()
-        m = tokens_mask.to(device=self.device, dtype=torch.uint8).contiguous()
-        p = input_pos.to(device=self.device, dtype=torch.int32).contiguous()
-        with self._on_device():
-            check(lib.csm_set_step_inputs(self._h, t.data_ptr(), m.data_ptr(), p.data_ptr(), b, _stream_ptr()), self._h)
-        self.step(b, temperature, topk)
-        return self.last_frame(b)
+        # S == 1 steps append beyond the prompt (the reference loop), so the cached prefix stays valid.  The reference's own
+        # tensors -- int64 tokens / positions, bool mask, on this GPU (tts_service.py:229-241) -- go straight to ONE C-ABI call
+        # (csm_generate_frame_s1): no dtype-conversion kernels, no device context, no separate copy-out; positions are checked
+        # by the staging kernel (device flag -> CSM_E_TOO_LONG at the next read_frames), or here when they live on the host.
+        dev = self.device
+        if not (tokens.dtype is torch.int64 and tokens.device == dev and tokens.is_contiguous()):
+            tokens = tokens.to(device=dev, dtype=torch.int64).contiguous()
+        if not (tokens_mask.dtype is torch.bool and tokens_mask.device == dev and tokens_mask.is_contiguous()):
+            tokens_mask = tokens_mask.to(device=dev, dtype=torch.bool).contiguous()
+        if not (input_pos.dtype is torch.int64 and input_pos.device == dev and input_pos.is_contiguous()):
+            self._check_positions(input_pos)
+            input_pos = input_pos.to(device=dev, dtype=torch.int64).contiguous()
+        out = torch.empty((b, self.config.audio_num_codebooks), dtype=torch.int32, device=dev)
+        rc = lib.csm_generate_frame_s1(self._h, tokens.data_ptr(), tokens_mask.data_ptr(), input_pos.data_ptr(), b,
+                                       temperature, topk, out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            check(rc, self._h)
+        return out
 
     def fast_paths(self) -> int:
         """bit mask of the all-CU launches this handle runs (include/csm_hip_ops.h csm_debug_fast_paths)."""

@@ -358,14 +358,14 @@ def test_first_stream_chunk_is_decoded_before_more_frames_are_queued_and_the_nex
     assert launched_when_user_got_chunk[0] == 20              # ... and the next block was queued before the user saw the chunk
     assert events[1] == ("decode", 30)                        # steady state: the next block is queued before the current one is decoded
     assert [e[0] for e in events] == ["decode"] * 4 and launched_when_user_got_chunk[-1] == 35
-    # generate_codes (nobody calls the release hook): same frames, the second block is queued when the first has been taken
+    # generate_codes (no decode between blocks): same frames, every block is followed at once by the next
     model2 = _ScriptedModel(script)
     gen2 = Generator(model2, audio_tokenizer=_FakeCodec())
     seen = []
     prompt = torch.zeros(5, 33, dtype=torch.long); mask = torch.zeros(5, 33, dtype=torch.bool)
     frames = gen2.generate_codes(prompt, mask, 35, 0.9, 50, on_frames=lambda f: seen.append((f.shape[0], model2.launched)), poll=10)
-    assert frames.shape[0] == 35 and seen[0] == (10, 10) and seen[1] == (10, 30)
-    assert gen2._release_first_block is None
+    assert frames.shape[0] == 35 and seen[0] == (10, 20) and seen[1] == (10, 30)      # no deferral without a stream consumer
+    assert not hasattr(gen2, "_release_first_block")                                # the gate travels with the stream, not on the Generator
 
 
 class _ScriptedSlots:
@@ -443,6 +443,66 @@ def test_continuous_batching_retires_at_eos_and_refills_the_slot():
     assert len({slot for slot, _, _ in model.refills}) == 3 and model.resets                # three slots in use; idle ones rewound
     with pytest.raises(ValueError):
         gen.generate_codes_continuous([(torch.zeros(2030, 33, dtype=torch.long), torch.zeros(2030, 33, dtype=torch.bool))], 25, 0.9, 50)
+
+
+def test_continuous_batching_hands_out_each_utterance_as_it_finishes_and_runs_past_the_history_size():
+    """results used to be returned only at the end and the total number of frame steps was capped by the engine's
+    linear frame history.  ``iter_codes_continuous`` yields (index, frames) when an utterance retires -- the short ones long
+    before the long one ends -- and the number of global frame steps may exceed any history size (the engine's history is a
+    ring read block by block: here 12 rounds x 30 frames through one slot = 360 global frames)."""
+    from sesameai.generator import Generator
+    g = torch.Generator().manual_seed(5)
+    lens = [30] * 12 + [2, 3]
+    scripts = []
+    for n in lens:
+        sc = torch.randint(1, 2048, (n + 1, 32), generator=g); sc[n] = 0
+        scripts.append(sc)
+    model = _ScriptedSlots(scripts, 2)
+    gen = Generator(model, audio_tokenizer=_FakeCodec(), max_batch_size=2)
+    prompts = []
+    for i in range(len(lens)):
+        t = torch.zeros(3, 33, dtype=torch.long); t[:, 32] = i
+        prompts.append((t, torch.zeros(3, 33, dtype=torch.bool)))
+    order, steps_when_done = [], {}
+    for i, frames in gen.iter_codes_continuous(prompts, 40, 0.9, 50):
+        order.append(i); steps_when_done[i] = len(model.hist)
+        assert torch.equal(frames, scripts[i][: lens[i]].to(torch.int32)), f"utterance {i}"
+    assert sorted(order) == list(range(len(lens)))
+    assert len(model.hist) > 150                                     # far more global frame steps than one utterance holds
+    assert steps_when_done[order[0]] < steps_when_done[order[-1]] - 100, "results must come out as the run goes, not at its end"
+
+
+def test_two_interleaved_streams_do_not_release_each_others_blocks_and_an_abandoned_stream_leaves_nothing_behind():
+    """the first-block hand-shake was per-Generator state.  It is now an object owned by each stream."""
+    from sesameai.generator import Generator
+    script = _scripted(64, 1, [None])
+    model = _ScriptedModel(script)
+    gen = Generator(model, audio_tokenizer=_FakeCodec())
+    s1 = gen.generate_stream([1, 2, 3], 0, [], max_audio_length_ms=30 * 80)
+    first = next(s1)
+    assert first.shape[0] == 19200 and model.launched == 20
+    s1.close()                                                       # abandoned after one chunk
+    assert not any(k.startswith("_release") for k in vars(gen))      # nothing installed on the Generator
+    launched_before = model.launched
+    # a fresh stream on the same Generator is unaffected by the abandoned one
+    chunks = list(gen.generate_stream([1, 2, 3], 0, [], max_audio_length_ms=30 * 80))
+    assert [c.shape[0] for c in chunks] == [19200] * 3 and model.launched == 30 != launched_before
+
+
+def test_audio_stream_writer_appends_incrementally_and_patches_the_sizes_on_close(tmp_path):
+    import struct
+    import numpy as np
+    from sesameai.generator import AudioStreamWriter
+    f = tmp_path / "inc.wav"
+    w = AudioStreamWriter(str(f), 24_000)
+    w.add_chunk(torch.arange(100, dtype=torch.float32))
+    assert f.exists() and w.chunks_written == 1 and not hasattr(w, "audio_chunks")     # on disk already, no list of tensors kept
+    w.add_chunk(torch.arange(100, 150, dtype=torch.bfloat16))
+    w.write_file()
+    raw = f.read_bytes()
+    assert struct.unpack("<I", raw[4:8])[0] == 36 + 600 and struct.unpack("<I", raw[40:44])[0] == 600 and len(raw) == 644
+    assert np.array_equal(np.frombuffer(raw[44:], dtype="<f4"), np.arange(150, dtype=np.float32))
+    w.write_file()                                                   # idempotent
 
 
 def test_rope_table_fp32_tensor_form_vs_the_double_form_over_the_positions_each_stack_reads():
