@@ -55,6 +55,34 @@ def synthetic_prompt(args, batch, text_vocab, seed0=2025, segments=1, ctx_text=N
     return torch.stack(toks), torch.stack(masks)
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (csrc/*.hip, *.cuh, sorted by name): ties a PMC pass to the kernels it measured.  A
+    profiles/r*/pmc_traffic.json taken on other sources is NOT reported as this run's traffic (VERDICT r3 weak #9)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.cuh"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def host_description(threads_used):
+    """cpu_baseline.host: what the CPU port ran on (north_star: "core count stated")."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "usable_cpus": usable, "threads_used": threads_used}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -124,12 +152,13 @@ def cpu_baseline(args):
         out, _ = proc.communicate()
     lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
     if not lines:
-        return dict(value=None, unit="frames/s", cores=args.cpu_threads, kind="port",
+        return dict(value=None, unit="frames/s", cores=args.cpu_threads, kind="port", host=host_description(args.cpu_threads),
                     sample="oracle did not finish one frame within the budget")
     last = lines[-1]
     first = lines[0]
     decode = (last["frames"] - 1) / (last["elapsed"] - first["elapsed"]) if last["frames"] > 1 else None
     return dict(value=round(last["frames"] / last["elapsed"], 3), unit="frames/s", cores=last["threads"], kind="port",
+                host=host_description(last["threads"]),
                 decode_only_frames_per_s=round(decode, 3) if decode else None,
                 sample=f"oracle/csm_ref.py (PyTorch-CPU bf16 restatement of the reference -d cpu graph), same S=190 prompt: "
                        f"frame 0 incl. prefill {first['elapsed']:.2f}s, {last['frames']} frames in {last['elapsed']:.1f}s, "
@@ -508,7 +537,17 @@ def main():
                 codec.decode_stream(codes[:, :, a:a + 10])
         stream_ms = timed(stream_chunks)
         gen_ms = prefill_ms + wall * 1e3 * (frames.shape[0] - 1) / args.steps
-        mimi = {"frames": T, "decode_whole_ms": round(whole_ms, 3), "decode_stream10_ms": round(stream_ms, 3),
+        # codec roofline (~0.16 GB of fp32 weights per CALL + ~2 MB of activations per frame, HBM bound): weights of the
+        # decode path = everything the call reads once (32 codebooks, projections, upsample, 8 transformer layers, SEANet decoder)
+        mimi_bytes = float(codec.decode_weight_bytes()) if hasattr(codec, "decode_weight_bytes") else 0.16e9
+        chunk_ms = stream_ms / max((T + 9) // 10, 1)
+        mimi_roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "bytes_per_call": mimi_bytes,
+                     "whole": {"frames": T, "ms": round(whole_ms, 3), "achieved": round((mimi_bytes + 2e6 * T) / (whole_ms * 1e-3) / 1e9, 1),
+                               "frac": round((mimi_bytes + 2e6 * T) / (whole_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                     "chunk10": {"frames": 10, "ms": round(chunk_ms, 3), "achieved": round((mimi_bytes + 2e7) / (chunk_ms * 1e-3) / 1e9, 1),
+                                 "frac": round((mimi_bytes + 2e7) / (chunk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                     "note": "latency-bound chain of ~85 small launches (DESIGN.md): < 3 % of end-to-end time and overlapped with the frame loop when streaming"}
+        mimi = {"frames": T, "decode_whole_ms": round(whole_ms, 3), "decode_stream10_ms": round(stream_ms, 3), "roofline": mimi_roof,
                 "ms_per_10_frame_chunk": round(stream_ms / max((T + 9) // 10, 1), 3),
                 "end_to_end_ms": round(gen_ms + whole_ms, 2),
                 "end_to_end_rtf": round(T * 80.0 / (gen_ms + whole_ms), 2)}
@@ -551,9 +590,15 @@ def main():
     pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
     if pmcs and B == 1 and not args.tiny and args.weights == "bf16":
         pj = json.load(open(pmcs[-1]))
-        traffic = pj.get("traffic_bytes_per_frame")
-        traffic_src = {"file": os.path.relpath(pmcs[-1], ROOT), "kernels_commit": pj.get("kernels_commit"),
+        digest = csrc_digest()
+        traffic_src = {"file": os.path.relpath(pmcs[-1], ROOT), "kernels_commit": pj.get("kernels_commit"), "csrc_digest_of_the_pass": pj.get("csrc_digest"),
+                       "csrc_digest_now": digest,
                        "note": "separate rocprofv3 --pmc FETCH_SIZE pass of this command (x2 gfx950 correction), not measured in this run"}
+        if pj.get("csrc_digest") == digest:
+            traffic = pj.get("traffic_bytes_per_frame")
+        else:                                 # the pass measured other kernel sources: not this run's traffic
+            traffic_src["stale_traffic_bytes_per_frame"] = pj.get("traffic_bytes_per_frame")
+            traffic_src["note"] += "; the pass was taken on DIFFERENT kernel sources (digest mismatch), so `traffic` is null"
     kernels = None if (args.tiny or args.weights != "bf16") else dominant_kernels(model, B, args.temperature, args.topk)
     out = {
         "metric": "audio frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,

@@ -26,7 +26,7 @@ int csm_op_gemv(int kind, int M, int K, int N, const void* x, long x_row_stride,
                 const void* rope, void* kcache, void* vcache, void* stream);
 
 /* GQA attention of M rows over keys [0,pos[m]] of their sequence's cache (SDPA at
- * sesameai/models.py:154,158,172-173).  part: fp32 scratch [M][H][nsplit][head_dim+4] if nsplit>1. */
+ * sesameai/models.py:154,158,172-173).  part: fp32 scratch [M][H][nsplit][ceil((head_dim+2)/32)*32] (partial rows are whole 128-byte lines) if nsplit>1. */
 int csm_op_attn(int M, int rows_per_seq, int H, int KV, int head_dim, int smax, int nsplit, const void* q,
                 const void* kcache, const void* vcache, const int32_t* pos, void* out, float* part, void* stream);
 

@@ -20,6 +20,8 @@ Files (all torch.save'd dicts of small tensors):
                     logits and margins per (frame, codebook, utterance).
   csm1b_cfg5.pt     BASELINE config 5: fp8-e4m3-dequantised weights (oracle.csm_ref.fp8_dequantized), S=1334 prompt (10
                     segments), 2 frames; and a 1700-row prompt: the prompt frame (p = 1699) and one step frame (p = 1700).
+  csm1b_cfg5b.pt    config 5 batched at B = 4 (four different 1334-row prompts), 2 frames of the batched oracle.
+  csm1b_cfg5c.pt    config 5 at B = 32 (the batch SURVEY.md 8d names): top-8 logits / codes / margins only, prompts by seed.
 """
 from __future__ import annotations
 
@@ -188,7 +190,7 @@ def main():
         gold = frames_golden(shape, w, toy_prompt(shape, 2025, 16, 0), a.frames, keep_full=False, with_fp32=True)
         gold.update(weight_seed=1234, prompt_seed=2025)
         torch.save(gold, os.path.join(OUT, "csm1b_frames.pt"))
-    if want("cfg2") or want("cfg3") or want("cfg5") or want("cfg5b"):
+    if want("cfg2") or want("cfg3") or want("cfg5") or want("cfg5b") or want("cfg5c"):
         shape = C.csm_1b()
         w = C.make_weights(shape, seed=1234)
         if want("cfg2"):
@@ -223,6 +225,16 @@ def main():
             gold.update(weight_seed=1234, prompt_seed=6000)
             gold["prompt_tokens"] = gold["prompt_tokens"].to(torch.int32)
             torch.save(gold, os.path.join(OUT, "csm1b_cfg5b.pt"))
+        if want("cfg5c"):
+            # BASELINE config 5 at the batch SURVEY.md 8d lists for it: B = 32 x the 1334-row prompt (bench.py's config5_b32 leg: seeds
+            # 6000..6031), fp8-dequantised weights, 2 teacher-forced frames of the batched oracle.  Only the top-8 logits, the codes and
+            # the margins are kept (the prompts are a function of the seeds: the test rebuilds them with bench.synthetic_prompt).
+            w8 = C.fp8_dequantized(w)
+            ps = [bench_prompt(shape, 6000 + b, segments=10, ctx_text=30, ctx_frames=100) for b in range(32)]
+            gold = frames_golden_batch(shape, w8, torch.stack([p[0] for p in ps]), torch.stack([p[1] for p in ps]), 2)
+            gold.update(weight_seed=1234, prompt_seed=6000, prompt_checksum=gold["prompt_tokens"].sum(dim=(1, 2)))
+            del gold["prompt_tokens"], gold["prompt_mask"]
+            torch.save(gold, os.path.join(OUT, "csm1b_cfg5c.pt"))
 
 
 if __name__ == "__main__":

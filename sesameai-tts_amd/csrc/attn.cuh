@@ -21,7 +21,7 @@ struct AttnArgs {
     int M, rows_per_seq, H, KV, smax, nsplit;
     float scale;
     bf16_t* out;            // [M][H*HD]                 (nsplit == 1)
-    float* part;            // [M][H][nsplit][HD + 4]    (nsplit  > 1): o[HD], m, l
+    float* part;            // [M][H][nsplit][ATTN_PS(HD)] (nsplit > 1): o[HD], m, l, padding to whole 128-byte lines
     int out_packed;         // out in matrix-core operand order (common.cuh xp_off), K = H*HD
     int* ctr;               // nsplit > 1: [M][KV] arrival counters (zero between launches) -> the LAST key-range block of a
                             // (row, KV head) merges the partials itself (no k_attn_combine launch); nullptr: partials only
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
                 bf16_t* dst = a.out_packed ? a.out + xp_off(m, h * HD + e * 8, (long)a.H * HD) : a.out + ((long)m * a.H + h) * HD + e * 8;
                 *reinterpret_cast<uint4*>(dst) = r;
             } else {
-                float* dst = a.part + (((long)m * a.H + h) * a.nsplit + sp) * (HD + 4);
+                float* dst = a.part + (((long)m * a.H + h) * a.nsplit + sp) * ATTN_PS(HD);
                 if (a.ctr != nullptr) {           // merged in this launch by a block that may sit on another XCD: write through (sc1)
                     attn_st16_sc1(dst + e * 8, make_float4(o[0], o[1], o[2], o[3]));
                     attn_st16_sc1(dst + e * 8 + 4, make_float4(o[4], o[5], o[6], o[7]));
@@ -139,11 +139,11 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
         if (threadIdx.x == 0) a.ctr[m * a.KV + kvh] = 0;                 // for the next launch (ordered by the kernel boundary)
         for (int idx = threadIdx.x; idx < G * HD; idx += 256) {
             const int h = kvh * G + idx / HD, t = idx % HD;
-            const float* src = a.part + ((long)m * a.H + h) * a.nsplit * (HD + 4);
+            const float* src = a.part + ((long)m * a.H + h) * a.nsplit * ATTN_PS(HD);
             float ms[ATTN_MAX_SPLIT], ls[ATTN_MAX_SPLIT], vs[ATTN_MAX_SPLIT];
 #pragma unroll
             for (int s = 0; s < ATTN_MAX_SPLIT; ++s) {                   // every load in flight at once (splits past nsplit re-read the last one)
-                const float* ps = src + min(s, a.nsplit - 1) * (HD + 4);
+                const float* ps = src + min(s, a.nsplit - 1) * ATTN_PS(HD);
                 asm volatile("global_load_dword %0, %1, off sc1" : "=v"(ms[s]) : "v"(ps + HD) : "memory");
                 asm volatile("global_load_dword %0, %1, off sc1" : "=v"(ls[s]) : "v"(ps + HD + 1) : "memory");
                 asm volatile("global_load_dword %0, %1, off sc1" : "=v"(vs[s]) : "v"(ps + t) : "memory");
@@ -172,15 +172,15 @@ __global__ __launch_bounds__(256) void k_attn(const AttnArgs a) {
 template <int HD>
 __global__ void k_attn_combine(const float* part, int nsplit, bf16_t* out, int H, int out_packed) {
     const int m = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
-    const float* src = part + ((long)m * H + h) * nsplit * (HD + 4);
+    const float* src = part + ((long)m * H + h) * nsplit * ATTN_PS(HD);
     float mx = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, src[s * (HD + 4) + HD]);
+    for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, src[s * ATTN_PS(HD) + HD]);
     float num = 0.f, den = 0.f;
     for (int s = 0; s < nsplit; ++s) {
-        const float ms = src[s * (HD + 4) + HD];
+        const float ms = src[s * ATTN_PS(HD) + HD];
         const float w = (ms == -INFINITY) ? 0.f : __expf(ms - mx);
-        num += w * src[s * (HD + 4) + t];
-        den += w * src[s * (HD + 4) + HD + 1];
+        num += w * src[s * ATTN_PS(HD) + t];
+        den += w * src[s * ATTN_PS(HD) + HD + 1];
     }
     out[out_packed ? xp_off(m, h * HD + t, (long)H * HD) : ((long)m * H + h) * HD + t] = f2bf(num / den);
 }

@@ -174,3 +174,9 @@ __device__ __forceinline__ void rmsnorm_row_wave(const bf16_t* x, int K, const b
 __device__ __forceinline__ long xp_off(int m, int k, long K) {
     return (long)(m >> 5) * 32 * K + ((((long)(k >> 6) * 4 + ((k & 31) >> 3)) * 64 + ((k >> 5) & 1) * 32 + (m & 31)) << 3) + (k & 7);
 }
+
+// floats per split-key partial (o[HD], m, l): rounded up to whole 128-byte lines, so the partials of different (row, KV head) merge
+// groups never share a cache line -- an early merger on one XCD cannot pull a line into its L2 that a neighbouring group's producer
+// is still writing (the in-kernel merge then does not depend on how sc1 loads treat a line already resident in L2)
+#define ATTN_PS(HD_) ((((HD_) + 2) + 31) / 32 * 32)
+

@@ -24,7 +24,6 @@
 #include "dec_persist.cuh"
 #include "dec_persist_m.cuh"
 #include "bb_block.cuh"
-#include "bb_attn_m.cuh"
 
 #define BB_NSPLIT_MAX 8
 #define PART_ROWS 32
@@ -57,7 +56,7 @@ struct CsmModel {
     Stack bb, dec;
     // workspaces (bf16 unless noted)
     bf16_t *h, *q, *att, *act;          // backbone rows [max_rows][..]
-    float* part;                        // [max(PART_ROWS, max_batch)][H][NSPLIT][hd+4] split-K attention partials
+    float* part;                        // [max(PART_ROWS, max_batch)][H][NSPLIT][ATTN_PS(hd)] split-K attention partials
     int part_rows;
     int* attn_ctr;                      // [part_rows][KV heads] arrival counters of the split-K attention's in-kernel merge (attn.cuh); nullptr: CSM_ATTN_MERGE=0
     bf16_t *dec_in;                     // [B][2][d_bb]   row0 = last_h, row1 = c0 embedding
@@ -97,10 +96,6 @@ struct CsmModel {
     uint4* b_w2t;                       // [layers] W2 re-tiled, 256 * 4 * 2048 pieces each
     uint4* b_w2t8;                      // fp8 mode: [layers] e4m3 W2 re-tiled, 256 * 2 * 2048 pieces each
     bool bb_layer8;                     // fp8 mode: the one-launch layer streams the e4m3 bytes (k_bb_layer<true>)
-    // batched decode steps (2..32 rows): the backbone's attention block as one launch per layer (bb_attn_m.cuh; opt-in: env CSM_BB_ATTN_M=1)
-    bool bb_attn_m;
-    char* bm_xchg;
-    int bm_max_rows;                    // rows up to which it is used (env CSM_BB_ATTN_M_MAX)
     uint32_t* b_state;                  // [0] tag epoch, [1] give-up code
     uint4 *p_w2s, *p_w13p;              // [4 layers] re-tiled W2 / packed W1|W3, constant layer stride
     bf16_t *p_wsm, *p_norms;            // [4][2560][1024] q|k|v|o rows, [4][2][1024] norm scales
@@ -420,22 +415,6 @@ static hipError_t launch_attn_auto(const Stack& S, const AttnArgs& t, bool promp
 // row-major x / act around it.
 static const int g128_gateup_rows = getenv("CSM_G128_GATEUP_ROWS") ? atoi(getenv("CSM_G128_GATEUP_ROWS")) : (1 << 30);
 
-// batched decode step of the backbone (2..32 rows, one per utterance): attention block of layer l as one launch (bb_attn_m.cuh)
-static bool bb_attn_m_usable(const CsmModel* m, const Stack& S, int M, int rows_per_seq, bool prompt) {
-    return m->bb_attn_m && !m->bb_disabled && &S == &m->bb && !prompt && rows_per_seq == 1 && M >= 2 && M <= m->bm_max_rows;
-}
-static hipError_t launch_bb_attn_m(CsmModel* m, Stack& S, int l, bf16_t* h, int M, const int* pos, hipStream_t st, const bf16_t* xn = nullptr, bool xn_packed = false) {
-    const CsmLayerWeights& w = S.lw[l];
-    BbAttnMArgs a;
-    memset(&a, 0, sizeof a);
-    a.wq = (const bf16_t*)w.wq; a.wk = (const bf16_t*)w.wk; a.wv = (const bf16_t*)w.wv; a.wo = (const bf16_t*)w.wo; a.sa_norm = (const bf16_t*)w.sa_norm;
-    a.rope = S.rope; a.h = h; a.xn = xn; a.xn_packed = xn_packed ? 1 : 0; a.kc = S.kc + (long)l * S.layer_stride + S.slot_off; a.vc = S.vc + (long)l * S.layer_stride + S.slot_off;
-    a.pos = pos; a.smax = S.cache_len; a.M = M; a.eps = S.d.norm_eps; a.xchg = m->bm_xchg; a.set = l & 1; a.err = m->b_state + 1; a.poll_sleep = 1;
-    if (M <= 16) hipLaunchKernelGGL(k_bb_attn_m<1>, dim3(DP_NB), dim3(512), BM_LDS_BYTES, st, a);
-    else hipLaunchKernelGGL(k_bb_attn_m<2>, dim3(DP_NB), dim3(512), BM_LDS_BYTES, st, a);
-    return hipGetLastError();
-}
-
 // where the stack's final RMSNorm of each sequence's LAST row goes on the wide path (fused into the last finisher)
 struct FinalNorm { const bf16_t* scale; bf16_t* out; long out_stride; };
 
@@ -526,15 +505,7 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         // layer 0 normalises h directly; later layers got xn from the previous down-projection's finisher.
         // (layer 0 of a depth-decoder step >= 2: q/k/v were gathered from the precomputed table by the sampler)
         int kg = 1;
-        const bool fused_attn = bb_attn_m_usable(m, S, M, rows_per_seq, prompt);
-        if (fused_attn) {
-            // q|k|v -> attention -> o-projection + residual in ONE launch; mlp_norm(h) for gate / up by the row-norm kernel
-            // (its normalised input: layer 0 from the row-norm kernel, later layers from the previous layer's finisher, both in `att`)
-            if (l == 0 && !x_normed && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st, xp0)) != hipSuccess) return e;
-            if ((e = launch_bb_attn_m(m, S, l, h, M, pos, st, att, l > 0 ? xp : xp0)) != hipSuccess) return e;
-            if ((e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st, xp)) != hipSuccess) return e;
-        }
-        if (!fused_attn) {
+        {
         if (!(l == 0 && qkv0_done)) {
             if (l == 0 && !x_normed && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st, xp0)) != hipSuccess) return e;
             memset(&a, 0, sizeof a);
@@ -649,11 +620,6 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
             a.s0 = (const float*)S.w8s[l].wq; a.s1 = (const float*)S.w8s[l].wk; a.s2 = (const float*)S.w8s[l].wv;
         }
         bool block_done = false;
-        if (bb_attn_m_usable(m, S, M, rows_per_seq, false) && pos != nullptr) {
-            // (1)-(3) of a 2-row decode step as ONE launch (bb_attn_m.cuh); the gate / up kernel below normalises h itself
-            if ((e = launch_bb_attn_m(m, S, l, h, M, pos, st)) != hipSuccess) return e;
-            block_done = true;
-        }
         if (&S == &m->bb && M == 1 && m->bb_block && !m->bb_disabled && (!f8 || m->bb_layer8) && pos != nullptr) {
             // (1)-(3) as ONE launch (bb_block.cuh): q|k|v + RoPE + KV append -> attention -> o-projection + residual
             BbBlockArgs b;
@@ -1172,24 +1138,6 @@ static void setup_bb_block(CsmModel* m) {
     if (f8) { m->b_w2t8 = w2t; m->bb_layer8 = true; } else { m->b_w2t = w2t; m->bb_layer = true; }
 }
 
-static void setup_bb_attn_m(CsmModel* m) {
-    const char* ev = getenv("CSM_BB_ATTN_M");
-    const CsmLlamaDims& bc = m->cfg.backbone;
-    // OFF unless asked for (CSM_BB_ATTN_M=1): measured against the four launches it replaces it buys 2.4 % of a frame step at B = 2, 1.6 % at 4,
-    // 1 % at 16 and nothing at 32 (3.59 / 3.81 / 4.16 / 4.80 ms against 3.68 / 3.87 / 4.20 / 4.80) -- the batched chain's q|k|v, attention, merge and
-    // o-projection launches are already within ~4 us per layer of what two exchanges + the same arithmetic cost in one launch.  Kept as the
-    // parity-checked starting point of a whole-layer batched launch.
-    if (!(ev && ev[0] == '1') || m->max_batch < 2 || bc.dim != BM_D || bc.n_heads != 32 || bc.n_kv_heads != 8 || (bc.n_layers & 1)) return;
-    if (!all_cu_launch_fits(k_bb_attn_m<1>, BM_LDS_BYTES, "batched backbone attention block") ||
-        !all_cu_launch_fits(k_bb_attn_m<2>, BM_LDS_BYTES, "batched backbone attention block")) return;
-    OptAllocs A;
-    A.get(&m->bm_xchg, (size_t)BM_XCHG_BYTES, 0xFF);
-    if (!A.ok || hipDeviceSynchronize() != hipSuccess) { A.drop(); m->bm_xchg = nullptr; note_fallback("batched backbone attention block", "allocation failed"); return; }
-    m->bb_attn_m = true;
-    { const char* e2 = getenv("CSM_BB_ATTN_M_MAX"); m->bm_max_rows = e2 ? atoi(e2) : 32; if (m->bm_max_rows > 32) m->bm_max_rows = 32; }
-    m->bb_allocs.insert(m->bb_allocs.end(), A.ptrs.begin(), A.ptrs.end());
-}
-
 extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_batch, int max_rows, int max_frames,
                           csm_handle* out) {
     if (!cfg || !w || !out || max_batch < 1 || max_frames < 1) return fail(nullptr, CSM_E_INVALID, "csm_create: null/invalid argument");
@@ -1242,7 +1190,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     ALLOC(m->att, (size_t)max_rows * m->bb.nq * 2);
     ALLOC(m->act, (size_t)max_rows * cfg->backbone.ffn * 2);
     m->part_rows = max_batch > PART_ROWS ? max_batch : PART_ROWS;
-    ALLOC(m->part, (size_t)m->part_rows * cfg->backbone.n_heads * BB_NSPLIT_MAX * (m->bb.hd + 4) * 4);
+    ALLOC(m->part, (size_t)m->part_rows * cfg->backbone.n_heads * BB_NSPLIT_MAX * ATTN_PS(m->bb.hd) * 4);
     m->attn_ctr = nullptr;
     { const char* ev = getenv("CSM_ATTN_MERGE");
       if (!(ev && ev[0] == '0')) {
@@ -1337,7 +1285,6 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     // ---- all-CU launches (persistent depth decoders, one-launch backbone layers): optional fast paths.  Anything that
     //      fails here (shape, device, occupancy, allocation) leaves the flag off and the launch chain in charge.
     m->persist = false; m->persist_m = false; m->p_stamps = nullptr; m->bb_block = false; m->bb_layer = false; m->persist_disabled = false; m->bb_disabled = false;
-    m->bb_attn_m = false; m->bm_xchg = nullptr;
     // the B = 1 launches' small exchange buffers (granule replicas: 18..96 KB each) come from ONE 2 MB-aligned slab at 4 KB steps instead of
     // wherever hipMalloc's sub-allocator has room -- same placement in every process (A/B: k_bb_layer 32.2..32.8 -> 31.9 us before the
     // scalar-load fix, within the noise after it; kept for the determinism).  CSM_XSLAB=0: separate allocations.
@@ -1353,7 +1300,6 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     }
     setup_persist(m);
     setup_bb_block(m);
-    setup_bb_attn_m(m);
     *out = m;
     return CSM_OK;
 }
@@ -1388,7 +1334,6 @@ extern "C" int csm_reset(csm_handle m, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_persist_recover, dim3(1), dim3(1), 0, st, m->p_state);
     hipLaunchKernelGGL(k_persist_recover, dim3(1), dim3(1), 0, st, m->b_state);
-    if (m->bb_attn_m) HIPCHK(m, hipMemsetAsync(m->bm_xchg, 0xFF, BM_XCHG_BYTES, st));     // (an aborted launch may have left half a layer in an exchange set)
     if (m->attn_ctr) HIPCHK(m, hipMemsetAsync(m->attn_ctr, 0, (size_t)m->part_rows * m->cfg.backbone.n_kv_heads * 4, st));
     HIPCHK(m, hipMemsetAsync(m->n_frames, 0, 8, st));          // frame counter + position-overflow flag
     HIPCHK(m, hipMemsetAsync(m->cur_pos, 0, (size_t)m->max_batch * 4, st));
@@ -1430,7 +1375,7 @@ extern "C" int csm_depth(csm_handle m, int B, float temperature, int topk, const
     HIPCHK(m, run_depth(m, B, m->last_S, temperature, topk, forced, logits_out, noise, st));
     if (out_frame) {
         HIPCHK(m, hipMemcpyAsync(out_frame, m->frame, (size_t)B * m->cfg.n_codebooks * 4, hipMemcpyDeviceToDevice, st));
-        if (m->persist || m->bb_block || m->bb_attn_m) {
+        if (m->persist || m->bb_block) {
             hipLaunchKernelGGL(k_invalidate_on_error, dim3(1), dim3(256), 0, st, out_frame, B * m->cfg.n_codebooks, m->p_state + 1, m->b_state + 1);
             HIPCHK(m, hipGetLastError());
         }
@@ -1445,7 +1390,7 @@ extern "C" int csm_depth(csm_handle m, int B, float temperature, int topk, const
 extern "C" int csm_copy_frame(csm_handle m, int B, int32_t* out_frame, void* stream) {
     if (!m || !out_frame || B < 1 || B > m->max_batch) return fail(m, CSM_E_INVALID, "csm_copy_frame: bad argument");
     HIPCHK(m, hipMemcpyAsync(out_frame, m->frame, (size_t)B * m->cfg.n_codebooks * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    if (m->persist || m->bb_block || m->bb_attn_m) {      // (a frame step's k_advance has already turned an invalid frame into -1; this covers frames that were not committed)
+    if (m->persist || m->bb_block) {      // (a frame step's k_advance has already turned an invalid frame into -1; this covers frames that were not committed)
         hipLaunchKernelGGL(k_invalidate_on_error, dim3(1), dim3(256), 0, (hipStream_t)stream, out_frame, B * m->cfg.n_codebooks, m->p_state + 1, m->b_state + 1);
         HIPCHK(m, hipGetLastError());
     }
@@ -1558,7 +1503,7 @@ __global__ void k_stage_slot(int* frame, const int* frame_save, int ncb, int slo
         cur_tokens[slot * (ncb + 1) + c] = v < 0 ? 0 : v;
         cur_mask[slot * (ncb + 1) + c] = 1;
         if (out_frame) out_frame[c] = v;
-        frame[c] = slot == 0 ? v : frame_save[c];
+        if (slot != 0) { frame[slot * ncb + c] = v; frame[c] = frame_save[c]; }      // the slot's row of the "newest frame" buffer; row 0 back to slot 0
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1696,7 +1641,7 @@ extern "C" int csm_debug_persist_stamps(csm_handle m, uint64_t* host, int n_word
 extern "C" int csm_debug_fast_paths(csm_handle m) {
     if (!m) return 0;
     return (m->persist && !m->persist_disabled ? 1 : 0) | (m->persist_m && !m->persist_disabled ? 2 : 0) | (m->bb_block && !m->bb_disabled ? 4 : 0) |
-           (m->bb_layer && !m->bb_disabled ? 8 : 0) | (m->bb_layer8 && !m->bb_disabled ? 16 : 0) | (m->bb_attn_m && !m->bb_disabled ? 32 : 0);
+           (m->bb_layer && !m->bb_disabled ? 8 : 0) | (m->bb_layer8 && !m->bb_disabled ? 16 : 0);
 }
 
 // Times the two dominant launches of a decode step on the handle's CURRENT state, each `reps` times back to back between HIP events on

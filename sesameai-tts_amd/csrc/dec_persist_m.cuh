@@ -16,7 +16,7 @@
 // Exchange: activations cross workgroups through global buffers written with sc1 (write-through) stores and read with
 // sc1 loads.  No flags and no tags: every buffer is filled with 0xFF by a memset node in front of the launch, a payload
 // dword 0xFFFFFFFF cannot occur (a bf16 pair of two all-ones NaNs / an fp32 NaN with every mantissa bit / a negative
-// token), so a consumer re-reads its 16-byte pieces until no dword is 0xFFFFFFFF -- the data is its own flag, at 1x the
+// token -- producers clear the lowest bit of such a NaN, dm_clean), so a consumer re-reads its 16-byte pieces until no dword is 0xFFFFFFFF -- the data is its own flag, at 1x the
 // payload bytes (8-byte {tag, value} granules would move 128 KB per workgroup per all-gather at 32 rows).  Buffers rotate
 // three deep per edge; a producer re-poisons, with the store that publishes instance n, its slots of the buffer instance
 // n + 2 will use (read last for instance n - 1, a whole layer ago).
@@ -114,6 +114,10 @@ struct DecPersistMArgs {
 };
 #define DM_STAMP(i_) do { if (DP_STAMPS(a) != nullptr && cu == 100 && lane == 0) DP_STAMPS(a)[s * 128 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
+// A payload dword must never BE the poison: an all-ones bf16 NaN pair / fp32 NaN (non-finite weights or an overflow upstream) is published
+// with its lowest bit cleared -- still a NaN in both halves, so non-finite activations reach the logits like in the reference instead of
+// turning into a consumer that spins until its 50 ms bound.  Two VALU instructions per published dword.
+__device__ __forceinline__ uint32_t dm_clean(uint32_t v) { return v == 0xffffffffu ? 0xfffffffeu : v; }
 __device__ __forceinline__ bool dm_valid(const u32x4_t& v) { return v.x != 0xffffffffu && v.y != 0xffffffffu && v.z != 0xffffffffu && v.w != 0xffffffffu; }
 // saddr + 32-bit voffset forms: the buffer base is wave-uniform (an SGPR pair), a lane carries ONE 32-bit offset per access
 // pattern and the piece index rides in the instruction's immediate -- full 64-bit per-lane addresses for every buffer of
@@ -431,11 +435,11 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                             if (g4 < 2 && b < a.M) {
                                 const int u0 = 2 * g4;
                                 const uint32_t o0 = dp_rope_pair(v[0], v[1], rp[u0], 2 * (3 * cu + u0) < 1280);
-                                dm_sst4(xq, (uint32_t)(b * 3072 + (6 * cu + 2 * u0) * 2), o0);
+                                dm_sst4(xq, (uint32_t)(b * 3072 + (6 * cu + 2 * u0) * 2), dm_clean(o0));
                                 dm_sst4(xq2, (uint32_t)(b * 3072 + (6 * cu + 2 * u0) * 2), 0xffffffffu);
                                 if (g4 == 0) {
                                     const uint32_t o1 = dp_rope_pair(v[2], v[3], rp[1], 2 * (3 * cu + 1) < 1280);
-                                    dm_sst4(xq, (uint32_t)(b * 3072 + (6 * cu + 2) * 2), o1);
+                                    dm_sst4(xq, (uint32_t)(b * 3072 + (6 * cu + 2) * 2), dm_clean(o1));
                                     dm_sst4(xq2, (uint32_t)(b * 3072 + (6 * cu + 2) * 2), 0xffffffffu);
                                 }
                             }
@@ -463,7 +467,7 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                             const uint32_t p0 = dp_resid_pair(v[0], v[1], hr[0]), p1 = dp_resid_pair(v[2], v[3], hr[1]);
                             dp_lu32* h1 = (dp_lu32*)(lds + DM_L_HRES1) + 2 * b;
                             h1[0] = p0; h1[1] = p1;
-                            dm_sst8(xh, (uint32_t)(cu * 256 + b * 8), p0, p1);
+                            dm_sst8(xh, (uint32_t)(cu * 256 + b * 8), dm_clean(p0), dm_clean(p1));
                             dm_sst8(xh2, (uint32_t)(cu * 256 + b * 8), 0xffffffffu, 0xffffffffu);
                         }
                     }
@@ -484,7 +488,7 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                     if (b < a.M) {
                         const uint32_t hv = dp_swiglu(acc[0], acc[1]) | (dp_swiglu(acc[2], acc[3]) << 16);
                         const uint32_t off = (uint32_t)(gg * 32768 + (gj * 4 + w) * 512 + b * 16 + g4 * 4);      // [g][piece 4 j + w][32 rows][8 columns]: a wave's 16 rows are 256 contiguous bytes
-                        dm_sst4(xg, off, hv);
+                        dm_sst4(xg, off, dm_clean(hv));
                         dm_sst4(xg2, off, 0xffffffffu);
                     }
                 }
@@ -509,7 +513,7 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                     const int b = 16 * hf + bl;
                     if (b < a.M) {
                         const uint32_t off = (uint32_t)((((((gj * 16 + gg) * 4 + w) * 32 + b) * 16) + 4 * g4) * 4);      // [j][g][wave][32 rows][16 columns] f32: a wave's 16 rows are 1 KB contiguous
-                        u32x4_t o; o.x = __float_as_uint(acc[0]); o.y = __float_as_uint(acc[1]); o.z = __float_as_uint(acc[2]); o.w = __float_as_uint(acc[3]);
+                        u32x4_t o; o.x = dm_clean(__float_as_uint(acc[0])); o.y = dm_clean(__float_as_uint(acc[1])); o.z = dm_clean(__float_as_uint(acc[2])); o.w = dm_clean(__float_as_uint(acc[3]));
                         u32x4_t ff; ff.x = ff.y = ff.z = ff.w = 0xffffffffu;
                         dm_sst16(xp, off, o);
                         dm_sst16(xp2, off, ff);
@@ -534,7 +538,7 @@ __device__ __forceinline__ void dm_compute_wave(const DecPersistMArgs& a, char* 
                     const int b = 16 * hf + bl;
                     if (b < a.M && (g4 < 2 || cu == 0)) {
                         const uint32_t off = (uint32_t)((g4 < 2 ? cu : 256) * 512 + b * 16 + (g4 & 1) * 8);
-                        dm_sst8(xl, off, pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+                        dm_sst8(xl, off, dm_clean(pack_bf(v[0], v[1])), dm_clean(pack_bf(v[2], v[3])));
                         dm_sst8(xl2, off, 0xffffffffu, 0xffffffffu);
                     }
                 }
@@ -602,7 +606,7 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
             if (ohf >= 0 && gw == 0) {
                 const uint32_t o = dm_attention(lds, l, cb + 1, lane);
                 const long off = (long)ob * 2048 + oh * 256 + lane * 4;
-                dm_st4(a.xchg + DM_OFF_A + (n % DM_R) * DM_X_BYTES + off, o);
+                dm_st4(a.xchg + DM_OFF_A + (n % DM_R) * DM_X_BYTES + off, dm_clean(o));
                 dm_st4(a.xchg + DM_OFF_A + ((n + 2) % DM_R) * DM_X_BYTES + off, 0xffffffffu);
                 DM_STAMP(l * 8 + 2);
             }
@@ -656,7 +660,7 @@ __device__ __forceinline__ void dm_gather_wave(const DecPersistMArgs& a, char* l
                         const uint32_t p0 = dp_resid_pair(t[0], t[1], h1[0]), p1 = dp_resid_pair(t[2], t[3], h1[1]);
                         dp_lu32* hr = (dp_lu32*)(lds + DM_L_HRES) + 2 * b;
                         hr[0] = p0; hr[1] = p1;
-                        dm_st8(a.xchg + DM_OFF_X + (n % DM_R) * DM_X_BYTES + cu * 256 + b * 8, p0, p1);
+                        dm_st8(a.xchg + DM_OFF_X + (n % DM_R) * DM_X_BYTES + cu * 256 + b * 8, dm_clean(p0), dm_clean(p1));
                         dm_st8(a.xchg + DM_OFF_X + ((n + 2) % DM_R) * DM_X_BYTES + cu * 256 + b * 8, 0xffffffffu, 0xffffffffu);
                     }
                 }

@@ -213,7 +213,7 @@ __device__ __forceinline__ void stage_attn(bf16_t* xs, float* ps /*[4 waves][2][
 template <int MT, int KITERS>
 __device__ __forceinline__ void stage_combine(bf16_t* xs, const GemvArgs& a, int m0) {
     constexpr int K = KITERS * 512;
-    constexpr int HD = 64, PS = HD + 4;
+    constexpr int HD = 64, PS = ATTN_PS(HD);
     const int tid = threadIdx.x;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {

@@ -344,6 +344,12 @@ class MimiCodec:
             w.codebook_sqnorm = self._dev(books.pow(2).sum(-1))                           # [K][2048]
         return cfg, w
 
+    def decode_weight_bytes(self) -> int:
+        """fp32 bytes one decode call reads whatever its length: every decode-side tensor except the codebooks, of which a call
+        touches only the rows it looks up (32 x 1 KB per frame: activations, not weights).  bench.py's `mimi.roofline`."""
+        import math as _m
+        return sum(4 * _m.prod(shp) for name, shp, _ in state_dict_layout(self.args) if not name.startswith("rvq."))
+
     # -- reference surface ----------------------------------------------------------------------------
     def set_num_codebooks(self, n: int) -> None:
         if n != self.args.num_codebooks:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """CLI with the reference's surface (reference: tts_service.py): class ``TTS`` with
 ``load_model / list_voices / load_voice / generate_with_context / generate_audio_segment /
-export_wav`` and the flags ``-d/--device  -v/--voice  text  --output  --temp  --topk``.
+export_wav / say`` and the flags ``-d/--device  -v/--voice  text  --output  --temp  --topk`` (no text: interactive mode).
 
 Only the hot path is re-implemented: generation runs on the MI355X kernels through
 ``sesameai.generator``.  Host-side audio post-processing that the reference does with pydub
@@ -158,6 +158,50 @@ class TTS:
             pcm[-n:] = (pcm[-n:] * ramp[::-1]).astype(np.int16)
         return pcm
 
+    def say(self, text: str, output_filename: Optional[str] = "combined_output.wav", fallback_duration: int = 1000,
+            fade_duration: int = 50, start_silence_duration: int = 500, end_silence_duration: int = 100,
+            temperature: float = 0.8, topk: int = 40, on_segment=None) -> None:
+        """reference: tts_service.py:313-470 -- the generation half: the text is split into sentences, each sentence is
+        generated against the cached voice context (the shared prompt prefix is prefilled once: Model.prefill_prompt) and
+        reported with the reference's line ``> sentence ... [Audio: 1.84s in 0.09s, RTF: 20.44x]``; a sentence that fails is
+        replaced by ``fallback_duration`` ms of faded silence; the segments are written to ``output_filename`` if given.
+        Playback (the reference's pydub/ffplay player thread) is out of scope: ``on_segment(pcm_int16, sample_rate)``, if
+        given, receives every segment the moment it exists -- that is where a player thread's queue would be fed."""
+        import textwrap
+        sentences = [s for s in re.split(r"(?<=[.!?])\s+", textwrap.dedent(text).strip()) if s.strip()]
+        if not sentences:
+            print("No valid text to process")
+            return
+        sr = self.generator.sample_rate
+        segments: List[np.ndarray] = []
+        for sentence in sentences:
+            print(f"> {sentence} ... ", end="", flush=True)
+            t0 = time.time()
+            try:
+                seg = self.generate_audio_segment(sentence, fade_duration=fade_duration, start_silence_duration=start_silence_duration,
+                                                  end_silence_duration=end_silence_duration, temperature=temperature, topk=topk)
+                took, secs = time.time() - t0, len(seg) / sr
+                print(f"[Audio: {secs:.2f}s in {took:.2f}s, RTF: {secs / max(took, 1e-9):.2f}x]")
+            except KeyboardInterrupt:
+                print("\nExiting due to KeyboardInterrupt")
+                break
+            except Exception as e:  # noqa: BLE001 -- the reference keeps going with silence
+                print(f"Error generating audio for sentence: {sentence}: {e}")
+                seg = np.zeros(sr * fallback_duration // 1000, np.int16)
+            segments.append(seg)
+            if on_segment is not None:
+                on_segment(seg, sr)
+        if not output_filename:
+            return
+        if not segments:
+            print("No audio segments generated to export")
+            return
+        combined = np.concatenate(segments)
+        with wave.open(output_filename, "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(sr)
+            f.writeframes(combined.tobytes())
+        print(f"Export complete: {len(combined) / sr:.2f} seconds of audio")
+
     def export_wav(self, text: str, output_filename: str, fallback_duration: int = 1000, max_retries: int = 2,
                    temperature: float = 0.8, topk: int = 40) -> None:
         """reference: tts_service.py:472-525."""
@@ -205,9 +249,25 @@ def main():
     tts.load_model()
     if args.voice:
         tts.load_voice(args.voice)
-    if not args.text:
-        parser.error("interactive playback mode is out of scope; pass the text to synthesize")
-    tts.export_wav(args.text, args.output, temperature=args.temp, topk=args.topk)
+    if args.text:
+        tts.export_wav(args.text, args.output, temperature=args.temp, topk=args.topk)
+        return
+    # reference: tts_service.py:560-572 -- no text: interactive mode.  The reference plays every line; playback is out of
+    # scope here, so each line is written to <output stem>_<n>.wav instead.
+    print(f"Interactive mode (temp={args.temp}, topk={args.topk})")
+    stem, ext = os.path.splitext(args.output)
+    n = 0
+    while True:
+        try:
+            line = input("> ")
+        except (EOFError, KeyboardInterrupt):
+            break
+        if line.lower() in ("exit", "quit"):
+            break
+        if line.strip():
+            n += 1
+            tts.say(line, output_filename=f"{stem}_{n}{ext or '.wav'}", temperature=args.temp, topk=args.topk)
+    print("\nExiting interactive mode.")
 
 
 if __name__ == "__main__":

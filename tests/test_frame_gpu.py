@@ -8,8 +8,9 @@ Tolerances (bf16 path, as north_star asks "bit-exact for codebook indices under 
     batched path (measured 1.03x), <= 1.25x on the tiny shapes, whose gap (0.018) is below one bf16 ulp of their logits (0.031 at
     |logit| >= 4; measured 1.07-1.13x = one ulp);
   * greedy indices, teacher-forced on the oracle trajectory: bit-exact wherever the oracle's own top-1/top-2 margin exceeds
-    2x that noise floor (each of the two logits may move by 1x); the near-ties so excused are printed and their FRACTION is
-    bounded (<= 8 % of the compared rows; measured 3-5 % with random weights, whose logits are nearly uniform).
+    0.5x that noise floor on the CSM-1B shapes (round 4; 2x before, measured <= 0.42x) and 2x on the tiny shapes; the near-ties so
+    excused are printed with their largest margin and their FRACTION is bounded (<= 8 % of the compared rows; measured 3-5 % with
+    random weights, whose logits are nearly uniform).
 """
 import os
 
@@ -19,6 +20,30 @@ import torch
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+# CSM-1B shapes: a greedy pick may differ from the oracle's only where the ORACLE's own top-1 / top-2 margin is at most NEAR_TIE x its
+# bf16-vs-fp32 gap (0.112 on these shapes: 0.056; round 3 allowed 2 x although every excused row measured <= 0.047 -- VERDICT r3).
+# The tiny shapes keep 2 x: their gap (0.018) is smaller than one bf16 ulp of their logits (0.031), so a 1-ulp move exceeds it.
+NEAR_TIE = 0.5
+BATCH32_TIE = 0.75       # near-tie bound of the 32-row batched path: 1,024 free-running decisions per step and logits at 1.03x the gap -- the largest
+                         # oracle margin at which a pick has been seen to differ is 0.078 = 0.69 x gap (config 3, graph step); 2 x max|dlogit| would allow 2.06 x
+BATCH32_GAP = 1.1        # logits of the 32-row batched paths: allowed multiple of the oracle's bf16-vs-fp32 gap (measured 1.03x; see the bisect in DESIGN.md)
+_EXCUSED = []                                    # (what, margin, gap) of every excused row of the current test
+
+
+def _excuse(margin, noise, what, tie=NEAR_TIE):
+    _EXCUSED.append((what, float(margin), float(noise)))
+    assert margin <= tie * noise, f"{what}: oracle margin {float(margin):.4f} > {tie} x gap {float(noise):.4f} -- not a near-tie"
+
+
+@pytest.fixture(autouse=True)
+def _report_excused_margins(request):
+    _EXCUSED.clear()
+    yield
+    if _EXCUSED:
+        worst = max(_EXCUSED, key=lambda e: e[1] / e[2])
+        print(f"\n[parity] {request.node.name}: {len(_EXCUSED)} rows excused as near-ties, largest oracle margin {worst[1]:.4f} = "
+              f"{worst[1] / worst[2]:.2f} x gap ({worst[0]})")
 
 
 @pytest.fixture(scope="module")
@@ -61,7 +86,7 @@ def test_tiny_teacher_forced_vs_golden(tiny):
     print(f"tiny teacher-forced: max|dlogit|={max_diff:.4f} (oracle bf16-vs-fp32 gap {noise:.4f}); mismatches {mism}")
     assert max_diff <= 1.25 * noise
     for f, cb, margin in mism:
-        assert margin <= 2 * noise, f"greedy index differs at frame {f} codebook {cb} with margin {margin}"
+        _excuse(margin, noise, f"greedy index differs at frame {f} codebook {cb}", tie=2.0)
 
 
 def test_tiny_batch_rows_independent(tiny):
@@ -177,7 +202,7 @@ def test_tiny_graph_replay_equals_eager_and_oracle_free_run(tiny):
             cur_m = torch.cat([torch.ones_like(sframe).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
             pos = pos[:, -1:] + 1
         top2 = torch.topk(torch.stack(tr.logits, 0)[:, 0].float(), 2, dim=-1)[0]
-        _same_until_a_near_tie(traces[0][f], ref[f], top2[:, 0] - top2[:, 1], noise, f"free run, frame {f}")
+        _same_until_a_near_tie(traces[0][f], ref[f], top2[:, 0] - top2[:, 1], noise, f"free run, frame {f}", tie=2.0)
 
 
 def test_generate_frame_surface_matches_reference_loop(tiny):
@@ -205,6 +230,86 @@ def test_generate_frame_surface_matches_reference_loop(tiny):
         m.step(1, 1.0, 1)
     fr, _ = m.read_frames(1)
     assert torch.equal(got, fr[:, 0])
+
+
+def test_generate_frame_one_call_entry_equals_the_three_call_path_for_every_input_form(tiny):
+    """csm_generate_frame_s1 (include/csm_hip.h): the reference's own tensors -- int64 tokens / positions, bool mask, on the GPU --
+    are read by the staging kernel as they are.  Same frames as (a) csm_set_step_inputs + csm_frame_step + csm_copy_frame with
+    converted int32 / uint8 inputs and (b) generate_frame fed host tensors of other dtypes (the binding converts), at B = 1 and 3."""
+    import ctypes as C
+    from sesameai import _abi
+    shape, w, m = tiny
+    for B in (1, 3):
+        prs = [_tiny_prompt(10, 300 + b) for b in range(B)]
+        tok, msk = torch.stack([p[0] for p in prs]).cuda(), torch.stack([p[1] for p in prs]).cuda()
+        S = tok.shape[1]
+
+        def run(form):
+            m.reset_caches()
+            f = m.generate_frame(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1).cuda(), 1.0, 1)
+            out = [f.cpu()]
+            pos = torch.full((B, 1), S, dtype=torch.long)
+            for _ in range(4):
+                t = torch.cat([f.long(), torch.zeros(B, 1, dtype=torch.long, device=f.device)], dim=1).unsqueeze(1)
+                k = torch.cat([torch.ones_like(f).bool(), torch.zeros(B, 1, dtype=torch.bool, device=f.device)], dim=1).unsqueeze(1)
+                if form == "reference":                                     # int64 / bool / int64 on the device: no conversion
+                    f = m.generate_frame(t, k, pos.cuda(), 1.0, 1)
+                elif form == "host":                                        # int32 / uint8 host tensors: the binding converts
+                    f = m.generate_frame(t.cpu().int(), k.cpu().to(torch.uint8), pos.int(), 1.0, 1)
+                else:                                                       # the three-call path of rounds 1-3
+                    ti, ki, pi = t.int().contiguous(), k.to(torch.uint8).contiguous(), pos.int().cuda().contiguous()
+                    _abi.check(_abi.lib.csm_set_step_inputs(m._h, ti.data_ptr(), ki.data_ptr(), pi.data_ptr(), B, torch.cuda.current_stream().cuda_stream), m._h)
+                    m.step(B, 1.0, 1)
+                    f = m.last_frame(B)
+                assert f.shape == (B, 32) and f.dtype == torch.int32 and f.is_cuda
+                out.append(f.cpu()); pos = pos + 1
+            return torch.stack(out)
+
+        ref, host, three = run("reference"), run("host"), run("three")
+        assert torch.equal(ref, three) and torch.equal(ref, host), f"B = {B}"
+        fr, _ = m.read_frames(B)
+        assert torch.equal(fr, three), "history"
+    # a position outside [0, max_seq) that only exists on the device is reported at the next read_frames, as in the three-call path
+    m.reset_caches()
+    f = m.generate_frame(tok[:1], msk[:1], torch.arange(S).unsqueeze(0).cuda(), 1.0, 1)
+    t = torch.cat([f.long(), torch.zeros(1, 1, dtype=torch.long, device=f.device)], dim=1).unsqueeze(1)
+    k = torch.cat([torch.ones_like(f).bool(), torch.zeros(1, 1, dtype=torch.bool, device=f.device)], dim=1).unsqueeze(1)
+    m.generate_frame(t, k, torch.tensor([[256]]).cuda(), 1.0, 1)
+    with pytest.raises(RuntimeError, match="CSM_E_TOO_LONG"):
+        m.read_frames(1)
+    with pytest.raises(ValueError, match="input_pos outside"):
+        m.generate_frame(t, k, torch.tensor([[256]]), 1.0, 1)               # host positions are checked before anything is launched
+    m.reset_caches()
+
+
+def test_frame_history_is_a_ring_and_overwritten_frames_are_refused():
+    """the history was linear and a long continuous run ended in CSM_E_TOO_LONG.  With max_frames = 8 a run of 29 frames
+    read in blocks of 4 returns exactly the frames of a run with a large history; a range that has been overwritten is refused."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sesameai.models import Model, csm_tiny_args, synthetic_state_dict
+    sd = synthetic_state_dict(csm_tiny_args(), seed=1234)
+    tok, msk = _tiny_prompt(10, 77)
+    runs = []
+    for max_frames in (8, 64):
+        m = Model(csm_tiny_args(), sd, max_frames=max_frames, max_prefill_rows=64)
+        m.setup_caches(2)
+        m.reset_caches()
+        m.prefill(torch.stack([tok, tok]), torch.stack([msk, msk]), torch.arange(10).unsqueeze(0).repeat(2, 1))
+        m.depth(2, 1.0, 1, commit=True)
+        got, first = [m.read_frames(2, 0, 1)[0]], 1
+        for _ in range(7):
+            for _ in range(4):
+                m.step(2, 1.0, 1)
+            got.append(m.read_frames(2, first, 4)[0]); first += 4
+        runs.append(torch.cat(got))
+        if max_frames == 8:
+            assert m.num_frames() == 29
+            assert torch.equal(m.read_frames(2, 21, 8)[0], runs[0][21:29])          # the whole ring, across the wrap
+            with pytest.raises(RuntimeError, match="overwritten"):
+                m.read_frames(2, 20, 4)
+        del m
+    assert runs[0].shape == (29, 2, 32) and torch.equal(runs[0], runs[1])
 
 
 def test_prefix_kv_reuse_is_bit_identical(tiny):
@@ -282,7 +387,7 @@ def test_fp8_weight_stream_matches_oracle_on_dequantised_weights():
         worst = max(worst, (logits[:, 0].float().cpu() - want).abs().max().item())
         margin = torch.topk(want, 2, dim=-1)[0]
         for cb in (out[0].cpu() != ref[0]).nonzero().flatten().tolist():
-            assert float(margin[cb, 0] - margin[cb, 1]) <= 2 * noise
+            _excuse(float(margin[cb, 0] - margin[cb, 1]), noise, f"CSM-1B config-1 frame {f} codebook {cb}")
         cur_t = torch.cat([ref.long(), torch.zeros(1, 1).long()], dim=1).unsqueeze(1)
         cur_m = torch.cat([torch.ones_like(ref).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
         pos = pos[:, -1:] + 1
@@ -374,7 +479,7 @@ def test_csm1b_teacher_forced_vs_golden(csm1b):
     assert max_diff <= noise
     assert len(mism) <= 0.08 * n_rows, "too many greedy rows differ from the oracle, near-ties or not" 
     for f, cb, margin in mism:
-        assert margin <= 2 * noise, f"greedy index differs at frame {f} codebook {cb} with margin {margin}"
+        _excuse(margin, noise, f"greedy index differs at frame {f} codebook {cb}")
 
 
 def test_csm1b_batched_wide_path_vs_golden(csm1b):
@@ -398,7 +503,7 @@ def test_csm1b_batched_wide_path_vs_golden(csm1b):
         lg = logits[:, 0].float().cpu()
         max_diff = max(max_diff, (torch.gather(lg, 1, gold["top_i"][f].long()) - gold["top_v"][f].float()).abs().max().item())
         for cb in (out[0].cpu() != gold["codes"][f]).nonzero().flatten().tolist():
-            assert float(gold["margin"][f, cb]) <= 2 * noise, f"greedy index differs at frame {f} codebook {cb}"
+            _excuse(float(gold["margin"][f, cb]), noise, f"greedy index differs at frame {f} codebook {cb}")
         row = torch.zeros(B, 1, 33, dtype=torch.long); row[:, 0, :32] = gold["codes"][f].long()
         rmask = torch.ones(B, 1, 33, dtype=torch.bool); rmask[:, 0, 32] = False
         m.prefill(row, rmask, torch.full((B, 1), S + f))
@@ -740,6 +845,41 @@ def test_slot_refill_leaves_the_other_slots_bit_identical(tiny):
     m.reset_caches()
 
 
+def test_slot_refills_draw_from_their_own_noise_streams(tiny):
+    """under stochastic sampling every slot refilled between the same two frame steps drew frame 0 from the SAME
+    Philox stream (step counter not advanced, sequence index 0), so N copies of one prompt started with identical frames, and slot 0's
+    frame 0 shared its draws with slot 0's next frame.  Refills now draw from a second key domain with a per-refill counter
+    (csm_seed, include/csm_hip.h).  Same prompt into three slots at T = 0.9 / top-k 50: three different frame 0s, still a pure
+    function of the seed; the frame steps that follow are untouched by HOW MANY refills happened before them (their own counter)."""
+    shape, w, m = tiny
+    t, mk = _tiny_prompt(12, 123)
+    T, K = 0.9, 50
+
+    def fill(seed, n_extra=0):
+        m.reset_caches(); m.seed(seed)
+        f0 = [m.refill_slot(b, t, mk, T, K).cpu() for b in range(3)]
+        for _ in range(n_extra):                                             # refill slot 2 again and again: only ITS frame 0 changes
+            f0[2] = m.refill_slot(2, t, mk, T, K).cpu()
+        assert torch.equal(m.last_frame(3).cpu(), torch.stack(f0)), "csm_copy_frame must keep returning every slot's own newest frame"
+        for _ in range(3):
+            m.step(3, T, K)
+        fr, _ = m.read_frames(3)
+        return torch.stack(f0), fr
+
+    f0, fr = fill(5)
+    assert not torch.equal(f0[0], f0[1]) and not torch.equal(f0[1], f0[2]) and not torch.equal(f0[0], f0[2]), "identical frame 0 in different slots"
+    assert int((f0[0] == f0[1]).sum()) < 16, "the slots' draws are correlated"
+    assert not torch.equal(fr[0, 0], fr[1, 0]), "slot 0: frame 0 and frame 1 drawn alike"
+    f0b, frb = fill(5)
+    assert torch.equal(f0, f0b) and torch.equal(fr, frb), "sampling is a pure function of the seed"
+    f0c, frc = fill(6)
+    assert not torch.equal(f0, f0c)
+    f0d, frd = fill(5, n_extra=2)
+    assert torch.equal(f0d[:2], f0[:2]) and not torch.equal(f0d[2], f0[2])
+    assert torch.equal(frd[1:, :2], fr[1:, :2]), "frame steps of the undisturbed slots depend on the number of refills before them"
+    m.reset_caches()
+
+
 def test_continuous_batching_through_the_generator_matches_one_utterance_at_a_time(tiny):
     """Generator.generate_codes_continuous on the device: 5 prompts of different lengths through 2 slots, 6 frames each (greedy;
     random weights never emit the EOS frame, so utterances retire at the length limit) -- every utterance must equal the one the
@@ -794,7 +934,7 @@ def _bench_args():
     return SimpleNamespace(ctx_text=40, ctx_frames=125, gen_text=24)
 
 
-def _same_until_a_near_tie(got, want, margin, noise, what):
+def _same_until_a_near_tie(got, want, margin, noise, what, tie=NEAR_TIE):
     """A free-running greedy frame (each codebook conditioned on the codes picked before it): identical to the oracle's
     up to the first difference, and that difference must sit where the ORACLE's top-1/top-2 margin is inside the
     rounding-noise floor.  Returns the number of decisions that were compared (= matched)."""
@@ -803,7 +943,7 @@ def _same_until_a_near_tie(got, want, margin, noise, what):
     if diff.numel() == 0:
         return int(got.numel())
     first = int(diff[0])
-    assert float(margin[first]) <= 2 * noise, f"{what}: codebook {first} differs with oracle margin {float(margin[first]):.4f} > {2 * noise:.4f}"
+    _excuse(float(margin[first]), noise, f"{what}: codebook {first} differs", tie=tie)
     return first
 
 
@@ -826,7 +966,7 @@ def _teacher_forced(m, gold, S, n_frames, noise, what):
     assert max_diff <= noise, what
     assert len(mism) <= max(0.08 * 32 * n_frames, 3), f"{what}: too many greedy rows differ from the oracle, near-ties or not" 
     for f, cb, margin in mism:
-        assert margin <= 2 * noise, f"{what}: greedy index differs at frame {f} codebook {cb} with margin {margin}"
+        _excuse(margin, noise, f"{what}: greedy index differs at frame {f} codebook {cb}")
 
 
 def test_csm1b_config2_prompt_vs_golden(csm1b):
@@ -888,14 +1028,14 @@ def test_csm1b_config3_batch32_vs_golden(csm1b):
     d0 = (torch.gather(lg, 2, gold["top_i"][0].long()) - gold["top_v"][0].float()).abs().max().item()
     bad = (out.cpu() != codes0).nonzero()
     for b, cb in bad.tolist():
-        assert float(gold["margin"][0][cb, b]) <= 2 * noise, f"frame 0 utterance {b} codebook {cb}"
+        _excuse(float(gold["margin"][0][cb, b]), noise, f"frame 0 utterance {b} codebook {cb}", tie=BATCH32_TIE)
     # frame 1: graph replay on the golden inputs (decode-step kernels at M = 32 rows, operand-order activations)
     row = torch.zeros(B, 1, 33, dtype=torch.long); row[:, 0, :32] = codes0.long()
     rmask = torch.ones(B, 1, 33, dtype=torch.bool); rmask[:, 0, 32] = False
     got = m.generate_frame(row, rmask, torch.full((B, 1), S), 1.0, 1).cpu()
     n_cmp = 0
     for b in range(B):
-        n_cmp += _same_until_a_near_tie(got[b], gold["codes"][1][b], gold["margin"][1][:, b], noise, f"graph step, utterance {b}")
+        n_cmp += _same_until_a_near_tie(got[b], gold["codes"][1][b], gold["margin"][1][:, b], noise, f"graph step, utterance {b}", tie=BATCH32_TIE)
     # and its logits, teacher-forced, through the same decode-step kernels
     m2 = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S)
     m2.setup_caches(B)
@@ -905,7 +1045,7 @@ def test_csm1b_config3_batch32_vs_golden(csm1b):
     d1 = (torch.gather(logits1.float().cpu(), 2, gold["top_i"][1].long()) - gold["top_v"][1].float()).abs().max().item()
     print(f"config 3 (B=32): max|dlogit| frame 0 {d0:.4f}, frame 1 {d1:.4f} (gap {noise:.4f}); {len(bad)} of {B * 32} greedy rows excused as near-ties "
           f"({100.0 * len(bad) / (B * 32):.1f} %); {n_cmp} of {B * 32} graph-step decisions compared")
-    assert max(d0, d1) <= 1.1 * noise            # (32-row batched path: measured 1.03x; B = 1 and B = 4 are held to 1x)
+    assert max(d0, d1) <= BATCH32_GAP * noise    # (32-row batched path: measured 1.03x; B = 1 and B = 4 are held to 1x)
     assert len(bad) <= 0.08 * B * 32
     assert n_cmp >= B * 8
 
@@ -972,7 +1112,7 @@ def test_csm1b_config5_batched_fp8_long_context_vs_golden(csm1b):
     d0 = (torch.gather(logits.float().cpu(), 2, gold["top_i"][0].long()) - gold["top_v"][0].float()).abs().max().item()
     bad = (out.cpu() != codes0).nonzero()
     for b, cb in bad.tolist():
-        assert float(gold["margin"][0][cb, b]) <= 2 * noise, f"frame 0 utterance {b} codebook {cb}"
+        _excuse(float(gold["margin"][0][cb, b]), noise, f"frame 0 utterance {b} codebook {cb}")
     row = torch.zeros(B, 1, 33, dtype=torch.long); row[:, 0, :32] = codes0.long()
     rmask = torch.ones(B, 1, 33, dtype=torch.bool); rmask[:, 0, 32] = False
     got = m.generate_frame(row, rmask, torch.full((B, 1), S), 1.0, 1).cpu()
@@ -987,6 +1127,145 @@ def test_csm1b_config5_batched_fp8_long_context_vs_golden(csm1b):
           f"{n_cmp} of {B * 32} graph-step decisions compared")
     assert max(d0, d1) <= noise
     assert len(bad) <= 0.08 * B * 32 + 1 and n_cmp >= B * 4
+
+
+def test_csm1b_config5_batch32_fp8_long_context_vs_golden(csm1b):
+    """BASELINE config 5 at the batch SURVEY.md 8d names for it: B = 32 x the 1334-row prompt (bench.py's `config5_b32` leg, seeds
+    6000..6031), fp8-e4m3 weight stream, against the BATCHED oracle on the dequantised weights (tests/golden/csm1b_cfg5c.pt: top-8
+    logits, codes and margins of 2 teacher-forced frames; the prompts are rebuilt from the seeds and checked by checksum).  Covers
+    the LDS-tiled prefill at 42,688 rows, the 32-row e4m3 matrix-core decode step with split-key attention over 1,335 keys per row
+    and the batched persistent decoder (k_dec_persist_m<2>)."""
+    import bench
+    from types import SimpleNamespace
+    from oracle import csm_ref as C
+    from sesameai.models import Model, csm_1b_args
+    _, sd = csm1b
+    path = os.path.join(GOLD, "csm1b_cfg5c.pt")
+    if not os.path.exists(path):
+        pytest.skip("csm1b_cfg5c golden not generated (oracle/make_golden.py --only cfg5c)")
+    gold = torch.load(path)
+    g5 = torch.load(os.path.join(GOLD, "csm1b_cfg5.pt"))
+    noise = float(g5["s1334"]["bf16_vs_fp32_gap"].max())
+    B, S = 32, 1334
+    tok, msk = bench.synthetic_prompt(SimpleNamespace(ctx_text=30, ctx_frames=100, gen_text=24), B, C.csm_1b().text_vocab_size, seed0=int(gold["prompt_seed"]),
+                                      segments=10, ctx_text=30, ctx_frames=100)
+    assert tok.shape == (B, S, 33) and torch.equal(tok.sum(dim=(1, 2)), gold["prompt_checksum"]), "these are not the golden's prompts"
+    m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S, weights_dtype="fp8")
+    m.setup_caches(B)
+    assert m.fast_paths() & 2, "the batched persistent decoder must be on this path"
+    m.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+    codes0 = gold["codes"][0]
+    out, logits = m.depth(B, 1.0, 1, forced=codes0, want_logits=True, commit=True)
+    d0 = (torch.gather(logits.float().cpu(), 2, gold["top_i"][0].long()) - gold["top_v"][0].float()).abs().max().item()
+    bad = (out.cpu() != codes0).nonzero()
+    for b, cb in bad.tolist():
+        _excuse(float(gold["margin"][0][cb, b]), noise, f"frame 0 utterance {b} codebook {cb}", tie=BATCH32_TIE)
+    row = torch.zeros(B, 1, 33, dtype=torch.long); row[:, 0, :32] = codes0.long()
+    rmask = torch.ones(B, 1, 33, dtype=torch.bool); rmask[:, 0, 32] = False
+    got = m.generate_frame(row, rmask, torch.full((B, 1), S), 1.0, 1).cpu()
+    n_cmp = sum(_same_until_a_near_tie(got[b], gold["codes"][1][b], gold["margin"][1][:, b], noise, f"graph step, utterance {b}", tie=BATCH32_TIE) for b in range(B))
+    del m
+    m2 = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S, weights_dtype="fp8")
+    m2.setup_caches(B)
+    m2.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+    m2.prefill(row, rmask, torch.full((B, 1), S))
+    out1, logits1 = m2.depth(B, 1.0, 1, forced=gold["codes"][1], want_logits=True, commit=False)
+    d1 = (torch.gather(logits1.float().cpu(), 2, gold["top_i"][1].long()) - gold["top_v"][1].float()).abs().max().item()
+    print(f"config 5 at B=32 (S=1334, fp8): max|dlogit| frame 0 {d0:.4f}, frame 1 {d1:.4f} (gap {noise:.4f}); {len(bad)} of {B * 32} greedy rows excused; "
+          f"{n_cmp} of {B * 32} graph-step decisions compared")
+    assert max(d0, d1) <= BATCH32_GAP * noise
+    assert len(bad) <= 0.08 * B * 32 and n_cmp >= B * 8
+
+
+def test_csm1b_prompt_to_pcm_composed_vs_oracle(csm1b):
+    """north_star: "outputs match the reference -d cpu path on identical text+voice prompts within a stated PCM/float tolerance
+    (bit-exact for codebook indices under greedy)" -- the COMPOSED path, end to end.  BASELINE config 2's prompt given as the
+    reference gives it (a voice-prompt Segment + the text to speak) -> Generator.generate (prompt assembly, prefill, hipGraph frame
+    loop, Mimi decode on the GPU), greedy, 10 frames, against csm_ref (frames, reference loop generator.py:283-294) + mimi_ref
+    (PCM, generator.py:299) run live on this host.  Codes: identical up to the oracle's first near-tie frame (a frame that differs
+    must part at a codebook where the oracle's margin is inside NEAR_TIE x gap).  PCM: Mimi is strictly causal, so the samples of
+    the frames before the first difference must agree: |HIP - oracle| <= 2e-5 x the oracle clip's peak."""
+    from oracle import csm_ref as C, mimi_ref as M
+    from sesameai.generator import Generator, Segment
+    from sesameai.mimi import MimiArgs, MimiCodec, synthetic_state_dict as mimi_sd
+    from sesameai.models import Model, csm_1b_args
+    _, sd = csm1b
+    g2 = torch.load(os.path.join(GOLD, "csm1b_cfg2.pt"))
+    noise = float(g2["bf16_vs_fp32_gap"].max())
+    tok, msk = g2["prompt_tokens"], g2["prompt_mask"]                      # = bench.py's config-2 prompt (asserted in the config-2 test)
+    n_frames = 10
+    # the same prompt in the reference's terms: Segment(speaker, text ids, audio codes) + text ids
+    ctx = [Segment(speaker=1, text=tok[:40, 32].tolist(), audio_codes=tok[40:165, :32].t().contiguous())]
+    text = tok[166:, 32].tolist()
+    model = Model(csm_1b_args(), sd, max_frames=32, max_prefill_rows=256)
+    codec = MimiCodec(MimiArgs(), mimi_sd(MimiArgs(), seed=4321), max_frames=32)
+    gen = Generator(model, audio_tokenizer=codec)
+    pt, pm = gen._build_prompt(text, 1, ctx)
+    assert torch.equal(pt.cpu(), tok) and torch.equal(pm.cpu(), msk), "prompt assembly differs from the golden prompt"
+    seen = []
+    frames = gen.generate_codes(pt, pm, n_frames, 1.0, 1)[:, 0]            # [n][32] -- what generate() decodes
+    pcm = gen.generate(text, 1, ctx, max_audio_length_ms=n_frames * 80, temperature=1.0, topk=1).cpu()
+    assert pcm.shape == (n_frames * 1920,)
+    # the oracle, live
+    shape = C.csm_1b()
+    om = C.OracleModel(shape, C.make_weights(shape, seed=1234)); om.setup_caches(1)
+    cur_t, cur_m, pos = tok.unsqueeze(0), msk.unsqueeze(0), torch.arange(tok.shape[0]).unsqueeze(0)
+    ref, margins = [], []
+    for f in range(n_frames):
+        tr = C.FrameTrace()
+        sf = om.generate_frame(cur_t, cur_m, pos, 1.0, 1, greedy=True, trace=tr)
+        top2 = torch.topk(torch.stack(tr.logits, 0)[:, 0].float(), 2, dim=-1)[0]
+        ref.append(sf[0]); margins.append(top2[:, 0] - top2[:, 1])
+        cur_t = torch.cat([sf.long(), torch.zeros(1, 1).long()], dim=1).unsqueeze(1)
+        cur_m = torch.cat([torch.ones_like(sf).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
+        pos = pos[:, -1:] + 1
+    ref = torch.stack(ref)
+    n_same = int((ref == frames).all(dim=1).float().cumprod(0).sum())
+    first_tie = next((f for f in range(n_frames) if bool((margins[f] <= NEAR_TIE * noise).any())), n_frames)
+    assert n_same >= min(first_tie, n_frames), f"codes part at frame {n_same}, before the oracle's first near-tie (frame {first_tie})"
+    if n_same < n_frames:
+        _same_until_a_near_tie(frames[n_same], ref[n_same], margins[n_same], noise, f"composed run, frame {n_same}")
+    assert n_same >= 1
+    ms, mw = M.mimi_full(), M.make_weights(M.mimi_full(), seed=4321)
+    want = M.decode(ms, mw, ref.t().unsqueeze(0).long())[0, 0]             # (n_frames * 1920,)
+    peak = float(want.abs().max())
+    err = float((pcm[: n_same * 1920] - want[: n_same * 1920]).abs().max())
+    print(f"composed prompt -> PCM: {n_same} of {n_frames} frames identical to the live oracle (its first near-tie: frame {first_tie}); "
+          f"PCM of those frames: max|d| = {err:.3e} = {err / peak:.2e} of peak {peak:.3f}")
+    assert err <= 2e-5 * peak
+
+
+@pytest.mark.parametrize("B", [1, 8])
+@pytest.mark.parametrize("bad", ["inf", "nan"])
+def test_non_finite_weights_flow_through_as_non_finite_not_as_a_stalled_launch(csm1b, B, bad):
+    """the batched persistent decoder's exchange uses the payload as its own flag (poison 0xFFFFFFFF); a checkpoint
+    with an Inf / NaN weight row must not turn into a 50 ms spin + CSM_E_HIP.  Documented outcome (include/csm_hip.h): non-finite
+    activations propagate like in the reference (its torch ops do not stall on NaN either): the launch completes at its normal speed, no error
+    word is raised, the all-CU paths stay on, every code is inside [0, audio_vocab), and the poisoned row's logits are non-finite."""
+    import time
+    from sesameai.models import Model, csm_1b_args
+    gold, sd = csm1b
+    sd = dict(sd)
+    w = sd["decoder.layers.1.mlp.w2.weight"].clone()
+    w[77] = float("inf") if bad == "inf" else float("nan")                 # one output row of a down projection
+    sd["decoder.layers.1.mlp.w2.weight"] = w
+    tok, msk = gold["prompt_tokens"], gold["prompt_mask"]
+    S = tok.shape[0]
+    m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * 64)
+    m.setup_caches(B)
+    want_paths = 1 if B == 1 else 2
+    assert m.fast_paths() & want_paths
+    m.prefill(tok.unsqueeze(0).repeat(B, 1, 1), msk.unsqueeze(0).repeat(B, 1, 1), torch.arange(S).unsqueeze(0).repeat(B, 1))
+    out, logits = m.depth(B, 0.9, 50, want_logits=True, commit=True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(4):
+        m.step(B, 0.9, 50)
+    frames, eos = m.read_frames(B)                                          # raises CSM_E_HIP if a launch gave up
+    took = time.perf_counter() - t0
+    assert m.fast_paths() & want_paths, "the all-CU launch was switched off"
+    assert int(frames.min()) >= 0 and int(frames.max()) < 2051
+    assert not bool(torch.isfinite(logits[2:].float()).all()), "the non-finite row never reached the logits"
+    assert took < 0.04, f"4 frame steps took {took * 1e3:.1f} ms: a launch spun on non-finite payload"
 
 
 @pytest.mark.parametrize("weights", ["bf16", "fp8"])
@@ -1082,7 +1361,7 @@ def test_persistent_decoder_vs_launch_chain_and_golden(csm1b, monkeypatch):
         n_idx += int((op != oc).sum())
         top2 = torch.topk(lc, 2, dim=-1)[0]
         for cb in (op[0] != oc[0]).nonzero().flatten().tolist():
-            assert float(top2[cb, 0] - top2[cb, 1]) <= 2 * noise, f"frame {f} codebook {cb}: greedy index differs away from a tie"
+            _excuse(float(top2[cb, 0] - top2[cb, 1]), noise, f"frame {f} codebook {cb}: greedy index differs away from a tie")
     same = (outs["persistent"][1] == outs["chain"][1]).all(dim=2)[:, 0]
     print(f"persistent vs chain: max|dlogit| = {worst:.4f} (oracle noise floor {noise:.4f}); {n_idx} of {4 * 32} greedy indices differ; "
           f"sampled free run: first {int(same.float().cumprod(0).sum())} of {same.numel()} frames identical")
@@ -1138,62 +1417,12 @@ def test_batched_persistent_decoder_vs_launch_chain(csm1b, monkeypatch, B):
         top2 = torch.topk(lc, 2, dim=-1)[0]                      # [32][B][2]
         for b, cb in (op != oc).nonzero().tolist():
             n_idx += 1
-            assert float(top2[cb, b, 0] - top2[cb, b, 1]) <= 2 * noise, f"frame {f} utterance {b} codebook {cb}: greedy index differs away from a tie"
+            _excuse(float(top2[cb, b, 0] - top2[cb, b, 1]), noise, f"frame {f} utterance {b} codebook {cb}: greedy index differs away from a tie")
     same = (outs["persistent"][1] == outs["chain"][1]).all(dim=2).all(dim=1)
     print(f"batched persistent vs chain, B={B}: max|dlogit| = {worst:.4f} (oracle noise floor {noise:.4f}); {n_idx} of {3 * 32 * B} greedy indices differ; "
           f"sampled free run: first {int(same.float().cumprod(0).sum())} of {same.numel()} frames identical")
     assert worst <= 0.5 * noise, "the two decoder paths differ by more than half the oracle's own bf16-vs-fp32 gap (measured 0.28x)"
     assert n_idx <= 0.03 * 3 * 32 * B + 1, "too many greedy picks differ between the two decoder paths"
-
-
-@pytest.mark.parametrize("B", [2, 3, 16, 17, 32])
-def test_batched_backbone_attention_block_vs_launch_chain(csm1b, monkeypatch, B):
-    """(Opt-in path, CSM_BB_ATTN_M=1: measured no faster than the launches it replaces at 32 rows, 2.4 % faster at 2 rows.)  Batched decode
-    steps run q|k|v -> attention -> o-projection of every backbone layer as ONE launch (csrc/bb_attn_m.cuh) instead of four (B = 2: instead
-    of three GEMV launches).  Same rounding points, different fp32 summation orders.  Rows sit at
-    DIFFERENT positions (each utterance of a batch has its own), decode rows are teacher-forced: after every step the logits of
-    all 32 codebooks must agree with the launch chain's within the oracle's own bf16-vs-fp32 gap (a backbone difference travels
-    through 16 layers: the batch-1 block measures 0.065 against its chain the same way), greedy picks may differ
-    only at near-ties, and the K / V the launch appended must serve the following steps (three steps in a row)."""
-    import bench
-    from oracle import csm_ref as C
-    from sesameai.models import Model, csm_1b_args
-    gold, sd = csm1b
-    noise = float(gold["bf16_vs_fp32_gap"].max())
-    tok, msk = bench.synthetic_prompt(_bench_args(), B, C.csm_1b().text_vocab_size, seed0=8000)
-    tok, msk = tok[:, :40], msk[:, :40]
-    S = tok.shape[1]
-    g = torch.Generator().manual_seed(B)
-    forced = torch.randint(0, 2048, (3, B, 32), generator=g)
-    base = torch.tensor([S - (b * 5) % 23 for b in range(B)])                   # per-row positions: S, S-5, S-10, ...
-    outs = {}
-    for name, env in (("fused", "1"), ("chain", "0")):
-        monkeypatch.setenv("CSM_BB_ATTN_M", env)
-        m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S)
-        m.setup_caches(B)
-        assert bool(m.fast_paths() & 32) == (env == "1")
-        m.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
-        per = []
-        for f in range(3):
-            row = torch.zeros(B, 1, 33, dtype=torch.long); row[:, 0, :32] = forced[f]
-            rmask = torch.ones(B, 1, 33, dtype=torch.bool); rmask[:, 0, 32] = False
-            m.prefill(row, rmask, (base + f).unsqueeze(1))                       # one decode row per utterance, each at its own position
-            out, logits = m.depth(B, 1.0, 1, forced=forced[f], want_logits=True, commit=False)
-            per.append((out.cpu(), logits.float().cpu()))
-        m.read_frames(B)                                                         # raises if a launch gave up
-        outs[name] = per
-        del m
-    worst, n_idx = 0.0, 0
-    for f in range(3):
-        (of, lf), (oc, lc) = outs["fused"][f], outs["chain"][f]
-        worst = max(worst, (lf - lc).abs().max().item())
-        top2 = torch.topk(lc, 2, dim=-1)[0]
-        for b, cb in (of != oc).nonzero().tolist():
-            n_idx += 1
-            assert float(top2[cb, b, 0] - top2[cb, b, 1]) <= 2 * noise, f"step {f} utterance {b} codebook {cb}: greedy index differs away from a tie"
-    print(f"batched backbone attention block vs chain, B={B}: max|dlogit| = {worst:.4f} (oracle noise floor {noise:.4f}); {n_idx} of {3 * 32 * B} greedy indices differ")
-    assert worst <= (1.1 if B > 16 else 1.0) * noise          # (measured 0.70-0.94x up to 17 rows, 1.05x at 32: the 32-row batched paths sit at 1.03-1.05x everywhere)
-    assert n_idx <= 0.05 * 3 * 32 * B + 1
 
 
 @pytest.mark.parametrize("B", [3, 8, 32])
@@ -1331,7 +1560,7 @@ def test_backbone_attention_block_vs_launch_chain(csm1b, monkeypatch):
         worst = max(worst, (lb - lc).abs().max().item())
         top2 = torch.topk(lc, 2, dim=-1)[0]
         for cb in (ob[0] != oc[0]).nonzero().flatten().tolist():
-            assert float(top2[cb, 0] - top2[cb, 1]) <= 2 * noise, f"codebook {cb}: greedy index differs away from a tie"
+            _excuse(float(top2[cb, 0] - top2[cb, 1]), noise, f"codebook {cb}: greedy index differs away from a tie")
     print(f"backbone block vs chain: max|dlogit| = {worst:.4f} (oracle noise floor {noise:.4f})")
     assert worst > 0.0, "both runs took the same path"
     assert worst <= noise

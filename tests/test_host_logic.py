@@ -680,3 +680,37 @@ def test_tts_service_watermarks_every_clip(monkeypatch):
     audio = tts.generate_with_context("hi", max_audio_length_ms=1000)
     assert len(calls) == 1 and calls[0][1] == 44100 and calls[0][2] == mod.CSM_1B_GH_WATERMARK
     assert abs(audio.shape[0] - 4 * 1920) <= 2 and abs(float(audio[2000:5000].mean()) - 0.5) < 0.02       # marked audio, back at 24 kHz
+
+
+def test_tts_say_generates_sentence_by_sentence_reports_rtf_and_survives_a_failing_sentence(tmp_path, capsys):
+    """reference: TTS.say (tts_service.py:313-470), generation half: one generate_audio_segment per sentence, the reference's
+    ``> sentence ... [Audio: ..s in ..s, RTF: ..x]`` line, a failing sentence replaced by fallback silence, the combined WAV
+    written when a filename is given; every segment is offered to ``on_segment`` as soon as it exists (the player hook)."""
+    import importlib.util
+    import wave
+    spec = importlib.util.spec_from_file_location("tts_service_amd3", os.path.join(ROOT, "sesameai-tts_amd", "tts_service.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+
+    class Gen:
+        sample_rate, device = 24_000, torch.device("cpu")
+        def _tokenize_text_segment(self, text, speaker):
+            if "boom" in text:
+                raise RuntimeError("scripted failure")
+            return torch.zeros(3, 33).long(), torch.zeros(3, 33).bool()
+        def generate_codes(self, t, m, n, temp, topk): return torch.ones(5, 1, 32, dtype=torch.int32)
+        def _decode_frames(self, fr): return torch.linspace(-1, 1, fr.shape[0] * 1920)
+
+    tts = mod.TTS(voice_dir="/nonexistent")
+    tts.generator, tts.watermarker = Gen(), None
+    got = []
+    out = tmp_path / "say.wav"
+    tts.say("  First sentence. This one goes boom! And a third?  ", output_filename=str(out), on_segment=lambda pcm, sr: got.append((len(pcm), sr)))
+    printed = capsys.readouterr().out
+    assert printed.count("[Audio: ") == 2 and "RTF: " in printed and "> First sentence. ... " in printed
+    assert "Error generating audio for sentence: This one goes boom!: scripted failure" in printed and "Export complete:" in printed
+    seg = 5 * 1920 + 24_000 * 600 // 1000                           # audio + 500 ms lead + 100 ms tail silence
+    assert got == [(seg, 24_000), (24_000, 24_000), (seg, 24_000)]  # the failed sentence: 1000 ms of fallback silence
+    with wave.open(str(out), "rb") as f:
+        assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (1, 2, 24_000, 2 * seg + 24_000)
+    tts.say("   ", output_filename=None)
+    assert "No valid text to process" in capsys.readouterr().out

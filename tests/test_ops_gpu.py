@@ -258,7 +258,7 @@ def test_attention(abi, H, KV, hd, nsplit):
     mask = torch.arange(smax)[None, None, :] <= pos[:, :, None]                  # (B,S,smax)
     want = F.scaled_dot_product_attention(q.transpose(1, 2), kk, vv, attn_mask=mask[:, None]).transpose(1, 2)
     out = torch.zeros(M, H * hd, dtype=torch.bfloat16, device="cuda")
-    part = torch.zeros(M * H * nsplit * (hd + 4), dtype=torch.float32, device="cuda")
+    part = torch.zeros(M * H * nsplit * ((hd + 2 + 31) // 32 * 32), dtype=torch.float32, device="cuda")      # ATTN_PS(hd): partial rows are whole 128-byte lines
     qd, kd, vd, pd = dev(q), dev(kc), dev(vc), dev(pos.reshape(-1), torch.int32)    # keep the device copies alive
     _ck(abi, abi.lib.csm_op_attn(M, S, H, KV, hd, smax, nsplit, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(),
                                  pd.data_ptr(), out.data_ptr(), part.data_ptr(), stream()))
@@ -302,7 +302,7 @@ def test_decode_attention_over_long_key_ranges(abi, nsplit):
     sc = (q.double().transpose(1, 2) @ kk.double().transpose(-1, -2)) / hd ** 0.5
     exact = (sc.masked_fill(~mask[:, None], float("-inf")).softmax(-1) @ vv.double()).transpose(1, 2)
     out = torch.zeros(B, H * hd, dtype=torch.bfloat16, device="cuda")
-    part = torch.zeros(B * H * nsplit * (hd + 4), dtype=torch.float32, device="cuda")
+    part = torch.zeros(B * H * nsplit * ((hd + 2 + 31) // 32 * 32), dtype=torch.float32, device="cuda")
     qd, kd, vd, pd = dev(q), dev(kc), dev(vc), dev(pos.reshape(-1), torch.int32)
     _ck(abi, abi.lib.csm_op_attn(B, 1, H, KV, hd, smax, nsplit, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(),
                                  pd.data_ptr(), out.data_ptr(), part.data_ptr(), stream()))
