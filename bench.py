@@ -234,7 +234,7 @@ def batch32_leg(args, margs, sd, dev, n_steps, seed0=4000, barrier=None):
     B3 = 32
     tok, msk = synthetic_prompt(args, B3, margs.text_vocab_size, seed0=seed0)
     S = tok.shape[1]
-    m3 = Model(margs, sd, device=str(dev), max_frames=n_steps + 16, max_prefill_rows=B3 * S)
+    m3 = Model(margs, sd, device=str(dev), max_frames=4 * n_steps + 64, max_prefill_rows=B3 * S)
     m3.setup_caches(B3); m3.seed(77)
     pos = torch.arange(S).unsqueeze(0).repeat(B3, 1)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -250,7 +250,43 @@ def batch32_leg(args, margs, sd, dev, n_steps, seed0=4000, barrier=None):
     frames, _ = m3.read_frames(B3)                    # raises if a launch gave up
     assert int(frames.min()) >= 0 and int(frames.max()) < margs.audio_vocab_size
     by = m3.bytes_per_frame(B3, S + 5 + n_steps / 2.0)
+    # ---- a slot refilled while the other 31 keep generating (reference: one prefill per sentence, tts_service.py:191-207) ----
+    refill = None
+    if os.environ.get("BENCH_SKIP_REFILL") != "1":
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # (a) csm_prefill_slot: the whole prompt + a batch-1 depth pass between two frame steps -- everybody waits
+        torch.cuda.synchronize(); e0.record(st)
+        m3.refill_slot(0, tok[0], msk[0], T, K)
+        e1.record(st); torch.cuda.synchronize()
+        stall_ms = e0.elapsed_time(e1)
+        # (b) csm_refill_begin / csm_refill_advance: `per_step` layers of the prompt after EVERY frame step, back to back refills (the worst case:
+        # a refill always in flight), frame 0 sampled in the batch
+        per_step = max(1, 600 // S)
+        slot = 1
+        m3.refill_begin(slot, tok[slot], msk[slot])
+        for _ in range(3):
+            m3.step(B3, T, K); m3.refill_advance(per_step)
+        torch.cuda.synchronize(); e0.record(st)
+        n_ref, done_refills = max(n_steps, 16), 0
+        for _ in range(n_ref):
+            m3.step(B3, T, K)
+            if m3.refill_advance(per_step):
+                done_refills += 1
+                slot = (slot + 1) % B3
+                m3.refill_begin(slot, tok[slot], msk[slot])
+        e1.record(st); torch.cuda.synchronize()
+        ms_ref = e0.elapsed_time(e1) / n_ref
+        while not m3.refill_advance(16):
+            pass
+        m3.read_frames(B3, m3.num_frames() - 1, 1)          # raises if a launch gave up / a position overflowed
+        refill = {"prompt_rows": S, "layers_per_step": per_step, "ms_per_step_no_refill": round(ms, 4), "ms_per_step_with_a_refill_always_in_flight": round(ms_ref, 4),
+                  "overhead_frac": round(ms_ref / ms - 1.0, 4), "refills_completed": done_refills, "steps": n_ref,
+                  "stall_of_a_whole_prompt_between_two_steps_ms": round(stall_ms, 3),
+                  "note": "csm_refill_begin/advance: the prompt's layers run beside the frame loop, its frame 0 is sampled by the batch's next step; "
+                          "csm_prefill_slot (the stall figure) runs prompt + batch-1 depth pass in one go"}
     res = {"workload": f"CSM-1B B={B3}, S={S} prompt rows each, hipGraph frame step, {n_steps} timed steps", "ms_per_step": round(ms, 4),
+           "refill_beside_the_loop": refill,
            "frames_per_s": round(B3 * 1e3 / ms, 1), "rtf_aggregate": round(B3 * 1e3 / ms / 12.5, 1),
            "prefill_plus_frame0_ms": round(pre_ms, 1), "roofline_frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "dominant_kernels": dominant_kernels(m3, B3, T, K, reps=5)}
@@ -260,8 +296,10 @@ def batch32_leg(args, margs, sd, dev, n_steps, seed0=4000, barrier=None):
 
 def reference_loop_leg(args, margs, sd, dev, n_frames=60):
     """ms per frame when the model is driven exactly like the reference's loop (tts_service.py:224-241, generator.py:283-294):
-    one Model.generate_frame call per frame with S = 1 host-built rows, `torch.all(sample == 0)` read on the host after every
-    frame (a device sync), next row assembled with torch.cat on the device."""
+    one Model.generate_frame call per frame with S = 1 rows built by the caller (int64 tokens / positions, bool mask, as the
+    reference's torch.cat promotes them), `torch.all(sample == 0)` read on the host after every frame (a device sync), next row
+    assembled with torch.cat on the device.  Also where the frame goes on the HOST: inside generate_frame (one C-ABI call,
+    csm_generate_frame_s1), in the EOS check (= waiting for the GPU's frame) and in the caller's own tensor ops."""
     from sesameai.models import Model
     T, K = args.temperature, args.topk
     tok, msk = synthetic_prompt(args, 1, margs.text_vocab_size)
@@ -269,33 +307,42 @@ def reference_loop_leg(args, margs, sd, dev, n_frames=60):
     m = Model(margs, sd, device=str(dev), max_frames=n_frames + 16, max_prefill_rows=S)
     m.setup_caches(1); m.seed(5)
     zeros_tok, zeros_msk = torch.zeros(1, 1, dtype=torch.long, device=dev), torch.zeros(1, 1, dtype=torch.bool, device=dev)
+    host = {"generate_frame": 0.0, "eos_check": 0.0, "caller_ops": 0.0}
 
-    def loop(n):
+    def loop(n, account=False):
         m.reset_caches()
         curr_tokens, curr_mask = tok.to(dev), msk.to(dev)
         curr_pos = torch.arange(S, device=dev).unsqueeze(0)
         samples = []
-        for _ in range(n):
+        for i in range(n):
+            t0 = time.perf_counter()
             sample = m.generate_frame(curr_tokens, curr_mask, curr_pos, T, K)
+            t1 = time.perf_counter()
             if torch.all(sample == 0):
                 break
+            t2 = time.perf_counter()
             samples.append(sample)
-            curr_tokens = torch.cat([sample, zeros_tok.to(sample.dtype)], dim=1).unsqueeze(1)
+            curr_tokens = torch.cat([sample, zeros_tok], dim=1).unsqueeze(1)                   # int32 + int64 -> int64, as in the reference
             curr_mask = torch.cat([torch.ones_like(sample).bool(), zeros_msk], dim=1).unsqueeze(1)
             curr_pos = curr_pos[:, -1:] + 1
+            t3 = time.perf_counter()
+            if account and i > 0:
+                host["generate_frame"] += t1 - t0; host["eos_check"] += t2 - t1; host["caller_ops"] += t3 - t2
         return len(samples)
     loop(6)                                            # captures the graph
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    n = loop(n_frames)
+    n = loop(n_frames, account=True)
     torch.cuda.synchronize(); wall = time.perf_counter() - t0
     # frame 0 is the prompt (prefill + depth): time the S = 1 frames alone as well
     torch.cuda.synchronize(); t0 = time.perf_counter()
     loop(1)
     torch.cuda.synchronize(); first = time.perf_counter() - t0
     del m
+    per = (wall - first) * 1e3 / max(n - 1, 1)
     return {"workload": f"reference-style host loop (tts_service.py:224-241): generate_frame per frame, host EOS check each frame, B=1, S={S} prompt, {n} frames",
-            "frames": n, "ms_per_frame_after_the_prompt": round((wall - first) * 1e3 / max(n - 1, 1), 4), "prompt_frame_ms": round(first * 1e3, 2),
-            "rtf": round(80.0 / ((wall - first) * 1e3 / max(n - 1, 1)), 2)}
+            "frames": n, "ms_per_frame_after_the_prompt": round(per, 4), "prompt_frame_ms": round(first * 1e3, 2), "rtf": round(80.0 / per, 2),
+            "host_us_per_frame": {k: round(v * 1e6 / max(n - 1, 1), 1) for k, v in host.items()},
+            "note": "eos_check = the host waiting for the frame (torch.all(sample == 0) synchronises); generate_frame = one ctypes call: stage kernel + graph launch + copy-out"}
 
 
 def extras_legs(args, margs, sd, dev):

@@ -164,6 +164,20 @@ int csm_reset_slots(csm_handle h, const int32_t* slots /*host*/, int n, void* st
 int csm_prefill_slot(csm_handle h, int slot, const int32_t* tokens, const uint8_t* mask, const int32_t* pos, int S,
                      int prompt_mode, float temperature, int topk, int32_t* out_frame, void* stream);
 
+/* Refill BESIDE the frame loop (round 4): csm_prefill_slot makes the other slots wait for the new prompt's whole prefill and a
+ * batch-1 depth pass (4 ms at 190 rows, > 8 ms at 1,334).  Here the prompt runs a few backbone layers per call between frame
+ * steps, in buffers of its own, and the new utterance's frame 0 is sampled BY THE NEXT FRAME STEP, in the batch, from the prompt's
+ * last row (an inject node in the frame-step graph; the slot's position stays for that one step and its EOS word restarts).
+ *   csm_refill_begin:   embeds the prompt rows (tokens [S][33] / mask [S][33] / pos [S], dev; pos must stay valid until the refill
+ *                       completes) and parks the slot: until completion its rows of the frame steps are placeholders whose frames
+ *                       the caller ignores.  One refill at a time per handle (CSM_E_STATE otherwise).  Needs max_batch >= 3.
+ *   csm_refill_advance: runs up to max_layers more backbone layers of the pending prompt.  Returns 1 when the prompt is complete --
+ *                       the NEXT csm_frame_step then yields the utterance's frame 0 in that slot's row, at that step's global frame
+ *                       index -- 0 while layers remain, < 0 on error.  Call both on the stream that runs the frame steps.
+ * The other slots' frames are bit-identical to an undisturbed run (their rows never see the refill).                          */
+int csm_refill_begin(csm_handle h, int slot, const int32_t* tokens, const uint8_t* mask, const int32_t* pos, int S, void* stream);
+int csm_refill_advance(csm_handle h, int max_layers, void* stream);
+
 /* Why there is no csm_broadcast_weights here (SURVEY.md 8b lists one): the multi-GPU layout is replicas with ONE start-up
  * broadcast of a flat weight blob and no per-step collective.  The communicator that does it belongs to
  * torch.distributed (backend "nccl" = RCCL over xGMI; sesameai/parallel.py), which owns the process's single RCCL instance; a

@@ -76,6 +76,12 @@ struct CsmModel {
     uint64_t* rng;                      // [0..1] {seed, frame-step counter}; [2..3] the refill domain {seed ^ REFILL_SALT, refill counter} (rng_slot)
     uint64_t* rng_slot;
     int* frame_save;                    // [ncb] slot 0's newest frame while a slot refill's depth pass uses scratch row 0
+    // refill beside the frame loop (csm_refill_begin / csm_refill_advance): a prompt runs a few backbone layers per call between frame
+    // steps; its residual stream and the next layer's normalised input live in buffers of their own, everything else is transient
+    int* fresh;                         // [max_batch] device flags: the slot's next frame step yields its frame 0 from rf_last
+    bf16_t *rf_h, *rf_xn, *rf_last;     // [max_rows][d_bb] x 2, [max_batch][2 d_bb] final-normed last prompt row per slot (dec_in layout)
+    int rf_slot, rf_S, rf_layer;        // pending refill: slot (-1 = none), prompt rows, next layer to run
+    const int* rf_pos;                  // the caller's position array of the pending refill (dev, valid until the refill completes)
     int device;                         // the GPU this handle lives on (csm_generate_frame_s1 makes it current itself)
     int host_frames;                    // frames launched since reset (host mirror); the history is a ring of max_frames rows
     int wide_path;                      // MFMA path for M >= wide_min (env CSM_WIDE=0 disables)
@@ -420,7 +426,10 @@ struct FinalNorm { const bf16_t* scale; bf16_t* out; long out_stride; };
 
 static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t* att, bf16_t* act,
                                  int M, int rows_per_seq, const int* pos, hipStream_t st, bool prompt, const FinalNorm& fin,
-                                 bool x_normed, bool qkv0_done) {
+                                 bool x_normed, bool qkv0_done, int l_begin = 0, int l_end = -1) {
+    // [l_begin, l_end): a prompt may run a few layers per call (csm_refill_advance): what carries over between calls is h (the residual
+    // stream) and att (the next layer's normalised input, written by the previous layer's finisher) -- and the K/V the layers appended
+    if (l_end < 0) l_end = S.d.n_layers;
     // unfused wide-M layer: norm -> MFMA qkv(+rope, KV append) -> attention -> MFMA o-proj(+res) ->
     // norm -> MFMA gate/up(SiLU*up) -> MFMA down(+res).  `att` doubles as the normalised-activation buffer.
     const int d = S.d.dim;
@@ -428,7 +437,7 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
     // 128 x 128 LDS-tiled kernels (same bits as the path below) for prefill; decode steps (<= 2 rows per sequence) stay on
     // the 32-row-tile kernels with operand-order activations whatever the batch (B = 256: 13.7 vs 21 ms)
     const bool big = M >= G128_MIN_ROWS && (prompt || rows_per_seq > 2);
-    for (int l = 0; l < S.d.n_layers; ++l) {
+    for (int l = l_begin; l < l_end; ++l) {
         const CsmLayerWeights& w = S.lw[l];
         const CsmLayerWeights& pk = S.pk[l];
         bf16_t* kc = S.kc + (long)l * S.layer_stride + S.slot_off;
@@ -584,13 +593,14 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
 // (depth decoder), which lets the narrow path drop the dependent position load
 static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t* att, bf16_t* act,
                             int M, int rows_per_seq, const int* pos_arr, int pos_const, hipStream_t st, bool force_wide = false,
-                            bool x_normed = false, bool qkv0_done = false) {
+                            bool x_normed = false, bool qkv0_done = false, int l_begin = 0, int l_end = -1, bf16_t* fin_out = nullptr) {
     if ((M >= m->wide_min || force_wide) && m->wide_path) {
         FinalNorm fin;
-        if (&S == &m->bb) { fin.scale = (const bf16_t*)m->w.bb_norm; fin.out = m->dec_in; fin.out_stride = 2L * S.d.dim; }
+        if (&S == &m->bb) { fin.scale = (const bf16_t*)m->w.bb_norm; fin.out = fin_out ? fin_out : m->dec_in; fin.out_stride = 2L * S.d.dim; }
         else { fin.scale = (const bf16_t*)m->w.dec_norm; fin.out = att; fin.out_stride = S.d.dim; }
-        return run_stack_wide(m, S, h, q, att, act, M, rows_per_seq, pos_arr, st, force_wide, fin, x_normed, qkv0_done);
+        return run_stack_wide(m, S, h, q, att, act, M, rows_per_seq, pos_arr, st, force_wide, fin, x_normed, qkv0_done, l_begin, l_end);
     }
+    if (l_begin != 0 || (l_end >= 0 && l_end != S.d.n_layers) || fin_out != nullptr) return hipErrorInvalidValue;      // layer ranges: matrix-core path only
     const int* pos = pos_const >= 0 ? nullptr : pos_arr;
     const int pos_base = pos_const >= 0 ? pos_const : 0;
     const int d = S.d.dim;
@@ -702,10 +712,10 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
     return hipSuccess;
 }
 
-static hipError_t launch_embed(CsmModel* m, const int* tokens, const uint8_t* mask, int M, hipStream_t st) {
+static hipError_t launch_embed(CsmModel* m, const int* tokens, const uint8_t* mask, int M, hipStream_t st, bf16_t* out = nullptr) {
     hipLaunchKernelGGL(k_embed_sum, dim3(M), dim3(256), 0, st, tokens, mask, (const bf16_t*)m->w.text_emb,
                        (const bf16_t*)m->w.audio_emb, m->cfg.audio_vocab, m->cfg.text_vocab, m->cfg.n_codebooks,
-                       m->cfg.backbone.dim, m->h);
+                       m->cfg.backbone.dim, out ? out : m->h);
     return hipGetLastError();
 }
 
@@ -852,6 +862,7 @@ static hipError_t launch_advance(CsmModel* m, int B, const int* fed, int pos_inc
     a.cur_mask = m->cur_mask; a.cur_pos = m->cur_pos; a.rng = m->rng; a.out_frame = nullptr; a.fed = fed; a.pos_inc = pos_inc;
     a.max_seq = m->cfg.backbone.max_seq; a.overflow = m->n_frames + 1;
     a.err0 = m->p_state + 1; a.err1 = m->b_state + 1;
+    a.fresh = pos_inc ? m->fresh : nullptr;
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(256), 0, st, a);
     return hipGetLastError();
 }
@@ -1216,6 +1227,9 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     ALLOC(m->rng, 32);
     m->rng_slot = m->rng + 2;
     ALLOC(m->frame_save, (size_t)ncb * 4);
+    ALLOC(m->fresh, (size_t)max_batch * 4);
+    HIPCHK((CsmModel*)nullptr, hipMemset(m->fresh, 0, (size_t)max_batch * 4));
+    m->rf_h = m->rf_xn = m->rf_last = nullptr; m->rf_slot = -1; m->rf_S = 0; m->rf_layer = 0; m->rf_pos = nullptr;
     ALLOC(m->dec_pos, (size_t)(ncb + 1) * 2 * max_batch * 4);
     ALLOC(m->slot_scratch, (size_t)max_batch * 4);
     ALLOC(m->p_state, 16);
@@ -1311,7 +1325,7 @@ extern "C" void csm_destroy(csm_handle m) {
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     void* ptrs[] = {m->bb.kc, m->bb.vc, m->dec.kc, m->dec.vc, m->h, m->q, m->att, m->act, m->part, m->attn_ctr, m->dec_in, m->proj_emb, m->slab,
                     m->hdec, m->qd, m->attd, m->actd, m->logits, m->frame, m->cur_tokens, m->cur_mask, m->cur_pos,
-                    m->history, m->n_frames, m->eos_at, m->rng, m->frame_save, m->dec_pos, m->slot_scratch, m->p_state, m->b_state, m->qkv0_tab};
+                    m->history, m->n_frames, m->eos_at, m->rng, m->frame_save, m->fresh, m->rf_h, m->rf_xn, m->rf_last, m->dec_pos, m->slot_scratch, m->p_state, m->b_state, m->qkv0_tab};
     for (void* p : ptrs) (void)hipFree(p);
     for (void* p : m->pk_allocs) (void)hipFree(p);
     if (m->xslab) (void)hipFree(m->xslab);
@@ -1338,7 +1352,8 @@ extern "C" int csm_reset(csm_handle m, void* stream) {
     HIPCHK(m, hipMemsetAsync(m->n_frames, 0, 8, st));          // frame counter + position-overflow flag
     HIPCHK(m, hipMemsetAsync(m->cur_pos, 0, (size_t)m->max_batch * 4, st));
     HIPCHK(m, hipMemsetAsync(m->eos_at, 0xff, (size_t)m->max_batch * 4, st));
-    m->host_frames = 0; m->have_last = false;
+    HIPCHK(m, hipMemsetAsync(m->fresh, 0, (size_t)m->max_batch * 4, st));
+    m->host_frames = 0; m->have_last = false; m->rf_slot = -1;
     return CSM_OK;
 }
 
@@ -1397,10 +1412,23 @@ extern "C" int csm_copy_frame(csm_handle m, int B, int32_t* out_frame, void* str
     return CSM_OK;
 }
 
+__global__ void k_inject_fresh(const int* fresh, const bf16_t* rf_last, bf16_t* dec_in, int stride, int d) {
+    const int b = blockIdx.x;
+    if (fresh[b] == 0) return;
+    for (int i = threadIdx.x; i < d / 8; i += blockDim.x)
+        reinterpret_cast<uint4*>(dec_in + (long)b * stride)[i] = reinterpret_cast<const uint4*>(rf_last + (long)b * stride)[i];
+}
+
 static hipError_t enqueue_frame(CsmModel* m, int B, float temperature, int topk, hipStream_t st) {
     hipError_t e;
     if ((e = launch_embed(m, m->cur_tokens, m->cur_mask, B, st)) != hipSuccess) return e;
     if ((e = run_stack(m, m->bb, m->h, m->q, m->att, m->act, B, 1, m->cur_pos, -1, st)) != hipSuccess) return e;
+    if (m->rf_last != nullptr && B >= m->wide_min && m->wide_path) {
+        // slots whose prompt was prefilled beside the frame loop take their backbone output from that prompt's last row (one block per
+        // slot; a no-op unless the slot's flag is up).  Only handles that have used csm_refill_begin carry this node.
+        hipLaunchKernelGGL(k_inject_fresh, dim3(B), dim3(256), 0, st, m->fresh, m->rf_last, m->dec_in, 2 * m->cfg.backbone.dim, m->cfg.backbone.dim);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     if ((e = run_depth(m, B, 1, temperature, topk, nullptr, nullptr, nullptr, st)) != hipSuccess) return e;
     return launch_advance(m, B, nullptr, 1, st);
 }
@@ -1549,6 +1577,51 @@ extern "C" int csm_prefill_slot(csm_handle m, int slot, const int32_t* tokens, c
     if (m->host_frames == 0) m->host_frames = 1;
     m->have_last = true; m->last_S = 1;
     return CSM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// refill BESIDE the frame loop: the other slots never wait for a whole prompt
+// ---------------------------------------------------------------------------------------
+extern "C" int csm_refill_begin(csm_handle m, int slot, const int32_t* tokens, const uint8_t* mask, const int32_t* pos, int S, void* stream) {
+    if (!m || !tokens || !mask || !pos) return fail(m, CSM_E_INVALID, "csm_refill_begin: null argument");
+    if (slot < 0 || slot >= m->max_batch || S < 1 || S > m->max_rows) return fail(m, CSM_E_INVALID, "csm_refill_begin: slot / S outside the limits given to csm_create");
+    if (m->rf_slot >= 0) return fail(m, CSM_E_STATE, "csm_refill_begin: a refill is already in progress (finish it with csm_refill_advance)");
+    if (!m->wide_path || m->max_batch < m->wide_min) return fail(m, CSM_E_STATE, "csm_refill_begin: needs the matrix-core decode path (max_batch >= 3); use csm_prefill_slot");
+    hipStream_t st = (hipStream_t)stream;
+    const int dbb = m->cfg.backbone.dim;
+    if (m->rf_last == nullptr) {
+        HIPCHK(m, hipMalloc((void**)&m->rf_h, (size_t)m->max_rows * dbb * 2));
+        HIPCHK(m, hipMalloc((void**)&m->rf_xn, (size_t)m->max_rows * m->bb.nq * 2));
+        HIPCHK(m, hipMalloc((void**)&m->rf_last, (size_t)m->max_batch * 2 * dbb * 2));
+        HIPCHK(m, hipMemsetAsync(m->rf_last, 0, (size_t)m->max_batch * 2 * dbb * 2, st));
+        if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }       // re-capture: the frame step gains its inject node
+    }
+    HIPCHK(m, launch_embed(m, tokens, mask, S, st, m->rf_h));
+    // parked: until the prompt is complete the slot's row of the frame steps is a placeholder at positions >= S (its K/V land beyond the prompt's)
+    hipLaunchKernelGGL(k_set_prefill_state, dim3(1), dim3(256), 0, st, pos, 1, S, m->cur_pos + slot, m->cfg.backbone.max_seq, m->n_frames + 1);
+    HIPCHK(m, hipGetLastError());
+    m->rf_slot = slot; m->rf_S = S; m->rf_layer = 0; m->rf_pos = pos;
+    return CSM_OK;
+}
+
+extern "C" int csm_refill_advance(csm_handle m, int max_layers, void* stream) {
+    if (!m || max_layers < 1) return fail(m, CSM_E_INVALID, "csm_refill_advance: bad argument");
+    if (m->rf_slot < 0) return fail(m, CSM_E_STATE, "csm_refill_advance: no refill in progress");
+    hipStream_t st = (hipStream_t)stream;
+    const int L = m->cfg.backbone.n_layers, dbb = m->cfg.backbone.dim, slot = m->rf_slot, S = m->rf_S;
+    const int l0 = m->rf_layer, l1 = l0 + max_layers < L ? l0 + max_layers : L;
+    m->bb.slot_off = (long)slot * m->cfg.backbone.n_kv_heads * m->bb.cache_len * m->bb.hd;
+    hipError_t e = run_stack(m, m->bb, m->rf_h, m->q, m->rf_xn, m->act, S, S, m->rf_pos, -1, st, true, false, false, l0, l1, m->rf_last + (long)slot * 2 * dbb);
+    m->bb.slot_off = 0;
+    HIPCHK(m, e);
+    m->rf_layer = l1;
+    if (l1 < L) return 0;
+    // complete: position = prompt length again (the placeholder rows drifted beyond it), flag up -- the next frame step samples frame 0
+    hipLaunchKernelGGL(k_set_prefill_state, dim3(1), dim3(256), 0, st, m->rf_pos, 1, S, m->cur_pos + slot, m->cfg.backbone.max_seq, m->n_frames + 1);
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, st, m->fresh + slot, 1, 1);
+    HIPCHK(m, hipGetLastError());
+    m->rf_slot = -1; m->rf_pos = nullptr;
+    return 1;
 }
 
 extern "C" int csm_num_frames(csm_handle m) { return m ? m->host_frames : 0; }

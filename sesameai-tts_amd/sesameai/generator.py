@@ -235,6 +235,10 @@ class Generator:
             return
         poll = poll or self._eos_poll
         B = min(self._max_batch, len(prompts))
+        beside = getattr(m, "supports_refill_beside_the_loop", None)
+        if B >= 3 and max_generation_len > 0 and beside is not None and beside() and getattr(self, "refill_beside_the_loop", True):
+            yield from self._iter_codes_refilling_beside_the_loop(prompts, max_generation_len, temperature, topk, poll, B)
+            return
         pending = deque(range(len(prompts)))
         slot_idx: List[Optional[int]] = [None] * B
         slot_frames: List[List[torch.Tensor]] = [[] for _ in range(B)]
@@ -286,6 +290,76 @@ class Generator:
                 m.reset_slots(idle)                                      # a retired slot keeps stepping: keep its position away from max_seq
             yield from finished
             finished.clear()
+
+    def _iter_codes_refilling_beside_the_loop(self, prompts, max_generation_len: int, temperature: float, topk: int, poll: int, B: int):
+        """The continuously refilled batch WITHOUT stalls (round 4): a retired slot's next prompt runs a few backbone layers after
+        each frame step (Model.refill_begin / refill_advance: about ``refill_row_layers`` = 600 prompt-row x layer units per step, i.e.
+        3 layers of a 190-row prompt = +8 % of a B = 32 step; measured: bench.py extras.config3.refill_beside_the_loop) while the other slots keep generating, and the new utterance's frame
+        0 is sampled by the batch's next frame step -- csm_prefill_slot made the other slots wait ~4 ms for a 190-row prompt and
+        > 8 ms for a 1,334-row one.  Until its prompt is complete a slot's rows are placeholders and are skipped here."""
+        from collections import deque
+        m = self._model
+        L = getattr(m.bb, "num_layers", 16)
+        budget = getattr(self, "refill_row_layers", 600)
+        pending = deque(range(len(prompts)))
+        free = deque(range(B))
+        slot_idx: List[Optional[int]] = [None] * B          # prompt index generating in the slot
+        start_g: List[int] = [0] * B                        # global frame index of its frame 0
+        slot_frames: List[List[torch.Tensor]] = [[] for _ in range(B)]
+        refilling: Optional[Tuple[int, int, int]] = None    # (slot, prompt index, layers per call)
+        m.reset_caches()
+
+        def feed(everything: bool) -> None:
+            """One bounded piece of refill work (``everything``: nobody is generating, so run whole prompts)."""
+            nonlocal refilling
+            while True:
+                if refilling is None:
+                    if not (free and pending):
+                        return
+                    slot, i = free.popleft(), pending.popleft()
+                    t, mk = prompts[i]
+                    m.refill_begin(slot, t, mk)
+                    refilling = (slot, i, L if everything else max(1, budget // max(int(t.shape[0]), 1)))
+                slot, i, per_call = refilling
+                if m.refill_advance(L if everything else per_call):
+                    slot_idx[slot], start_g[slot], slot_frames[slot] = i, m.num_frames(), []
+                    refilling = None
+                if not everything:
+                    return
+
+        feed(True)                                          # the initial fill: nothing to protect yet
+        g = m.num_frames()
+        while any(i is not None for i in slot_idx) or refilling is not None or (pending and free):
+            if not any(i is not None for i in slot_idx):
+                feed(True)                                  # only prompts left: finish them at full speed
+                continue
+            active = [s_ for s_ in range(B) if slot_idx[s_] is not None]
+            n = min(poll, min(max_generation_len - len(slot_frames[s_]) for s_ in active))
+            n = max(n, 1)
+            for _ in range(n):
+                m.step(B, temperature, topk)
+                feed(False)
+            fr, eos = m.read_frames(B, g, n)
+            done = []
+            for s_ in [s_ for s_ in range(B) if slot_idx[s_] is not None]:      # (a slot may have joined during this block)
+                lo = max(start_g[s_] - g, 0)                # rows of this block that belong to the slot's current utterance
+                if lo >= n:
+                    continue                                # (it joined after this block's last step)
+                rows, e = fr[lo:, s_], int(eos[s_])
+                ended = e >= start_g[s_]
+                if ended:
+                    rows = rows[: max(e - (g + lo), 0)]
+                slot_frames[s_].extend(rows.unbind(0))
+                if ended or len(slot_frames[s_]) >= max_generation_len:
+                    done.append(s_)
+            g += n
+            for s_ in done:
+                fs = slot_frames[s_][:max_generation_len]
+                yield slot_idx[s_], (torch.stack(fs).to(torch.int32) if fs else torch.empty(0, 32, dtype=torch.int32))
+                slot_idx[s_], slot_frames[s_] = None, []
+                free.append(s_)
+            if free and (pending or any(i is not None for i in slot_idx)):
+                m.reset_slots(list(free))                   # retired slots keep stepping as placeholders: keep their positions away from max_seq
 
     def generate_codes_continuous(self, prompts: Sequence[Tuple[torch.Tensor, torch.Tensor]], max_generation_len: int,
                                   temperature: float, topk: int, poll: Optional[int] = None) -> List[torch.Tensor]:

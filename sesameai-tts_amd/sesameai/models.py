@@ -434,6 +434,36 @@ class Model:
                                        out.data_ptr(), _stream_ptr()), self._h)
         return out
 
+    def refill_begin(self, slot: int, tokens: torch.Tensor, tokens_mask: torch.Tensor) -> None:
+        """Starts a refill BESIDE the frame loop (csm_refill_begin): the prompt (S,33) is embedded and the slot parked; its layers run
+        a few at a time through ``refill_advance`` between frame steps, so the other slots never wait for a whole prompt.  One
+        refill at a time per model."""
+        self._require()
+        s = tokens.shape[0]
+        if s >= self.bb.max_seq_len or s > max(self._max_prefill_rows, 2 * self._max_batch):
+            raise ValueError(f"prompt of {s} rows exceeds the limits (max_seq_len {self.bb.max_seq_len}, max_prefill_rows {self._max_prefill_rows})")
+        self._kv_prompt = None
+        t = tokens.to(device=self.device, dtype=torch.int32).contiguous()
+        m = tokens_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        p = torch.arange(s, device=self.device, dtype=torch.int32)
+        self._refill_keep = (t, m, p)                             # the position array is read by every advance call
+        with self._on_device():
+            check(lib.csm_refill_begin(self._h, int(slot), t.data_ptr(), m.data_ptr(), p.data_ptr(), s, _stream_ptr()), self._h)
+
+    def refill_advance(self, max_layers: int) -> bool:
+        """Up to ``max_layers`` more backbone layers of the pending refill.  True when the prompt is complete: the NEXT frame step
+        yields the new utterance's frame 0 in the slot's row (csm_refill_advance)."""
+        with self._on_device():
+            rc = lib.csm_refill_advance(self._h, int(max_layers), _stream_ptr())
+        if rc < 0:
+            check(rc, self._h)
+        if rc == 1:
+            self._refill_keep = None
+        return rc == 1
+
+    def supports_refill_beside_the_loop(self) -> bool:
+        return self._max_batch >= 3
+
     def depth(self, batch: int, temperature: float, topk: int, *, forced: Optional[torch.Tensor] = None,
               noise: Optional[torch.Tensor] = None, want_logits: bool = False, commit: bool = True):
         """c0 head + 31 decoder steps on the current backbone state -> (B,32) int32 [, logits]."""

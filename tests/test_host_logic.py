@@ -445,6 +445,97 @@ def test_continuous_batching_retires_at_eos_and_refills_the_slot():
         gen.generate_codes_continuous([(torch.zeros(2030, 33, dtype=torch.long), torch.zeros(2030, 33, dtype=torch.bool))], 25, 0.9, 50)
 
 
+class _ScriptedSlotsBeside:
+    """Stands in for sesameai.models.Model under Generator._iter_codes_refilling_beside_the_loop (the contract of csm_refill_begin /
+    csm_refill_advance / k_advance's fresh flag, include/csm_hip.h): a prompt needs 16 layers of refill work, handed out a few per call
+    between frame steps; until it is complete the slot emits placeholder frames (all 7); the step after completion emits the
+    utterance's frame 0 and restarts the slot's EOS word; a retired slot emits placeholders too."""
+
+    class _BB:
+        num_layers = 16
+
+    def __init__(self, scripts, max_batch):
+        self.scripts, self.device, self._max_batch, self.bb = scripts, torch.device("cpu"), max_batch, self._BB()
+        self.advance_calls, self.calls_between_steps, self.resets = [], [], []
+
+    def setup_caches(self, b): pass
+    def supports_refill_beside_the_loop(self): return True
+
+    def reset_caches(self):
+        self.hist, self.cur, self.eos, self.pending, self._since_step = [], {}, {}, None, []
+
+    def num_frames(self): return len(self.hist)
+
+    def refill_begin(self, slot, tokens, mask):
+        assert self.pending is None, "one refill at a time"
+        self.pending = [slot, int(tokens[0, 32]), 16]
+        self.cur[slot] = None                                    # parked
+
+    def refill_advance(self, k):
+        self.advance_calls.append(k); self._since_step.append(k)
+        self.pending[2] -= k
+        if self.pending[2] > 0:
+            return False
+        slot, pid, _ = self.pending
+        self.cur[slot], self.pending = [pid, 0, True], None       # fresh: the next step emits frame 0
+        return True
+
+    def reset_slots(self, slots): self.resets.append(list(slots))
+
+    def step(self, B, T, k, use_graph=True):
+        self.calls_between_steps.append(self._since_step); self._since_step = []
+        row = {}
+        for s_ in range(B):
+            c = self.cur.get(s_)
+            if c is None:
+                row[s_] = torch.full((32,), 7, dtype=torch.int32)
+                continue
+            pid, i, fresh = c
+            sc = self.scripts[pid]
+            f = sc[i].to(torch.int32) if i < sc.shape[0] else torch.zeros(32, dtype=torch.int32)
+            if fresh:
+                self.eos[s_] = -1
+            if self.eos.get(s_, -1) < 0 and bool((f == 0).all()):
+                self.eos[s_] = len(self.hist)
+            c[1], c[2] = i + 1, False
+            row[s_] = f
+        self.hist.append(row)
+
+    def read_frames(self, B, first=0, n=None):
+        fr = torch.stack([torch.stack([self.hist[g][s_] for s_ in range(B)]) for g in range(first, first + n)])
+        return fr, torch.tensor([self.eos.get(s_, -1) for s_ in range(B)], dtype=torch.int32)
+
+
+def test_continuous_batching_refills_beside_the_loop_a_few_layers_per_step():
+    """Round 4: a retired slot's prompt runs a few backbone layers after each frame step instead of stalling the batch (csm_refill_*).
+    9 utterances (EOS after 0..40 frames, one cut by the length limit) through 3 slots: every one comes back complete and cut at
+    ITS EOS; while anybody generates, at most ONE bounded refill call sits between two frame steps (the initial fill and the
+    all-idle case run whole prompts); placeholder frames of parked / retired slots never leak into a result."""
+    from sesameai.generator import Generator
+    g = torch.Generator().manual_seed(9)
+    lens = [3, 17, 0, 5, 40, 11, 8, 1, 22]
+    scripts = []
+    for n in lens:
+        sc = torch.randint(8, 2048, (n + 1, 32), generator=g); sc[n] = 0
+        scripts.append(sc)
+    model = _ScriptedSlotsBeside(scripts, 3)
+    gen = Generator(model, audio_tokenizer=_FakeCodec(), max_batch_size=3)
+    gen.refill_row_layers = 20                                        # 5-row prompts: 4 layers per call -> 4 calls per prompt
+    prompts = []
+    for i in range(len(lens)):
+        t = torch.zeros(5, 33, dtype=torch.long); t[:, 32] = i
+        prompts.append((t, torch.zeros(5, 33, dtype=torch.bool)))
+    out = gen.generate_codes_continuous(prompts, 25, 0.9, 50)
+    for i, n in enumerate(lens):
+        want = scripts[i][: min(n, 25)].to(torch.int32)
+        assert out[i].shape == want.shape and torch.equal(out[i], want), f"utterance {i} (length {n})"
+        assert not bool((out[i] == 7).all(dim=-1).any()), "a placeholder frame leaked into a result"
+    for calls in model.calls_between_steps[1:]:                       # refill calls between two frame steps: ONE bounded piece while anybody generates,
+        assert sum(k < 16 for k in calls) <= 1, calls                   # (whole prompts, 16 layers per call, only once nobody does)
+    assert 4 in model.advance_calls and 16 in model.advance_calls      # bounded pieces beside the loop, whole prompts in the initial fill
+    assert model.resets, "retired slots must be rewound while they wait"
+
+
 def test_continuous_batching_hands_out_each_utterance_as_it_finishes_and_runs_past_the_history_size():
     """results used to be returned only at the end and the total number of frame steps was capped by the engine's
     linear frame history.  ``iter_codes_continuous`` yields (index, frames) when an utterance retires -- the short ones long
