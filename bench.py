@@ -308,6 +308,7 @@ def reference_loop_leg(args, margs, sd, dev, n_frames=60):
     m.setup_caches(1); m.seed(5)
     zeros_tok, zeros_msk = torch.zeros(1, 1, dtype=torch.long, device=dev), torch.zeros(1, 1, dtype=torch.bool, device=dev)
     host = {"generate_frame": 0.0, "eos_check": 0.0, "caller_ops": 0.0}
+    iter_s = []                                        # wall time of every loop iteration of the accounted run (the caller's frame-to-frame time)
 
     def loop(n, account=False):
         m.reset_caches()
@@ -326,21 +327,22 @@ def reference_loop_leg(args, margs, sd, dev, n_frames=60):
             curr_mask = torch.cat([torch.ones_like(sample).bool(), zeros_msk], dim=1).unsqueeze(1)
             curr_pos = curr_pos[:, -1:] + 1
             t3 = time.perf_counter()
-            if account and i > 0:
-                host["generate_frame"] += t1 - t0; host["eos_check"] += t2 - t1; host["caller_ops"] += t3 - t2
+            if account:
+                iter_s.append(t3 - t0)
+                if i > 0:
+                    host["generate_frame"] += t1 - t0; host["eos_check"] += t2 - t1; host["caller_ops"] += t3 - t2
         return len(samples)
     loop(6)                                            # captures the graph
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = loop(n_frames, account=True)
     torch.cuda.synchronize(); wall = time.perf_counter() - t0
-    # frame 0 is the prompt (prefill + depth): time the S = 1 frames alone as well
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    loop(1)
-    torch.cuda.synchronize(); first = time.perf_counter() - t0
     del m
-    per = (wall - first) * 1e3 / max(n - 1, 1)
+    # frame 0 is the prompt (prefill + depth); the frames after it are what the loop costs per 80 ms of audio: mean wall time of the
+    # loop's iterations 1.. (each ends when the caller has built the next row; the sync in the EOS check makes that the frame-to-frame time)
+    per = sum(iter_s[1:]) * 1e3 / max(len(iter_s) - 1, 1)
     return {"workload": f"reference-style host loop (tts_service.py:224-241): generate_frame per frame, host EOS check each frame, B=1, S={S} prompt, {n} frames",
-            "frames": n, "ms_per_frame_after_the_prompt": round(per, 4), "prompt_frame_ms": round(first * 1e3, 2), "rtf": round(80.0 / per, 2),
+            "frames": n, "ms_per_frame_after_the_prompt": round(per, 4), "prompt_frame_ms": round(iter_s[0] * 1e3, 2), "whole_loop_wall_ms": round(wall * 1e3, 2),
+            "rtf": round(80.0 / per, 2),
             "host_us_per_frame": {k: round(v * 1e6 / max(n - 1, 1), 1) for k, v in host.items()},
             "note": "eos_check = the host waiting for the frame (torch.all(sample == 0) synchronises); generate_frame = one ctypes call: stage kernel + graph launch + copy-out"}
 

@@ -1261,9 +1261,9 @@ def test_csm1b_prompt_to_pcm_composed_vs_oracle(csm1b):
     (bit-exact for codebook indices under greedy)" -- the COMPOSED path, end to end.  BASELINE config 2's prompt given as the
     reference gives it (a voice-prompt Segment + the text to speak) -> Generator.generate (prompt assembly, prefill, hipGraph frame
     loop, Mimi decode on the GPU), greedy, 10 frames, against csm_ref (frames, reference loop generator.py:283-294) + mimi_ref
-    (PCM, generator.py:299) run live on this host.  Codes: identical up to the oracle's first near-tie frame (a frame that differs
-    must part at a codebook where the oracle's margin is inside NEAR_TIE x gap).  PCM: Mimi is strictly causal, so the samples of
-    the frames before the first difference must agree: |HIP - oracle| <= 2e-5 x the oracle clip's peak."""
+    (PCM, generator.py:299) run live on this host.  Codes: the frame in which the two trajectories part must part at a codebook where the
+    oracle's margin is inside NEAR_TIE x gap.  PCM (tolerance 2e-5 x the clip's peak): generate()'s samples are mimi_ref's decode of the codes
+    the frame loop produced, and -- Mimi being strictly causal -- the samples of the frames identical to the oracle's are the oracle pipeline's."""
     from oracle import csm_ref as C, mimi_ref as M
     from sesameai.generator import Generator, Segment
     from sesameai.mimi import MimiArgs, MimiCodec, synthetic_state_dict as mimi_sd
@@ -1300,18 +1300,22 @@ def test_csm1b_prompt_to_pcm_composed_vs_oracle(csm1b):
         pos = pos[:, -1:] + 1
     ref = torch.stack(ref)
     n_same = int((ref == frames).all(dim=1).float().cumprod(0).sum())
-    first_tie = next((f for f in range(n_frames) if bool((margins[f] <= NEAR_TIE * noise).any())), n_frames)
-    assert n_same >= min(first_tie, n_frames), f"codes part at frame {n_same}, before the oracle's first near-tie (frame {first_tie})"
+    # With seeded random weights the logits are nearly uniform: 23 % of the oracle's rows have a top-1 / top-2 margin inside 0.5 x gap (2-4 bf16
+    # ulps of a logit), so a free-running frame stays identical with probability ~0.3 and the trajectories part within a frame or two -- at a
+    # near-tie, which is what is asserted: the frame in which the codes part must part at a row whose oracle margin is inside NEAR_TIE x gap.
     if n_same < n_frames:
         _same_until_a_near_tie(frames[n_same], ref[n_same], margins[n_same], noise, f"composed run, frame {n_same}")
-    assert n_same >= 1
     ms, mw = M.mimi_full(), M.make_weights(M.mimi_full(), seed=4321)
-    want = M.decode(ms, mw, ref.t().unsqueeze(0).long())[0, 0]             # (n_frames * 1920,)
-    peak = float(want.abs().max())
-    err = float((pcm[: n_same * 1920] - want[: n_same * 1920]).abs().max())
-    print(f"composed prompt -> PCM: {n_same} of {n_frames} frames identical to the live oracle (its first near-tie: frame {first_tie}); "
-          f"PCM of those frames: max|d| = {err:.3e} = {err / peak:.2e} of peak {peak:.3f}")
-    assert err <= 2e-5 * peak
+    # PCM, composed: what generate() returned must be mimi_ref's decode of the codes the frame loop produced (all 10 frames) ...
+    want_own = M.decode(ms, mw, frames.t().unsqueeze(0).long())[0, 0]
+    peak = float(want_own.abs().max())
+    err_own = float((pcm - want_own).abs().max())
+    # ... and, Mimi being strictly causal, the samples of the frames that are identical to the oracle's are the reference pipeline's samples
+    want = M.decode(ms, mw, ref.t().unsqueeze(0).long())[0, 0]             # csm_ref codes -> mimi_ref PCM: the reference -d cpu path's output
+    err_ref = float((pcm[: n_same * 1920] - want[: n_same * 1920]).abs().max()) if n_same else 0.0
+    print(f"composed prompt -> PCM: {n_same} of {n_frames} frames identical to the live oracle before the first near-tie parts them; "
+          f"PCM vs mimi_ref on the same codes: max|d| = {err_own:.3e} = {err_own / peak:.2e} of peak {peak:.3f}; vs the oracle pipeline over the identical frames: {err_ref:.3e}")
+    assert err_own <= 2e-5 * peak and err_ref <= 2e-5 * peak
 
 
 @pytest.mark.parametrize("B", [1, 8])
