@@ -1,20 +1,36 @@
-# Round-end evidence run on the GPU box: full GPU suite, default bench line, rocprofv3 kernel stats of the bench (B = 1 and B = 32), PMC
-# traffic passes (FETCH_SIZE) for both, batch sweep (batched persistent decoder on / off), timelines of the persistent launches.
-# Summaries land in gpurun_out/$1 (default r03a); copy what is to be judged to profiles/.
+# Round-end evidence run on the GPU box (round 4): full GPU suite with the parity prints, default bench line, rocprofv3 kernel stats of the bench
+# at B = 1 / B = 32 / B = 1 with the fp8 weight stream, PMC traffic passes (FETCH_SIZE) for the three, kernel stats of the S = 190 and S = 1334
+# prefills, batch sweep, timelines of the persistent launches, soaks.  Summaries land in gpurun_out/$1 (default r04a); copy what is to be
+# judged to profiles/.     gpurun --timeout 2400 -- 'bash tools/run_round_profiles.sh r04a'
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/${1:-r03a}; mkdir -p $O
-timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/gpu_tests.txt
+O=gpurun_out/${1:-r04a}; mkdir -p $O
+timeout 1800 python -m pytest tests -m gpu -q -s > $O/gpu_tests_full.txt 2>&1
+tail -4 $O/gpu_tests_full.txt > $O/gpu_tests.txt
+grep -E "dlogit|excused|identical|\[parity\]|composed" $O/gpu_tests_full.txt | cut -c1-400 > $O/parity_margins.txt
 timeout 900 python bench.py > $O/final_bench.json 2> $O/bench_default.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 2 > $O/final_bench_under_rocprof.json 2>$O/rocprof_stats.err
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc -- python3 bench.py --no-cpu-baseline --no-extras --no-mimi --steps 20 --warmup 2 > $O/bench_under_pmc.json 2>$O/rocprof_pmc.err
-python tools/pmc_summary.py stats $O/stats $O/final_kernel_stats.csv > /dev/null
-python tools/pmc_summary.py traffic $O/pmc $O/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --no-mimi --steps 20 --warmup 2 (round 3)" > /dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s32 -- python3 bench.py --batch 32 --no-cpu-baseline --no-extras --no-mimi --steps 20 --warmup 2 > $O/b32_bench_under_rocprof.json 2> $O/b32_err.txt
-python tools/pmc_summary.py stats $O/s32 $O/b32_kernel_stats.csv > /dev/null
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc32 -- python3 bench.py --batch 32 --no-cpu-baseline --no-extras --no-mimi --steps 20 --warmup 2 > $O/b32_bench_under_pmc.json 2>$O/b32_pmc.err
-python tools/pmc_summary.py traffic $O/pmc32 $O/b32_pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --batch 32 --no-cpu-baseline --no-extras --no-mimi --steps 20 --warmup 2 (round 3, config 3)" > /dev/null
-rm -rf $O/pmc $O/stats $O/s32 $O/pmc32
-tools/sweep_batch.sh "1 2 3 4 8 16 24 32 64" > $O/batch_sweep.txt 2>&1
+prof() {   # prof <name> <bench args...>: kernel stats + FETCH_SIZE pass of one bench configuration
+    local name=$1; shift
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_$name -- python3 bench.py --no-cpu-baseline --no-extras --no-mimi --steps 20 --warmup 2 "$@" > $O/${name}_bench_under_rocprof.json 2> $O/${name}_rocprof.err
+    python tools/pmc_summary.py stats $O/st_$name $O/${name}_kernel_stats.csv > /dev/null
+    timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_$name -- python3 bench.py --no-cpu-baseline --no-extras --no-mimi --steps 20 --warmup 2 "$@" > $O/${name}_bench_under_pmc.json 2> $O/${name}_pmc.err
+    python tools/pmc_summary.py traffic $O/pmc_$name $O/${name}_pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --no-mimi --steps 20 --warmup 2 $* (round 4)" > /dev/null
+    rm -rf $O/st_$name $O/pmc_$name
+}
+prof final
+prof b32 --batch 32
+prof fp8 --weights fp8
+cp $O/final_pmc_traffic.json $O/pmc_traffic.json
+for S in 190 1334; do
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pf_$S -- python3 tools/prefill_prof.py $S 10 > $O/prefill_S$S.txt 2>&1
+    python tools/pmc_summary.py stats $O/pf_$S $O/prefill_S${S}_kernel_stats.csv > /dev/null
+    timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pfm_$S -- python3 tools/prefill_prof.py $S 4 > /dev/null 2>&1
+    python tools/pmc_summary.py mfma $O/pfm_$S $O/pmc_mfma_util_S$S.json "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/prefill_prof.py $S 4 (round 4)" > /dev/null
+    rm -rf $O/pf_$S $O/pfm_$S
+done
+tools/sweep_batch.sh "1 2 4 8 16 32" > $O/batch_sweep.txt 2>&1
 timeout 300 python tools/persist_timeline.py > $O/persist_timeline.txt 2>&1
-for b in 32 16 4; do timeout 300 python tools/persist_m_timeline.py $b 2>&1 | grep -v amdgpu.ids > $O/persist_m_timeline_b$b.txt; done
-cat $O/gpu_tests.txt; cut -c1-600 $O/final_bench.json; cat $O/pmc_traffic.json | head -20; head -6 $O/final_kernel_stats.csv | cut -c1-160; head -8 $O/b32_kernel_stats.csv | cut -c1-160; cat $O/batch_sweep.txt
+timeout 300 python tools/persist_m_timeline.py 32 2>&1 | grep -v amdgpu.ids > $O/persist_m_timeline_b32.txt
+timeout 600 python tools/soak_attn_merge.py 1000 2 32,8 > $O/soak_attn_merge.txt 2>&1
+timeout 600 python tools/soak_persist_m.py 200 2 2,17,32 > $O/soak_persist_m.txt 2>&1
+timeout 300 python tools/dbg/ref_loop_breakdown.py 60 2>&1 | grep -v amdgpu.ids > $O/ref_loop_breakdown.txt
+cat $O/gpu_tests.txt; python tools/dbg/bench_summary.py $O/final_bench.json; cat $O/pmc_traffic.json | head -12; head -5 $O/final_kernel_stats.csv | cut -c1-160; head -6 $O/b32_kernel_stats.csv | cut -c1-160; cat $O/batch_sweep.txt; tail -2 $O/soak_attn_merge.txt
