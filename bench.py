@@ -226,7 +226,7 @@ def timed_steps(model, B, n, temperature, topk, use_graph=True):
     return e0.elapsed_time(e1) / n
 
 
-def batch32_leg(args, margs, sd, dev, n_steps, seed0=4000, barrier=None):
+def batch32_leg(args, margs, sd, dev, n_steps, seed0=4000, barrier=None, with_refill=True):
     """BASELINE config 3 (and, per rank, config 4): B = 32 x the config-2 prompt, hipGraph-captured frame step.  Returns
     (result dict, wall seconds of the timed steps)."""
     from sesameai.models import Model
@@ -252,7 +252,7 @@ def batch32_leg(args, margs, sd, dev, n_steps, seed0=4000, barrier=None):
     by = m3.bytes_per_frame(B3, S + 5 + n_steps / 2.0)
     # ---- a slot refilled while the other 31 keep generating (reference: one prefill per sentence, tts_service.py:191-207) ----
     refill = None
-    if os.environ.get("BENCH_SKIP_REFILL") != "1":
+    if with_refill and os.environ.get("BENCH_SKIP_REFILL") != "1":
         st = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         # (a) csm_prefill_slot: the whole prompt + a batch-1 depth pass between two frame steps -- everybody waits
@@ -678,7 +678,7 @@ def main():
         # ---- BASELINE config 4: B = 32 per GPU on every rank (batch 32 x N sharded over the N GPUs, no per-step collective);
         #      aggregate = all ranks' frames / the slowest rank's time, like `value`
         del model
-        res, wall4 = batch32_leg(args, margs, sd, dev, args.extra_steps, seed0=4000 + 32 * rank, barrier=sync_all)
+        res, wall4 = batch32_leg(args, margs, sd, dev, args.extra_steps, seed0=4000 + 32 * rank, barrier=sync_all, with_refill=False)
         t4 = torch.tensor([wall4], device=dev, dtype=torch.float64)
         dist.all_reduce(t4, op=dist.ReduceOp.MAX)
         res["workload"] = f"CSM-1B batch {32 * world} sharded over {world} GPUs (B=32 per GPU), S=190 prompt rows each, hipGraph frame step, {args.extra_steps} timed steps"
