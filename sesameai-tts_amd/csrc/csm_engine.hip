@@ -719,6 +719,10 @@ static hipError_t launch_embed(CsmModel* m, const int* tokens, const uint8_t* ma
     return hipGetLastError();
 }
 
+__global__ void k_fill_u128(uint4* p, uint4 v, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
 // codebooks 2..ncb-1 of a frame as ONE persistent launch: batch 1 (dec_persist.cuh) or 2..32 utterances (dec_persist_m.cuh).  The chain's
 // cb = 1 step left the step's input rows, their layer-0 q / k / v and the decoder caches of positions 0, 1 where the kernels pick them up.
 static bool persist_usable(const CsmModel* m, int B) {
@@ -755,7 +759,13 @@ static hipError_t launch_dec_persist(CsmModel* m, int B, float temperature, int 
     p.temperature = temperature; p.topk = topk; p.noise = (const bf16_t*)noise; p.rng = rng; p.forced = forced;
     p.V = V; p.ncb = ncb; p.M = B; p.frame = m->frame; p.logits_out = (bf16_t*)logits_out; p.cb_first = 2; p.cb_last = ncb - 1;
     p.xchg = m->pm_xchg; p.stamps = m->p_stamps; p.err = m->p_state + 1; p.eps = c.decoder.norm_eps; p.trickle_sleep = m->pm_trickle; p.poll_sleep = m->p_poll;
-    hipError_t e = hipMemsetAsync(m->pm_xchg, 0xFF, DM_XCHG_BYTES, st);      // every exchange dword starts as the poison (dec_persist_m.cuh)
+    // every exchange dword starts as the poison (dec_persist_m.cuh).  A KERNEL node, not a memset node (round 4): with hipMemsetAsync captured
+    // into the frame-step graph, a handle replaying its graph beside another handle whose graph has a different shape (tools/dbg/two_handles_diag2.py:
+    // CSM_ATTN_MERGE=0 beside =1) got garbage from codebook 2 on -- the launch saw exchange buffers that were not (yet) poisoned; eager launches,
+    // and graphs whose only non-kernel node this was removed, are deterministic.
+    static_assert(DM_XCHG_BYTES % 16 == 0, "exchange buffers are filled 16 bytes per thread");
+    hipLaunchKernelGGL(k_fill_u128, dim3(1024), dim3(256), 0, st, (uint4*)m->pm_xchg, make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu), (long)(DM_XCHG_BYTES / 16));
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (B <= 16) hipLaunchKernelGGL(k_dec_persist_m<1>, dim3(DP_NB), dim3(512), DM_LDS_BYTES, st, p);
     else hipLaunchKernelGGL(k_dec_persist_m<2>, dim3(DP_NB), dim3(512), DM_LDS_BYTES, st, p);

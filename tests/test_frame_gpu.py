@@ -895,6 +895,63 @@ def test_refill_beside_the_loop_leaves_the_other_slots_bit_identical_and_joins_i
     m.reset_caches()
 
 
+def test_csm1b_refill_beside_the_loop_at_batch_8(csm1b):
+    """The same at CSM-1B size, B = 8 (batched persistent decoder, one-launch-free batched backbone chain, 16 layers): slot 5 is refilled with a
+    60-row prompt four layers per frame step while the other seven keep generating under T = 0.9 / top-k 50 sampling -- their frames are bit
+    for bit those of an undisturbed run (same seed: a frame step's noise depends on (seed, step, row) only), and the joined utterance's frames
+    are those of the same utterance filled into slot 5 before the first step of a batch whose step counter is at the same value."""
+    import bench
+    from oracle import csm_ref as C
+    from sesameai.models import Model, csm_1b_args
+    gold, sd = csm1b
+    B = 8
+    tok, msk = bench.synthetic_prompt(_bench_args(), B + 1, C.csm_1b().text_vocab_size, seed0=8300)
+    tok, msk = tok[:, :60], msk[:, :60]
+    m = Model(csm_1b_args(), sd, max_frames=32, max_prefill_rows=B * 64)
+    m.setup_caches(B)
+    assert m.fast_paths() & 2
+
+    def fill(rows):
+        m.reset_caches(); m.seed(21)
+        for b, r in enumerate(rows):
+            m.refill_begin(b, tok[r], msk[r])
+            while not m.refill_advance(16):
+                pass
+
+    fill(range(B))
+    for _ in range(10):
+        m.step(B, 0.9, 50)
+    und, _ = m.read_frames(B)
+    fill(range(B))
+    rejoin = None
+    for k in range(10):
+        m.step(B, 0.9, 50)
+        if k == 1:
+            m.refill_begin(5, tok[B], msk[B])
+        if k >= 1 and rejoin is None and m.refill_advance(4):
+            rejoin = m.num_frames()
+    dis, _ = m.read_frames(B)                                            # raises if a launch gave up
+    assert rejoin == 5
+    for b in range(B):
+        if b != 5:
+            assert torch.equal(dis[:, b], und[:, b]), f"the refill disturbed slot {b}"
+    assert torch.equal(dis[:2, 5], und[:2, 5]) and int(dis.min()) >= 0 and int(dis.max()) < 2051
+    # the greedy part of the claim (independent of the noise stream): the joined utterance's frame 0 is the batch's frame 0 of that prompt
+    fill([0, 1, 2, 3, 4, B, 6, 7])
+    m.step(B, 1.0, 1)
+    ref0, _ = m.read_frames(B)
+    fill(range(B))
+    for k in range(2):
+        m.step(B, 1.0, 1)
+    m.refill_begin(5, tok[B], msk[B])
+    while not m.refill_advance(5):
+        pass
+    m.step(B, 1.0, 1)
+    got, _ = m.read_frames(B)
+    assert torch.equal(got[2, 5], ref0[0, 5]), "frame 0 of the joined utterance differs from the same prompt's frame 0 at the start of a batch"
+    m.reset_caches()
+
+
 def test_continuous_batching_beside_the_loop_through_the_generator(tiny):
     """Generator.generate_codes_continuous with max_batch 4 takes the non-stalling path: 7 prompts of different lengths, 6 frames each,
     greedy -- every utterance equals the one the same prompt produces when it is filled into slot 0 of the same 4-slot batch alone."""
@@ -1537,6 +1594,42 @@ def test_split_key_attention_merged_in_kernel_gives_the_merge_launch_bits(csm1b,
         del m
     assert torch.equal(outs["1"][0], outs["0"][0])
     assert torch.equal(outs["1"][1], outs["0"][1])
+
+
+def test_two_handles_with_frame_graphs_of_different_shapes_do_not_disturb_each_other(csm1b, monkeypatch):
+    """Round 4 regression (found by tools/soak_attn_merge.py): with the batched persistent decoder's exchange buffers poisoned by a MEMSET node
+    of the captured frame step, a handle replaying its graph beside a second handle whose graph has another shape (here: split-key attention
+    merged by a second launch vs in the kernel) produced garbage from codebook 2 on -- its launch ran on exchange buffers that were not poisoned
+    yet; eager launches were fine.  The poison is written by a kernel node now.  Two B = 32 handles, run alternately three times with the same
+    seed: every run of a handle equals its first, and the two handles (same arithmetic, same order) equal each other."""
+    import bench
+    from oracle import csm_ref as C
+    from sesameai.models import Model, csm_1b_args
+    gold, sd = csm1b
+    B = 32
+    tok, msk = bench.synthetic_prompt(_bench_args(), B, C.csm_1b().text_vocab_size, seed0=9100 + B)
+    tok, msk = tok[:, :100], msk[:, :100]
+    S = tok.shape[1]
+    handles = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("CSM_ATTN_MERGE", env)
+        m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S)
+        m.setup_caches(B)
+        assert m.fast_paths() & 2
+        handles.append(m)
+
+    def run(m):
+        m.reset_caches(); m.seed(778)
+        m.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+        m.depth(B, 0.9, 50, commit=True)
+        for _ in range(6):
+            m.step(B, 0.9, 50)
+        return m.read_frames(B)[0]
+
+    out = [[run(m) for m in handles] for _ in range(3)]
+    for rep in range(3):
+        assert torch.equal(out[rep][0], out[0][0]) and torch.equal(out[rep][1], out[0][1]), f"run {rep} of a handle differs from its first run"
+        assert torch.equal(out[rep][0], out[rep][1]), "the two handles differ"
 
 
 _FAULT_SCRIPT = r"""
