@@ -216,28 +216,33 @@ class Generator:
         return torch.cat(blocks) if blocks else torch.empty(0, B, 32, dtype=torch.int32)
 
     @torch.inference_mode()
-    def iter_codes_continuous(self, prompts: Sequence[Tuple[torch.Tensor, torch.Tensor]], max_generation_len: int,
+    def iter_codes_continuous(self, prompts: Sequence[Tuple[torch.Tensor, torch.Tensor]], max_generation_len: Union[int, Sequence[int]],
                               temperature: float, topk: int, poll: Optional[int] = None
                               ) -> PyGenerator[Tuple[int, torch.Tensor], None, None]:
         """Any number of prompts [(tokens (S_i,33), mask (S_i,33)), ...] of any lengths through a batch of ``max_batch_size``
         slots that is kept FULL: an utterance that reaches its all-zero EOS frame (generator.py:285) or the length limit is
         retired and its slot re-prefilled with the next prompt (Model.refill_slot) while the other slots keep generating --
         their frames are bit-identical to an undisturbed run.  Yields ``(index of the prompt, frames [n_i][32] int32 CPU)`` as
-        each utterance FINISHES (cut at its EOS like the reference's batch-1 loop), so a long run hands its results out as it
+        each utterance FINISHES (cut at its EOS like the reference's batch-1 loop, or at ``max_generation_len`` -- one limit for
+        all prompts or one per prompt), so a long run hands its results out as it
         goes.  There is no limit on the total number of frame steps: the engine's frame history is a ring (include/csm_hip.h,
         csm_read_frames) and every block of ``poll`` steps is read before the next one is launched."""
         from collections import deque
         m = self._model
-        for t, _ in prompts:
-            if t.shape[0] >= MAX_SEQ_LEN - max_generation_len:
-                raise ValueError(f"Inputs too long, must be below max_seq_len - max_generation_len: {MAX_SEQ_LEN - max_generation_len}")
+        # one length limit for all, or one per prompt (a request's own max_audio_length_ms)
+        limits = [int(max_generation_len)] * len(prompts) if isinstance(max_generation_len, (int, float)) else [int(x) for x in max_generation_len]
+        if len(limits) != len(prompts):
+            raise ValueError("max_generation_len: one value, or one per prompt")
+        for (t, _), lim in zip(prompts, limits):
+            if t.shape[0] >= MAX_SEQ_LEN - lim:
+                raise ValueError(f"Inputs too long, must be below max_seq_len - max_generation_len: {MAX_SEQ_LEN - lim}")
         if not prompts:
             return
         poll = poll or self._eos_poll
         B = min(self._max_batch, len(prompts))
         beside = getattr(m, "supports_refill_beside_the_loop", None)
-        if B >= 3 and max_generation_len > 0 and beside is not None and beside() and getattr(self, "refill_beside_the_loop", True):
-            yield from self._iter_codes_refilling_beside_the_loop(prompts, max_generation_len, temperature, topk, poll, B)
+        if B >= 3 and beside is not None and beside() and getattr(self, "refill_beside_the_loop", True):
+            yield from self._iter_codes_refilling_beside_the_loop(prompts, limits, temperature, topk, poll, B)
             return
         pending = deque(range(len(prompts)))
         slot_idx: List[Optional[int]] = [None] * B
@@ -251,7 +256,7 @@ class Generator:
                 i = pending.popleft()
                 t, mk = prompts[i]
                 f0 = m.refill_slot(slot, t, mk, temperature, topk).cpu()
-                if max_generation_len <= 0 or bool((f0 == 0).all()):
+                if limits[i] <= 0 or bool((f0 == 0).all()):
                     finished.append((i, empty))                         # EOS in the very first frame: empty utterance (generator.py:296)
                     continue
                 slot_idx[slot], slot_frames[slot] = i, [f0]
@@ -266,9 +271,9 @@ class Generator:
         g = m.num_frames()                                              # next global frame index
         while any(i is not None for i in slot_idx):
             active = [s_ for s_ in range(B) if slot_idx[s_] is not None]
-            done = [s_ for s_ in active if len(slot_frames[s_]) >= max_generation_len]
+            done = [s_ for s_ in active if len(slot_frames[s_]) >= limits[slot_idx[s_]]]
             if not done:
-                n = min(poll, min(max_generation_len - len(slot_frames[s_]) for s_ in active))
+                n = min(poll, min(limits[slot_idx[s_]] - len(slot_frames[s_]) for s_ in active))
                 for _ in range(n):
                     m.step(B, temperature, topk)
                 fr, eos = m.read_frames(B, g, n)
@@ -278,12 +283,12 @@ class Generator:
                         rows = rows[: max(int(eos[s_]) - g, 0)]
                         done.append(s_)
                     slot_frames[s_].extend(rows.unbind(0))
-                    if len(slot_frames[s_]) >= max_generation_len and s_ not in done:
+                    if len(slot_frames[s_]) >= limits[slot_idx[s_]] and s_ not in done:
                         done.append(s_)
                 g += n
             idle = []
             for s_ in done:
-                finished.append((slot_idx[s_], torch.stack(slot_frames[s_][:max_generation_len]).to(torch.int32)))
+                finished.append((slot_idx[s_], torch.stack(slot_frames[s_][:limits[slot_idx[s_]]]).to(torch.int32)))
                 if not start(s_):
                     idle.append(s_)
             if idle and any(i is not None for i in slot_idx):
@@ -291,7 +296,7 @@ class Generator:
             yield from finished
             finished.clear()
 
-    def _iter_codes_refilling_beside_the_loop(self, prompts, max_generation_len: int, temperature: float, topk: int, poll: int, B: int):
+    def _iter_codes_refilling_beside_the_loop(self, prompts, limits: List[int], temperature: float, topk: int, poll: int, B: int):
         """The continuously refilled batch WITHOUT stalls (round 4): a retired slot's next prompt runs a few backbone layers after
         each frame step (Model.refill_begin / refill_advance: about ``refill_row_layers`` = 600 prompt-row x layer units per step, i.e.
         3 layers of a 190-row prompt = +8 % of a B = 32 step; measured: bench.py extras.config3.refill_beside_the_loop) while the other slots keep generating, and the new utterance's frame
@@ -306,7 +311,7 @@ class Generator:
         slot_idx: List[Optional[int]] = [None] * B          # prompt index generating in the slot
         start_g: List[int] = [0] * B                        # global frame index of its frame 0
         slot_frames: List[List[torch.Tensor]] = [[] for _ in range(B)]
-        refilling: Optional[Tuple[int, int, int]] = None    # (slot, prompt index, layers per call)
+        refilling: Optional[Tuple[int, int, int]] = None    # (slot, prompt index, prompt rows)
         m.reset_caches()
 
         def feed(everything: bool) -> None:
@@ -319,9 +324,12 @@ class Generator:
                     slot, i = free.popleft(), pending.popleft()
                     t, mk = prompts[i]
                     m.refill_begin(slot, t, mk)
-                    refilling = (slot, i, L if everything else max(1, budget // max(int(t.shape[0]), 1)))
-                slot, i, per_call = refilling
-                if m.refill_advance(L if everything else per_call):
+                    refilling = (slot, i, int(t.shape[0]))
+                slot, i, rows = refilling
+                # the per-step budget grows with the backlog: every slot that waits for a prompt is 1/B of the batch's throughput idle, and
+                # the refill work is the same whenever it is done -- with nobody waiting the steps stay within ~8 % of an undisturbed one
+                per_call = max(1, budget * (1 + len(free)) // max(rows, 1))
+                if m.refill_advance(L if everything else min(per_call, L)):
                     slot_idx[slot], start_g[slot], slot_frames[slot] = i, m.num_frames(), []
                     refilling = None
                 if not everything:
@@ -334,8 +342,7 @@ class Generator:
                 feed(True)                                  # only prompts left: finish them at full speed
                 continue
             active = [s_ for s_ in range(B) if slot_idx[s_] is not None]
-            n = min(poll, min(max_generation_len - len(slot_frames[s_]) for s_ in active))
-            n = max(n, 1)
+            n = max(min(poll, min(limits[slot_idx[s_]] - len(slot_frames[s_]) for s_ in active)), 1)
             for _ in range(n):
                 m.step(B, temperature, topk)
                 feed(False)
@@ -350,11 +357,11 @@ class Generator:
                 if ended:
                     rows = rows[: max(e - (g + lo), 0)]
                 slot_frames[s_].extend(rows.unbind(0))
-                if ended or len(slot_frames[s_]) >= max_generation_len:
+                if ended or len(slot_frames[s_]) >= limits[slot_idx[s_]]:
                     done.append(s_)
             g += n
             for s_ in done:
-                fs = slot_frames[s_][:max_generation_len]
+                fs = slot_frames[s_][:max(limits[slot_idx[s_]], 0)]
                 yield slot_idx[s_], (torch.stack(fs).to(torch.int32) if fs else torch.empty(0, 32, dtype=torch.int32))
                 slot_idx[s_], slot_frames[s_] = None, []
                 free.append(s_)
@@ -369,10 +376,12 @@ class Generator:
             results[i] = frames
         return results
 
-    def generate_many(self, texts: Sequence, speakers: Sequence[int], contexts: Sequence[List[Segment]], max_audio_length_ms: float = 90_000,
+    def generate_many(self, texts: Sequence, speakers: Sequence[int], contexts: Sequence[List[Segment]], max_audio_length_ms=90_000,
                       temperature: float = 0.7, topk: int = 30) -> List[torch.Tensor]:
-        """``generate`` for a list of requests through the continuously refilled batch: one audio tensor per request."""
-        max_generation_len = int(max_audio_length_ms / FRAME_MS)
+        """``generate`` for a list of requests through the continuously refilled batch: one audio tensor per request
+        (``max_audio_length_ms``: one value, or one per request)."""
+        max_generation_len = (int(max_audio_length_ms / FRAME_MS) if isinstance(max_audio_length_ms, (int, float))
+                              else [int(x / FRAME_MS) for x in max_audio_length_ms])
         prompts = [self._build_prompt(t, sp, ctx) for t, sp, ctx in zip(texts, speakers, contexts)]
         out: List[torch.Tensor] = [torch.tensor([]) for _ in prompts]
         for i, frames in self.iter_codes_continuous(prompts, max_generation_len, temperature, topk):

@@ -525,9 +525,10 @@ def test_continuous_batching_refills_beside_the_loop_a_few_layers_per_step():
     for i in range(len(lens)):
         t = torch.zeros(5, 33, dtype=torch.long); t[:, 32] = i
         prompts.append((t, torch.zeros(5, 33, dtype=torch.bool)))
-    out = gen.generate_codes_continuous(prompts, 25, 0.9, 50)
+    limits = [25, 25, 25, 25, 25, 25, 25, 25, 10]                     # one length limit per request (the last one cuts a 22-frame utterance at 10)
+    out = gen.generate_codes_continuous(prompts, limits, 0.9, 50)
     for i, n in enumerate(lens):
-        want = scripts[i][: min(n, 25)].to(torch.int32)
+        want = scripts[i][: min(n, limits[i])].to(torch.int32)
         assert out[i].shape == want.shape and torch.equal(out[i], want), f"utterance {i} (length {n})"
         assert not bool((out[i] == 7).all(dim=-1).any()), "a placeholder frame leaked into a result"
     for calls in model.calls_between_steps[1:]:                       # refill calls between two frame steps: ONE bounded piece while anybody generates,
