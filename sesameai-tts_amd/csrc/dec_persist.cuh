@@ -35,7 +35,10 @@
 
 typedef unsigned long long dp_u64;
 #define DP_NB 256                     // workgroups = CUs of an MI355X
-#define DP_NREP 8                     // granule copies
+#ifndef DP_NREP
+#define DP_NREP 8                     // granule copies (one per XCD under round-robin placement: the 32 workgroups of an XCD poll the same lines;
+                                      //  round 4 A/B in the product: 4 copies k_dec_persist 2,144 us, 8: 2,075, 16: 2,221)
+#endif
 #define DP_TIMEOUT 5000000ull         // 50 ms of s_memrealtime (100 MHz)
 #define DP_NL 4
 #define DP_D 1024
