@@ -100,25 +100,36 @@ class TTS:
         return list(self.voices.keys())
 
     def load_voice(self, voice_name: str) -> None:
+        """reference: tts_service.py:105-119."""
         if voice_name not in self.voices:
             raise ValueError(f"Voice '{voice_name}' not found. Available voices: {list(self.voices.keys())}")
-        if not self.generator:
-            raise ValueError("Model not loaded. Call load_model() first.")
         self.cached_context_tokens, self.cached_context_masks = [], []
         self.voice_name = voice_name
         src = self.voices[voice_name]
-        if isinstance(src, dict):                                  # {wav path: transcript}: encode with Mimi on the GPU
-            self.voice_data = src
-            segments = [Segment(speaker=1, text=text, audio=load_audio(path, self.generator.sample_rate))
-                        for path, text in src.items()]
+        self.voice_data = src if isinstance(src, dict) else torch.load(src)      # {wav path: transcript} | [(text, codes[32,T]), ...]
+        self._prepare_context()
+        self.generate_audio_segment("I'm getting all warmed up for our chatting to begin.")   # warm-up, :119
+
+    def _load_audio(self, audio_path: str) -> torch.Tensor:
+        """reference: tts_service.py:141-168 (mono, resampled to the codec's rate)."""
+        return load_audio(audio_path, self.generator.sample_rate)
+
+    def _prepare_context(self) -> None:
+        """reference: tts_service.py:122-139 -- the voice prompt's segments tokenised once (WAV prompts are encoded by the GPU Mimi encoder;
+        pre-tokenised prompts carry their codes) and cached for every sentence; with them cached, Model.prefill_prompt re-runs only the rows
+        after the shared prefix."""
+        if not self.generator:
+            raise ValueError("Model not loaded. Call load_model() first.")
+        print(f"Preparing reference audio context for voice: {self.voice_name}...")
+        if isinstance(self.voice_data, dict):
+            segments = [Segment(speaker=1, text=text, audio=self._load_audio(path)) for path, text in self.voice_data.items()]
         else:
-            self.voice_data = torch.load(src)
             segments = [Segment(speaker=1, text=text, audio_codes=codes) for text, codes in self.voice_data]
-        for segment in segments:                                   # reference: _prepare_context :121-139
+        for segment in segments:
             tokens, masks = self.generator._tokenize_segment(segment)
             self.cached_context_tokens.append(tokens)
             self.cached_context_masks.append(masks)
-        self.generate_audio_segment("I'm getting all warmed up for our chatting to begin.")   # warm-up, :119
+        print("Reference audio context prepared")
 
     @torch.inference_mode()
     def generate_with_context(self, prompt, speaker: int = 1, max_audio_length_ms: float = 60_000,
@@ -157,6 +168,10 @@ class TTS:
             pcm[:n] = (pcm[:n] * ramp).astype(np.int16)
             pcm[-n:] = (pcm[-n:] * ramp[::-1]).astype(np.int16)
         return pcm
+
+    def _generate_audio_segment_wrapper(self, sentence, fade_duration, start_silence_duration, end_silence_duration, temperature=0.8, topk=40):
+        """reference: tts_service.py:310-311."""
+        return self.generate_audio_segment(sentence, fade_duration, start_silence_duration, end_silence_duration, temperature, topk)
 
     def say(self, text: str, output_filename: Optional[str] = "combined_output.wav", fallback_duration: int = 1000,
             fade_duration: int = 50, start_silence_duration: int = 500, end_silence_duration: int = 100,
