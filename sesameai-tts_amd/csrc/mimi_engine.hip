@@ -30,7 +30,7 @@ static thread_local std::string g_mimi_err;
 #define MAX_TAPS 16
 
 struct GemmArgs {
-    const float* x; long ldx;       // A row for output time t, tap j: x + (t * in_stride + shift[j]) * ldx
+    const float* x; long ldx;       // A row for output time t, tap j: x + (t * in_stride + shift0 + j * dshift) * ldx
     int in_stride;                  // 1, or the stride of a down-sampling conv
     int edge, row_lo, row_hi;       // edge 0: rows are always in range (left context stored in front of row 0);
                                     // 1: rows outside [row_lo,row_hi) read as zero; 2: clamped (replicate padding)
@@ -38,12 +38,15 @@ struct GemmArgs {
     const float* w;                 // [phases][taps][C_out][C_in]
     const float* bias;
     int taps, phases;
-    int shift[MAX_TAPS];
-    int elu_in;                     // ELU(alpha=1) applied to A on load
+    int shift0, dshift;             // tap j reads row t * in_stride + shift0 + j * dshift
     int act_out;                    // 1 = exact GELU
     const float* col_scale;         // optional per-output-channel scale (LayerScale)
     const float* resid; long ldr;   // optional residual, indexed like out
     float* out; long ldo;
+    // q|k|v projection of the transformer (round 4: was a k_rope_split launch behind every in_proj): C_out = 3 d; channels
+    // [0,d) -> rope_q[t] with RoPE, [d,2d) -> rope_k[rope_offset + t] with RoPE, [2d,3d) -> rope_v[rope_offset + t]; head_dim 64,
+    // interleaved pairs (the partner channel sits in the neighbouring lane)
+    float *rope_q, *rope_k, *rope_v; const float* rope_freqs; int rope_offset, rope_d;
 };
 
 __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expf(v) - 1.0f; }
@@ -55,9 +58,21 @@ __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expf(v) - 
 #ifndef G32_NW
 #define G32_NW 8
 #endif
+// ELU = the input activation as a compile-time choice.
+// Round 4 (tools/dbg/mimi_chunk_timeline.py, profiles/r04/mimi_chunk10_timeline.txt): at 20 transformer tokens every iteration was
+// TWO dependent memory round trips -- the tap's row shift came from an indexed array in the argument block (a vector load the
+// operand addresses waited for), then the operands -- and every MFMA sat behind a run-time "ELU?" branch.  Now the shift is
+// arithmetic (shift0 + j * dshift: every convolution here is an arithmetic progression of taps) and the iteration index is scalar.
+// Measured and NOT kept: four iterations' operands requested at once (slower: these launches are bound by the misses 16..64 CUs
+// keep in flight and by ~4.7 us of dependent-launch latency each, not by the depth of one wave's queue); the LayerNorm folded
+// into the following product (every block normalising its 32 rows itself: 12.7 us against 4.7 + 8.0 for the two launches -- equal);
+// the weights re-tiled into MFMA operand order so that every wave load is one contiguous 1 KB (the K = 2048 linear 24 us against
+// 19.5 row-major: with one 32-row tile these launches sit on 16..64 CUs and are bound by the fp32 matrix pipe -- 128 dependent
+// 64-cycle v_mfma_f32_32x32x2_f32 per wave, two waves per SIMD = 6.8 us -- plus the ~4.7 us of a dependent launch, not by loads).
+template <bool ELU>
 __global__ __launch_bounds__(64 * G32_NW) void k_gemm32(const GemmArgs a) {
     __shared__ float red[G32_NW][16][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 32, p = blockIdx.z;
     f32x16 acc;
 #pragma unroll
@@ -67,14 +82,16 @@ __global__ __launch_bounds__(64 * G32_NW) void k_gemm32(const GemmArgs a) {
     const int trow = trow_ok ? (t0 + r) : (a.T_in - 1);
     const int nrow = nrow_ok ? (n0 + r) : (a.C_out - 1);
     const int kchunks = a.C_in / 32, iters = a.taps * kchunks;
+    const int arow0 = trow * a.in_stride + a.shift0;
+    const float* const wrow = a.w + ((long)p * a.taps * a.C_out + nrow) * a.C_in + h * 16;
     for (int it = wave; it < iters; it += G32_NW) {
-        const int j = it / kchunks, kc = (it % kchunks) * 32;
-        int arow = trow * a.in_stride + a.shift[j];
-        bool aok = true;
-        if (a.edge == 1) { aok = arow >= a.row_lo && arow < a.row_hi; arow = min(max(arow, a.row_lo), a.row_hi - 1); }
+        const int j = it / kchunks, kc = (it - j * kchunks) * 32;
+        int arow = arow0 + j * a.dshift;
+        bool use = trow_ok;
+        if (a.edge == 1) { use = trow_ok && arow >= a.row_lo && arow < a.row_hi; arow = min(max(arow, a.row_lo), a.row_hi - 1); }
         else if (a.edge == 2) arow = min(max(arow, a.row_lo), a.row_hi - 1);
         const float* xa = a.x + (long)arow * a.ldx + h * 16 + kc;
-        const float* wb = a.w + (((long)p * a.taps + j) * a.C_out + nrow) * a.C_in + h * 16 + kc;
+        const float* wb = wrow + (long)j * a.C_out * a.C_in + kc;
         float4 av[4], bv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -90,8 +107,8 @@ __global__ __launch_bounds__(64 * G32_NW) void k_gemm32(const GemmArgs a) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             float va = af[s];
-            if (a.elu_in) va = elu1(va);
-            if (!trow_ok || !aok) va = 0.f;
+            if (ELU) va = elu1(va);
+            va = use ? va : 0.f;
             const float vb = nrow_ok ? bf[s] : 0.f;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, acc, 0, 0, 0);
         }
@@ -115,6 +132,17 @@ __global__ __launch_bounds__(64 * G32_NW) void k_gemm32(const GemmArgs a) {
         for (int w = 0; w < G32_NW; ++w) sum += red[w][reg][lane];          // fixed order
         const long orow = (long)t * a.phases + p;
         float v = sum + bias;
+        if (a.rope_q) {                                                 // (whole 32-channel tiles: every lane of the half-wave is here)
+            const float partner = __shfl_xor(v, 1, 64);
+            const int sec = ch / a.rope_d, cc = ch - sec * a.rope_d;
+            if (sec == 2) { a.rope_v[(long)(a.rope_offset + t) * a.rope_d + cc] = v; continue; }
+            const float ang = (float)(a.rope_offset + t) * a.rope_freqs[(cc & 63) >> 1];
+            const float c = cosf(ang), s = sinf(ang);
+            const float o = (cc & 1) ? partner * s + v * c : v * c - partner * s;
+            if (sec == 0) a.rope_q[(long)t * a.rope_d + cc] = o;
+            else a.rope_k[(long)(a.rope_offset + t) * a.rope_d + cc] = o;
+            continue;
+        }
         if (a.act_out == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
         if (a.col_scale) v = cs * v;
         if (a.resid) v = a.resid[orow * a.ldr + ch] + v;
@@ -142,10 +170,13 @@ __global__ __launch_bounds__(256) void k_rvq(const int* codes, long stride_k, lo
         q[d] = s1; q[cbdim + d] = s2;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < hidden; c += blockDim.x) {
+    // blockIdx.y = group of 64 output channels (round 4: with one block per frame a 10-frame chunk was 10 blocks pulling 1 MB of
+    // projection weights each, 30 us); the lookup-sum above is repeated per group (32 KB of codebook rows from L2)
+    const int c_lo = blockIdx.y * 64, c_hi = min(c_lo + 64, hidden);
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
         float a1 = 0.f, a2 = 0.f;
 #pragma unroll 8
-        for (int d = 0; d < cbdim; ++d) {
+        for (int d = 0; d < cbdim; ++d) {                                 // (unroll 32 -- 64 loads in flight -- was measured: 4x SLOWER)
             a1 = fmaf(pf[(long)d * hidden + c], q[d], a1);
             a2 = fmaf(pr[(long)d * hidden + c], q[cbdim + d], a2);
         }
@@ -194,26 +225,6 @@ __global__ __launch_bounds__(64) void k_layernorm(const float* x, int d, const f
         const int i = lane + 64 * j;
         if (i < d) out[row * d + i] = (v[j] - mean) * rstd * wv[j] + bv[j];
     }
-}
-
-// qkv [T][3d] -> q [T][d] (RoPE), K/V caches [cap][d] at rows offset+t (K with RoPE); hd = 64
-__global__ void k_rope_split(const float* qkv, int T, int d, int offset, const float* freqs, float* q, float* kc, float* vc) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (t, pair)
-    const int pairs = d / 2;
-    if (i >= (long)T * pairs) return;
-    const int t = (int)(i / pairs), pr = (int)(i % pairs);
-    const int e = pr % 32;                                         // pair index inside the head (hd/2 = 32)
-    const float ang = (float)(offset + t) * freqs[e];
-    const float c = cosf(ang), s = sinf(ang);
-    const float* row = qkv + (long)t * 3 * d;
-    const float q0 = row[2 * pr], q1 = row[2 * pr + 1];
-    const float k0 = row[d + 2 * pr], k1 = row[d + 2 * pr + 1];
-    q[(long)t * d + 2 * pr] = q0 * c - q1 * s;
-    q[(long)t * d + 2 * pr + 1] = q0 * s + q1 * c;
-    kc[(long)(offset + t) * d + 2 * pr] = k0 * c - k1 * s;
-    kc[(long)(offset + t) * d + 2 * pr + 1] = k0 * s + k1 * c;
-    vc[(long)(offset + t) * d + 2 * pr] = row[2 * d + 2 * pr];
-    vc[(long)(offset + t) * d + 2 * pr + 1] = row[2 * d + 2 * pr + 1];
 }
 
 // causal windowed attention, one wave per (query, head); head_dim 64
@@ -341,7 +352,10 @@ struct MimiDecoder {
     HBuf rvq, a0, s0;                   // rvq out (hist 1), transformer out (hist kernel-1), conv_in out (hist 1)
     HBuf u[MIMI_MAX_STAGES], xj[MIMI_MAX_STAGES];
     float *r1[MIMI_MAX_STAGES];
-    float *tok, *ln, *qkv, *q, *att, *ffn, *kc, *vc;
+    float *tok, *ln, *q, *att, *ffn, *kc, *vc;
+    hipStream_t cap_stream = nullptr;   // graph capture of decode_middle
+    hipGraphExec_t mid_exec[65] = {};   // by T (stateless decodes of up to MIMI_GRAPH_MAX_T frames)
+    int mid_uses[65] = {};
     std::string err;
 };
 
@@ -396,7 +410,7 @@ extern "C" int mimi_create(const MimiConfig* cfg, const MimiWeights* w, int max_
         MCHK((MimiDecoder*)nullptr, alloc_hbuf(m->xj[j], nh, Tj, C));
     }
 #define A4(p, n) MCHK((MimiDecoder*)nullptr, hipMalloc((void**)&(p), (size_t)(n) * 4))
-    A4(m->tok, T2 * d); A4(m->ln, T2 * d); A4(m->qkv, T2 * 3 * d); A4(m->q, T2 * d); A4(m->att, T2 * d);
+    A4(m->tok, T2 * d); A4(m->ln, T2 * d); A4(m->q, T2 * d); A4(m->att, T2 * d);
     A4(m->ffn, T2 * (cfg->tr_ffn > cfg->codebook_size ? cfg->tr_ffn : cfg->codebook_size));   // also the RVQ score buffer
     A4(m->kc, (long)cfg->tr_layers * m->cap_tokens * d); A4(m->vc, (long)cfg->tr_layers * m->cap_tokens * d);
 #undef A4
@@ -409,8 +423,10 @@ extern "C" void mimi_destroy(mimi_handle m) {
     if (!m) return;
     (void)hipFree(m->rvq.base); (void)hipFree(m->a0.base); (void)hipFree(m->s0.base);
     for (int j = 0; j < m->cfg.n_stages; ++j) { (void)hipFree(m->u[j].base); (void)hipFree(m->xj[j].base); (void)hipFree(m->r1[j]); }
-    void* ps[] = {m->tok, m->ln, m->qkv, m->q, m->att, m->ffn, m->kc, m->vc};
+    void* ps[] = {m->tok, m->ln, m->q, m->att, m->ffn, m->kc, m->vc};
     for (void* p : ps) (void)hipFree(p);
+    for (hipGraphExec_t g : m->mid_exec) if (g) (void)hipGraphExecDestroy(g);
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     delete m;
 }
 
@@ -440,19 +456,23 @@ extern "C" int mimi_reset_stream(mimi_handle m, void* stream) {
     return 0;
 }
 
+struct RopeOut { float *q, *k, *v; const float* freqs; int offset, d; };
 static hipError_t gemm(hipStream_t st, const float* x, long ldx, long T_in, const float* w, const float* bias, int C_in,
                        int C_out, int taps, int phases, const int* shifts, int elu_in, int act_out, const float* col_scale,
                        const float* resid, long ldr, float* out, long ldo, int in_stride = 1, int edge = 0, int row_lo = 0,
-                       int row_hi = 0) {
+                       int row_hi = 0, const RopeOut* rope = nullptr) {
     GemmArgs a;
     memset(&a, 0, sizeof a);
+    if (rope) { a.rope_q = rope->q; a.rope_k = rope->k; a.rope_v = rope->v; a.rope_freqs = rope->freqs; a.rope_offset = rope->offset; a.rope_d = rope->d; }
     a.in_stride = in_stride; a.edge = edge; a.row_lo = row_lo; a.row_hi = row_hi;
     a.x = x; a.ldx = ldx; a.T_in = (int)T_in; a.C_in = C_in; a.C_out = C_out; a.w = w; a.bias = bias; a.taps = taps;
     a.phases = phases;
-    for (int j = 0; j < taps; ++j) a.shift[j] = shifts[j];
-    a.elu_in = elu_in; a.act_out = act_out; a.col_scale = col_scale; a.resid = resid; a.ldr = ldr; a.out = out; a.ldo = ldo;
+    a.shift0 = shifts[0]; a.dshift = taps > 1 ? shifts[1] - shifts[0] : 0;
+    for (int j = 0; j < taps; ++j) if (shifts[j] != a.shift0 + j * a.dshift) return hipErrorInvalidValue;   // (every convolution here is an arithmetic progression of taps)
+    a.act_out = act_out; a.col_scale = col_scale; a.resid = resid; a.ldr = ldr; a.out = out; a.ldo = ldo;
     dim3 grid((unsigned)((T_in + 31) / 32), (unsigned)((C_out + 31) / 32), (unsigned)phases);
-    hipLaunchKernelGGL(k_gemm32, grid, dim3(64 * G32_NW), 0, st, a);
+    if (elu_in) hipLaunchKernelGGL(k_gemm32<true>, grid, dim3(64 * G32_NW), 0, st, a);
+    else hipLaunchKernelGGL(k_gemm32<false>, grid, dim3(64 * G32_NW), 0, st, a);
     return hipGetLastError();
 }
 
@@ -462,16 +482,25 @@ static hipError_t slide(const HBuf& b, long T, hipStream_t st) {
     return hipGetLastError();
 }
 
-static int decode_one(MimiDecoder* m, const int32_t* codes, long stride_k, long stride_t, int T, float* pcm, hipStream_t st) {
+// A decode is three pieces: front (the only kernel that reads the caller's codes), middle (everything between buffers the handle
+// owns: up-sampling, transformer, SEANet stages -- ~70 launches whose arguments depend on T and the stream offset only) and back (the
+// only kernel that writes the caller's PCM).  The middle of a STATELESS decode (offset 0) is replayed from a hipGraph per T.
+static int decode_front(MimiDecoder* m, const int32_t* codes, long stride_k, long stride_t, int T, hipStream_t st) {
+    const MimiConfig& c = m->cfg;
+    const int d = c.hidden;
+    // 1. RVQ lookup-sum + output projections -> rvq [T][d]
+    hipLaunchKernelGGL(k_rvq, dim3(T, (d + 63) / 64), dim3(256), (size_t)(2 * c.codebook_dim + c.n_codebooks) * 4, st, codes, stride_k, stride_t, T, c.n_codebooks,
+                       c.n_semantic, c.codebook_size, c.codebook_dim, d, m->w.codebooks, m->w.proj_first, m->w.proj_rest,
+                       m->rvq.row0(), (long)d);
+    MCHK(m, hipGetLastError());
+    return 0;
+}
+
+static int decode_middle(MimiDecoder* m, int T, hipStream_t st) {
     const MimiConfig& c = m->cfg;
     const int d = c.hidden;
     const long T2 = 2L * T;
     const int zero = 0;
-    // 1. RVQ lookup-sum + output projections -> rvq [T][d]
-    hipLaunchKernelGGL(k_rvq, dim3(T), dim3(256), (size_t)(2 * c.codebook_dim + c.n_codebooks) * 4, st, codes, stride_k, stride_t, T, c.n_codebooks,
-                       c.n_semantic, c.codebook_size, c.codebook_dim, d, m->w.codebooks, m->w.proj_first, m->w.proj_rest,
-                       m->rvq.row0(), (long)d);
-    MCHK(m, hipGetLastError());
     // 2. depthwise transposed conv x2 -> tok [2T][d]
     {
         const long n = T2 * d;
@@ -485,12 +514,8 @@ static int decode_one(MimiDecoder* m, const int32_t* codes, long stride_k, long 
         float* kc = m->kc + (long)l * m->cap_tokens * d;
         float* vc = m->vc + (long)l * m->cap_tokens * d;
         hipLaunchKernelGGL(k_layernorm, dim3((unsigned)T2), dim3(64), 0, st, m->tok, d, L.ln1_w, L.ln1_b, c.norm_eps, m->ln);
-        MCHK(m, gemm(st, m->ln, d, T2, L.in_proj, nullptr, d, 3 * d, 1, 1, &zero, 0, 0, nullptr, nullptr, 0, m->qkv, 3 * d));
-        {
-            const long n = T2 * (d / 2);
-            hipLaunchKernelGGL(k_rope_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->qkv, (int)T2, d, m->offset,
-                               m->w.rope_freqs, m->q, kc, vc);
-        }
+        const RopeOut ro = {m->q, kc, vc, m->w.rope_freqs, m->offset, d};
+        MCHK(m, gemm(st, m->ln, d, T2, L.in_proj, nullptr, d, 3 * d, 1, 1, &zero, 0, 0, nullptr, nullptr, 0, nullptr, 0, 1, 0, 0, 0, &ro));
         hipLaunchKernelGGL(k_mimi_attn, dim3((unsigned)T2, c.tr_heads), dim3(64), 0, st, m->q, kc, vc, d, m->offset, c.tr_context, m->att);
         MCHK(m, gemm(st, m->att, d, T2, L.out_proj, nullptr, d, d, 1, 1, &zero, 0, 0, L.ls1, m->tok, d, m->tok, d));
         hipLaunchKernelGGL(k_layernorm, dim3((unsigned)T2), dim3(64), 0, st, m->tok, d, L.ln2_w, L.ln2_b, c.norm_eps, m->ln);
@@ -523,11 +548,49 @@ static int decode_one(MimiDecoder* m, const int32_t* codes, long stride_k, long 
                      up.c_out, m->xj[j].row0(), r2.c_out));
         xin = m->xj[j].row0(); Cin = r2.c_out;
     }
+    return 0;
+}
+
+static int decode_back(MimiDecoder* m, int T, float* pcm, hipStream_t st) {
+    const MimiConfig& c = m->cfg;
+    long Tj = 2L * T;
+    for (int j = 0; j < c.n_stages; ++j) Tj *= m->w.up[j].phases;
+    const HBuf& last = m->xj[c.n_stages - 1];
     const MimiConv& co = m->w.conv_out;
-    hipLaunchKernelGGL(k_conv_out, dim3((unsigned)((Tj + 255) / 256)), dim3(256), 0, st, xin, (long)Cin, Tj, co.c_in, co.taps, co.w,
+    hipLaunchKernelGGL(k_conv_out, dim3((unsigned)((Tj + 255) / 256)), dim3(256), 0, st, last.row0(), (long)last.C, Tj, co.c_in, co.taps, co.w,
                        co.bias, pcm);
     MCHK(m, hipGetLastError());
     return 0;
+}
+
+// chunk sizes whose middle is worth a graph (a streaming chunk is 10 frames, the last one of an utterance 1..9): captured at the
+// SECOND stateless decode of a T, replayed from then on.  Longer decodes (whole utterances, a different T every time) stay eager.
+static const int MIMI_GRAPH_MAX_T = getenv("MIMI_GRAPH_MAX_T") ? atoi(getenv("MIMI_GRAPH_MAX_T")) : 32;
+
+static int decode_one(MimiDecoder* m, const int32_t* codes, long stride_k, long stride_t, int T, float* pcm, hipStream_t st, bool stateless) {
+    int rc = decode_front(m, codes, stride_k, stride_t, T, st);
+    if (rc) return rc;
+    if (stateless && T <= MIMI_GRAPH_MAX_T && T < (int)(sizeof m->mid_uses / sizeof m->mid_uses[0]) && m->offset == 0) {
+        if (!m->mid_exec[T] && ++m->mid_uses[T] >= 2) {
+            if (!m->cap_stream) MCHK(m, hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+            hipGraph_t g = nullptr;
+            MCHK(m, hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+            const int rc_mid = decode_middle(m, T, m->cap_stream);
+            const hipError_t e2 = hipStreamEndCapture(m->cap_stream, &g);
+            if (rc_mid) { if (g) (void)hipGraphDestroy(g); return rc_mid; }
+            MCHK(m, e2);
+            const hipError_t e3 = hipGraphInstantiate(&m->mid_exec[T], g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            MCHK(m, e3);
+        }
+        if (m->mid_exec[T]) {
+            MCHK(m, hipGraphLaunch(m->mid_exec[T], st));
+            return decode_back(m, T, pcm, st);
+        }
+    }
+    rc = decode_middle(m, T, st);
+    if (rc) return rc;
+    return decode_back(m, T, pcm, st);
 }
 
 static int slide_all(MimiDecoder* m, int T, hipStream_t st) {
@@ -552,12 +615,8 @@ static int transformer_pass(MimiDecoder* m, const MimiTrLayer* layers, long T2, 
         float* kc = m->kc + (long)l * m->cap_tokens * d;
         float* vc = m->vc + (long)l * m->cap_tokens * d;
         hipLaunchKernelGGL(k_layernorm, dim3((unsigned)T2), dim3(64), 0, st, m->tok, d, L.ln1_w, L.ln1_b, c.norm_eps, m->ln);
-        MCHK(m, gemm(st, m->ln, d, T2, L.in_proj, nullptr, d, 3 * d, 1, 1, &zero, 0, 0, nullptr, nullptr, 0, m->qkv, 3 * d));
-        {
-            const long n = T2 * (d / 2);
-            hipLaunchKernelGGL(k_rope_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->qkv, (int)T2, d, offset,
-                               m->w.rope_freqs, m->q, kc, vc);
-        }
+        const RopeOut ro = {m->q, kc, vc, m->w.rope_freqs, offset, d};
+        MCHK(m, gemm(st, m->ln, d, T2, L.in_proj, nullptr, d, 3 * d, 1, 1, &zero, 0, 0, nullptr, nullptr, 0, nullptr, 0, 1, 0, 0, 0, &ro));
         hipLaunchKernelGGL(k_mimi_attn, dim3((unsigned)T2, c.tr_heads), dim3(64), 0, st, m->q, kc, vc, d, offset, c.tr_context, m->att);
         MCHK(m, gemm(st, m->att, d, T2, L.out_proj, nullptr, d, d, 1, 1, &zero, 0, 0, L.ls1, m->tok, d, m->tok, d));
         hipLaunchKernelGGL(k_layernorm, dim3((unsigned)T2), dim3(64), 0, st, m->tok, d, L.ln2_w, L.ln2_b, c.norm_eps, m->ln);
@@ -654,7 +713,7 @@ extern "C" int mimi_decode_strided(mimi_handle m, const int32_t* codes, int B, i
     for (int b = 0; b < B; ++b) {
         if (!stateful) { int rc = mimi_reset_stream(m, stream); if (rc) return rc; }
         if (m->offset + 2L * T > m->cap_tokens) return mfail(m, "mimi_decode: stream longer than max_frames; call mimi_reset_stream");
-        int rc = decode_one(m, codes + (long)b * stride_b, stride_k, stride_t, T, (float*)pcm + (long)b * hop * T, st);
+        int rc = decode_one(m, codes + (long)b * stride_b, stride_k, stride_t, T, (float*)pcm + (long)b * hop * T, st, !stateful);
         if (rc) return rc;
         if (stateful) { rc = slide_all(m, T, st); if (rc) return rc; m->offset += 2 * T; }
     }

@@ -14,7 +14,11 @@ for _ in range(3): codec.decode(c10)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(20): codec.decode(c10)
-torch.cuda.synchronize(); print("10 frames ms", (time.perf_counter() - t0) * 50)
+t1 = time.perf_counter()
+torch.cuda.synchronize(); print("10 frames ms", (time.perf_counter() - t0) * 50, "| host time to enqueue one decode ms", (t1 - t0) * 50)
+for _ in range(3):                                    # one decode at a time, GPU idle before each: what a streaming chunk sees
+    torch.cuda.synchronize(); t0 = time.perf_counter(); codec.decode(c10); torch.cuda.synchronize(); one = (time.perf_counter() - t0) * 1e3
+print("10 frames, one call from an idle GPU ms", one)
 wav = torch.randn(1, 1, 24000 * 10, generator=torch.Generator().manual_seed(1)).cuda() * 0.1
 for _ in range(2): codec.encode(wav)
 torch.cuda.synchronize()
