@@ -29,8 +29,10 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 template <int HD>
 __global__ __launch_bounds__(256) void k_attn_flash(const AttnArgs a) {
     static_assert(HD == 64, "k_attn_flash: head_dim 64");
-    __shared__ __align__(16) bf16_t Ks[2][32 * AF_KLD];
-    __shared__ __align__(16) bf16_t Vs[2][32 * AF_VLD];
+    // (round 4: a buffer holds TWO 32-key tiles -- one global round trip, one LDS write and one barrier per 64 keys; the tiles are
+    //  still consumed one after the other with the same online-softmax update, so the bits are those of the 32-key walk)
+    __shared__ __align__(16) bf16_t Ks[2][64 * AF_KLD];
+    __shared__ __align__(16) bf16_t Vs[2][64 * AF_VLD];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int kvh = blockIdx.y, G = a.H / a.KV;
     const int groups = (a.rows_per_seq + 31) / 32;
@@ -40,26 +42,27 @@ __global__ __launch_bounds__(256) void k_attn_flash(const AttnArgs a) {
     const int mq = m_base + min(r, nr - 1);                            // this lane's query row (padding repeats the last)
     const int pq = min(max(a.pos[mq], 0), a.smax - 1);
     const int pmax = (int)wave_max((float)pq);                          // same for the 4 waves (same 32 queries)
-    const int ntiles = pmax / 32 + 1;
+    const int npairs = pmax / 64 + 1;                                   // pairs of 32-key tiles
     const bf16_t* kb = a.kcache + ((long)b * a.KV + kvh) * a.smax * HD;
     const bf16_t* vb = a.vcache + ((long)b * a.KV + kvh) * a.smax * HD;
 
     // staging: thread t moves segment (t & 7) of key row (t >> 3) of both tiles
     const int skey = tid >> 3, sseg = tid & 7;
-    u32x4_t kreg, vreg;
+    u32x4_t kreg[2], vreg[2];
     const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+    // (t = index of a PAIR of 32-key tiles; rows skey and skey + 32 of the pair share (row >> 1) & 7, so one swizzled segment serves both)
 #define AF_GLOAD(t)                                                                                     \
-    {                                                                                                   \
-        const int j = (t) * 32 + skey;                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                     \
+        const int j = (t) * 64 + 32 * u + skey;                                                         \
         const long off = (long)min(j, pmax) * HD + sseg * 8;                                            \
-        kreg = *reinterpret_cast<const u32x4_t*>(kb + off);                                             \
-        vreg = *reinterpret_cast<const u32x4_t*>(vb + off);                                             \
-        if (j > pmax) { kreg = zero4; vreg = zero4; }   /* never-written cache rows may hold NaN bit patterns */ \
+        kreg[u] = *reinterpret_cast<const u32x4_t*>(kb + off);                                          \
+        vreg[u] = *reinterpret_cast<const u32x4_t*>(vb + off);                                          \
+        if (j > pmax) { kreg[u] = zero4; vreg[u] = zero4; }   /* never-written cache rows may hold NaN bit patterns */ \
     }
 #define AF_LWRITE(buf)                                                                                  \
-    {                                                                                                   \
-        *reinterpret_cast<u32x4_t*>(&Ks[buf][skey * AF_KLD + ((sseg ^ ((skey >> 1) & 7)) * 8)]) = kreg; \
-        *reinterpret_cast<u32x4_t*>(&Vs[buf][skey * AF_VLD + sseg * 8]) = vreg;                         \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                     \
+        *reinterpret_cast<u32x4_t*>(&Ks[buf][(32 * u + skey) * AF_KLD + ((sseg ^ ((skey >> 1) & 7)) * 8)]) = kreg[u]; \
+        *reinterpret_cast<u32x4_t*>(&Vs[buf][(32 * u + skey) * AF_VLD + sseg * 8]) = vreg[u];           \
     }
 
     for (int g = wave; g < G; g += 4) {
@@ -78,10 +81,13 @@ __global__ __launch_bounds__(256) void k_attn_flash(const AttnArgs a) {
         AF_GLOAD(0)
         AF_LWRITE(0)
         __syncthreads();
-        for (int t = 0; t < ntiles; ++t) {
-            AF_GLOAD(min(t + 1, ntiles - 1))                           // in flight while this tile is computed
-            const bf16_t* Kt = Ks[t & 1];
-            const bf16_t* Vt = Vs[t & 1];
+        for (int tp = 0; tp < npairs; ++tp) {
+            AF_GLOAD(min(tp + 1, npairs - 1))                          // in flight while this pair of tiles is computed
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {                              // (a tile past pmax is all zeros and fully masked: an exact no-op)
+            const int t = 2 * tp + u;
+            const bf16_t* Kt = Ks[tp & 1] + u * 32 * AF_KLD;
+            const bf16_t* Vt = Vs[tp & 1] + u * 32 * AF_VLD;
             // ---- S^T = K . Q^T ------------------------------------------------------------------------
             f32x16_t sacc;
 #pragma unroll
@@ -98,17 +104,20 @@ __global__ __launch_bounds__(256) void k_attn_flash(const AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int j = t * 32 + 8 * (i >> 2) + 4 * h + (i & 3);  // key of accumulator register i
-                p[i] = (j <= pq) ? sacc[i] * a.scale : -INFINITY;
+                p[i] = (j <= pq) ? __fmul_rn(sacc[i], a.scale) : -INFINITY;   // (explicit roundings: see below)
                 tmax = fmaxf(tmax, p[i]);
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, WAVE));
             const float mnew = fmaxf(mrun, tmax);                       // finite: key 0 is visible to every row
-            const float corr = __expf(mrun - mnew);                     // 0 on the first tile
+            const float corr = __expf(__fsub_rn(mrun, mnew));           // 0 on the first tile
             float psum = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { p[i] = __expf(p[i] - mnew); psum += p[i]; }
-            psum += __shfl_xor(psum, 32, WAVE);
-            lrun = lrun * corr + psum;
+            // (score * scale and its distance to the maximum are rounded separately, the running sum is ONE fma: without the explicit forms
+            //  hipcc contracts `s * scale - m` into an fma or not depending on the surrounding code -- the 64-key restructuring of round 4
+            //  moved one element per ~500 rows by an ulp against the 32-key build)
+            for (int i = 0; i < 16; ++i) { p[i] = __expf(__fsub_rn(p[i], mnew)); psum = __fadd_rn(psum, p[i]); }
+            psum = __fadd_rn(psum, __shfl_xor(psum, 32, WAVE));
+            lrun = fmaf(lrun, corr, psum);
             mrun = mnew;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o0[i] *= corr; o1[i] *= corr; }
@@ -135,7 +144,8 @@ __global__ __launch_bounds__(256) void k_attn_flash(const AttnArgs a) {
                     else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf), as_bf16x8(pf), o1, 0, 0, 0);
                 }
             }
-            AF_LWRITE((t + 1) & 1)
+            }
+            AF_LWRITE((tp + 1) & 1)
             __syncthreads();
         }
         // ---- out[query][hq][d] = O^T / l: registers 4g4 .. 4g4+3 are 4 consecutive d -> one 8-byte store ---------

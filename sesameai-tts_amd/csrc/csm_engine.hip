@@ -297,7 +297,7 @@ static const int G128_MIN_ROWS = getenv("CSM_G128_MIN_ROWS") ? atoi(getenv("CSM_
 static const int G256_MIN_ROWS = getenv("CSM_G256_MIN_ROWS") ? atoi(getenv("CSM_G256_MIN_ROWS")) : (1 << 30);
 template <int EPI, int HD, int MI>
 static hipError_t launch_g128_t(const GemvArgs& a, int K, hipStream_t st) {
-    constexpr int SMEM = MI == 2 ? G128_SMEM : G256_SMEM, BM = 64 * MI;
+    constexpr int SMEM = MI == 1 ? G64_SMEM : MI == 2 ? G128_SMEM : G256_SMEM, BM = 64 * MI;
     static bool attr_set_dev[64] = {false};              // hipFuncSetAttribute is per device
     int dev_ = 0; (void)hipGetDevice(&dev_);
     bool& attr_set = attr_set_dev[dev_ & 63];
@@ -312,15 +312,20 @@ static hipError_t launch_g128_t(const GemvArgs& a, int K, hipStream_t st) {
     const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.N + nout - 1) / nout;
     static const int switch_tiles = getenv("CSM_G128_ROWTILES") ? atoi(getenv("CSM_G128_ROWTILES")) : 32;
     int mt8; unsigned blocks;
-    if (mtiles * (BM / 128) >= switch_tiles) { mt8 = (mtiles + 7) / 8; blocks = (unsigned)(8L * ntiles * mt8); }   // row tiles per XCD
+    if (mtiles * BM / 128 >= switch_tiles) { mt8 = (mtiles + 7) / 8; blocks = (unsigned)(8L * ntiles * mt8); }   // row tiles per XCD
     else { mt8 = -mtiles; blocks = (unsigned)(8L * ((ntiles + 7) / 8) * mtiles); }                            // column tiles per XCD
     if (EPI == EPI_SLAB) blocks *= 4;                                                                         // one block per K quarter
     hipLaunchKernelGGL((k_gemm128<EPI, HD, 0, MI>), dim3(blocks), dim3(256), SMEM, st, a, K, mt8, (long)K);
     return hipGetLastError();
 }
+// 64-row blocks when the 128-row tiling would leave at most ~one block per CU (measured at 1,334 rows: q|k|v 64 -> ? us); same bits
+static const int G64_MAX_BLOCKS = getenv("CSM_G64_MAX_BLOCKS") ? atoi(getenv("CSM_G64_MAX_BLOCKS")) : 320;
 template <int EPI, int HD>
 static hipError_t launch_g128_mi(const GemvArgs& a, int K, hipStream_t st) {
-    return a.M >= G256_MIN_ROWS ? launch_g128_t<EPI, HD, 4>(a, K, st) : launch_g128_t<EPI, HD, 2>(a, K, st);
+    if (a.M >= G256_MIN_ROWS) return launch_g128_t<EPI, HD, 4>(a, K, st);
+    const int nout = EPI == EPI_SWIGLU ? 64 : 128;
+    const long blocks128 = (long)((a.M + 127) / 128) * ((a.N + nout - 1) / nout) * (EPI == EPI_SLAB ? 4 : 1);
+    return blocks128 <= G64_MAX_BLOCKS ? launch_g128_t<EPI, HD, 1>(a, K, st) : launch_g128_t<EPI, HD, 2>(a, K, st);
 }
 static hipError_t launch_g128(int kind, int K, int hd, const GemvArgs& a, hipStream_t st) {
     if (K % 256 != 0) return hipErrorInvalidValue;

@@ -27,15 +27,18 @@ __device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4_t& v) { return __built
 
 #define G128_LD 64                        // LDS row = one 64-deep K slice (128 B); 16-byte segments XOR-swizzled
 #define G128_SMEM (2 * 256 * G128_LD * 2) // two buffers of (128 A rows + 128 B rows) = 64 KB
+#define G64_SMEM (2 * 192 * G128_LD * 2)  // MI = 1: two buffers of (64 A rows + 128 B rows) = 48 KB
 #define G256_SMEM (3 * 384 * G128_LD * 2) // MI = 4: THREE buffers of (256 A rows + 128 B rows) = 144 KB, filled by LDS-DMA
 
-// MI = 32-row tiles per wave along M: 2 -> the 128 x 128 block (two blocks per CU), 4 -> a 256 x 128 block (round 3; one block per CU;
+// MI = 32-row tiles per wave along M: 1 -> a 64 x 128 block (round 4: for launches whose 128-row tiling leaves one block per CU --
+// q|k|v at ~1,300 rows is 264 blocks of 32 slices, each slice one exposed memory round trip; 64-row blocks put two on every CU),
+// 2 -> the 128 x 128 block (two blocks per CU), 4 -> a 256 x 128 block (round 3; one block per CU;
 // NOT used by default: measured slower, see csm_engine.hip G256_MIN_ROWS).  The bigger block's bytes per flop fall from 1/64 to 1/85 --
 // these kernels need 64 KB per CU and slice pair from the L2s, whose ~70 GB/s per CU (MI355X_MICROARCH.md) caps them near 46 % of the
 // matrix cores' peak -- but its accumulators take the register file: one block per CU, one wave per SIMD, and that costs more than the
 // bytes save.  Same per-tile MFMA chains and the same K-quarter fold in both: same bits.
 template <int EPI, int HD, int DBG = 0, int MI = 2>
-__global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void k_gemm128(const GemvArgs a, const int K, const int mt8, const long ldw) {
+__global__ __launch_bounds__(256, MI <= 2 ? 2 : 1) void k_gemm128(const GemvArgs a, const int K, const int mt8, const long ldw) {
     constexpr int BM = 64 * MI;                             // rows per block
     constexpr int NA = MI * 2;                              // 16-byte A pieces per thread and slice (rows row0 + 32 i)
     constexpr int LROWS = BM + 128;                         // LDS rows per buffer
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void k_gemm128(const GemvArgs
 #define G128_ARRIVED(set, younger)                                                       \
     {                                                                                    \
         if (!(younger)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+        else if (NA == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");               \
         else if (NA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               \
         else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                           \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(ra[set][i])); \
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void k_gemm128(const GemvArgs
     }
     // (slices past the last one re-load the last one: no control flow around the register staging)
 #define G128_KOFF(s_) ((c_first + min((s_), ns - 1)) * 64)
-    if constexpr (MI == 2) {
+    if constexpr (MI <= 2) {
         // Every asm-loaded register set is requested AND consumed inside one loop iteration (two slices per iteration): no such value is
         // live across the loop's back edge or its entry, where the register allocator may insert copies -- a copy of a register whose
         // load is still in flight copies stale bits (seen in a first version of a 4-deep ring for k_attn_flash: v_mov at the back edge).
