@@ -318,7 +318,7 @@ static hipError_t launch_g128_t(const GemvArgs& a, int K, hipStream_t st) {
     hipLaunchKernelGGL((k_gemm128<EPI, HD, 0, MI>), dim3(blocks), dim3(256), SMEM, st, a, K, mt8, (long)K);
     return hipGetLastError();
 }
-// 64-row blocks when the 128-row tiling would leave at most ~one block per CU (measured at 1,334 rows: q|k|v 64 -> ? us); same bits
+// 64-row blocks when the 128-row tiling would leave at most ~one block per CU (measured at 1,334 rows under rocprofv3: q|k|v 64 -> 47 us); same bits
 static const int G64_MAX_BLOCKS = getenv("CSM_G64_MAX_BLOCKS") ? atoi(getenv("CSM_G64_MAX_BLOCKS")) : 320;
 template <int EPI, int HD>
 static hipError_t launch_g128_mi(const GemvArgs& a, int K, hipStream_t st) {
