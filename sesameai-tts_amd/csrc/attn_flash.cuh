@@ -101,6 +101,9 @@ __global__ __launch_bounds__(256) void k_attn_flash(const AttnArgs a) {
             // ---- online softmax over this lane pair's 32 keys -------------------------------------------
             float p[16];
             float tmax = -INFINITY;
+            // (round 4, measured and removed: skipping the causal mask on tiles below every row's position and the rescale of O while no
+            //  row's maximum moves -- wave-uniform branches, same bits, 53.5 us before and after at 1,334 rows: not VALU-bound; what is left
+            //  is one K/V round trip per 64 keys with a single pair of tiles in flight per block)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int j = t * 32 + 8 * (i >> 2) + 4 * h + (i & 3);  // key of accumulator register i
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void k_attn_flash(const AttnArgs a) {
 #pragma unroll
             // (score * scale and its distance to the maximum are rounded separately, the running sum is ONE fma: without the explicit forms
             //  hipcc contracts `s * scale - m` into an fma or not depending on the surrounding code -- the 64-key restructuring of round 4
-            //  moved one element per ~500 rows by an ulp against the 32-key build)
+            //  moved one element per ~500 rows by an ulp against the 32-key build; with them both builds give the same bits: tools/dbg/flash_ab.py)
             for (int i = 0; i < 16; ++i) { p[i] = __expf(__fsub_rn(p[i], mnew)); psum = __fadd_rn(psum, p[i]); }
             psum = __fadd_rn(psum, __shfl_xor(psum, 32, WAVE));
             lrun = fmaf(lrun, corr, psum);
