@@ -86,7 +86,11 @@ const char* mimi_last_error(mimi_handle h);
  * these T frames (what the reference does, whole utterance or per 10-frame chunk);
  * stateful != 0: continue the stream of the previous stateful call (B must be 1): conv left
  * contexts and the transformer KV window carry over, so chunked output == whole decode.
- * Codes >= codebook_size (CSM's vocab is 2051 > 2048) are clamped to codebook_size-1.       */
+ * Codes >= codebook_size (CSM's vocab is 2051 > 2048) are clamped to codebook_size-1.
+ * A stateless decode of T <= 32 frames (a streaming chunk) replays everything between the code
+ * lookup and the output convolution from a hipGraph the handle captures at the second decode
+ * of that T (kernel nodes only; MIMI_GRAPH_MAX_T=0 turns it off): same kernels, a quarter of
+ * the host time per chunk.  One handle serves one thread at a time.                          */
 int mimi_decode(mimi_handle h, const int32_t* codes, int B, int T, long stride_b, long stride_k,
                 void* pcm, int stateful, void* stream);
 /* stride_t is 1 for a (B,32,T) tensor; use mimi_decode_strided for other layouts. */
