@@ -66,6 +66,29 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
+def cpu_quota():
+    """CPUs the container may use per scheduling period (cgroup v2 cpu.max / v1 cfs quota), or None.  More runnable threads than this
+    get the whole process throttled for the rest of each period -- on the GPU boxes of this pool (quota 16, 256 logical CPUs) a torch
+    CPU op on 128 OpenMP threads turned a 6 ms call into 85 ms (tools/dbg/prefill_wall_diag.py)."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(int(q) / int(p)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, q // p)
+    except (OSError, ValueError):
+        return None
+
+
+def default_cpu_threads():
+    n = min(32, os.cpu_count() or 1)
+    q = cpu_quota()
+    return min(n, q) if q else n
+
+
 def host_description(threads_used):
     """cpu_baseline.host: what the CPU port ran on (north_star: "core count stated")."""
     model = None
@@ -80,7 +103,7 @@ def host_description(threads_used):
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count()
-    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "usable_cpus": usable, "threads_used": threads_used}
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "usable_cpus": usable, "cgroup_cpu_quota": cpu_quota(), "threads_used": threads_used}
 
 
 def log(msg):
@@ -443,7 +466,8 @@ def main():
     ap.add_argument("--no-mimi", action="store_true", help="skip the (untimed-region) Mimi decode report")
     ap.add_argument("--cpu-frames", type=int, default=64)
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle frames to time")
-    ap.add_argument("--cpu-threads", type=int, default=min(32, os.cpu_count() or 1))
+    ap.add_argument("--cpu-threads", type=int, default=default_cpu_threads(),
+                    help="host threads of the CPU baseline (default: min(32, logical CPUs, the container's CPU quota))")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16",
                     help="fp8 = OCP-e4m3 weight stream for the decode step (BASELINE config 5; not the headline)")
@@ -454,6 +478,9 @@ def main():
     if args.cpu_worker:
         cpu_worker(args)
         return
+    q = cpu_quota()
+    if q and torch.get_num_threads() > q:
+        torch.set_num_threads(q)                   # host-side set-up (synthetic weights) on no more threads than the container may run
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args, sys.argv[1:])            # never returns

@@ -351,6 +351,39 @@ class Model:
             check(lib.csm_seed(self._h, seed, _stream_ptr()), self._h)
         self._seeded = True
 
+    def _to_dev(self, x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        """A prompt tensor on the device in the dtype the C ABI reads.  A host tensor is cast by ONE single-threaded numpy pass straight
+        into a pinned staging buffer the model keeps, then copied asynchronously: 4x fewer bytes than the int64 original, no pinning
+        of the caller's pages -- and no torch CPU kernel.  The last point is what round 4 measured (tools/dbg/prefill_wall_diag.py):
+        a 1,334-row prompt is 44,022 elements, above torch's 32,768-element grain, so ``x.to(torch.int32)`` becomes an OpenMP region
+        on every hardware thread torch sees (128 here); in a container with a CPU quota (16 on the GPU boxes of this pool) the
+        spinning team burns the quota and the cgroup throttles the process for the rest of the period: every third 6 ms prefill took
+        ~85 ms.  (Callers that run their own large torch CPU ops in such a container want OMP_NUM_THREADS <= the quota.)"""
+        if x.device.type != "cpu" or self.device.type != "cuda":
+            return x.to(device=self.device, dtype=dtype).contiguous()
+        import numpy as np
+        out = torch.empty(x.shape, dtype=dtype, device=self.device)
+        n = out.numel() * out.element_size()
+        if n == 0:
+            return out
+        n_al = (n + 255) // 256 * 256
+        st = getattr(self, "_stage", None)
+        if st is None or st["buf"].numel() < n_al:
+            if st is not None:
+                st["done"].synchronize()
+            st = self._stage = {"buf": torch.empty(max(n_al, 1 << 20), dtype=torch.uint8, pin_memory=True), "off": 0,
+                                "done": torch.cuda.Event()}
+        if st["off"] + n_al > st["buf"].numel():
+            st["done"].synchronize()                     # the copies issued from the buffer so far have left it
+            st["off"] = 0
+        piece = st["buf"][st["off"]: st["off"] + n].view(dtype).view(x.shape)
+        st["off"] += n_al
+        np.copyto(piece.numpy(), x.detach().numpy(), casting="unsafe")
+        with self._on_device():
+            out.copy_(piece, non_blocking=True)
+            st["done"].record()
+        return out
+
     def _check_positions(self, input_pos: torch.Tensor) -> None:
         """Positions must lie in [0, max_seq_len): checked here when that costs no device sync; positions that only
         exist on the device are checked by the kernels (device flag -> CSM_E_TOO_LONG from read_frames)."""
@@ -379,9 +412,9 @@ class Model:
         if b * s > max(self._max_prefill_rows, 2 * self._max_batch):
             raise ValueError(f"prompt of {b}x{s} rows exceeds max_prefill_rows={self._max_prefill_rows}")
         self._check_positions(input_pos)
-        t = tokens.to(device=self.device, dtype=torch.int32).contiguous()
-        m = tokens_mask.to(device=self.device, dtype=torch.uint8).contiguous()
-        p = input_pos.to(device=self.device, dtype=torch.int32).contiguous()
+        t = self._to_dev(tokens, torch.int32)
+        m = self._to_dev(tokens_mask, torch.uint8)
+        p = self._to_dev(input_pos, torch.int32)
         with self._on_device():
             check(lib.csm_prefill(self._h, t.data_ptr(), m.data_ptr(), p.data_ptr(), b, s, int(_keeps_prompt_prefix), _stream_ptr()), self._h)
 
@@ -393,8 +426,8 @@ class Model:
         b, s, _ = tokens.shape
         if s > self.bb.max_seq_len:
             raise ValueError(f"prompt of {s} rows exceeds max_seq_len={self.bb.max_seq_len}")
-        t = tokens.to(device=self.device, dtype=torch.int32)
-        m = tokens_mask.to(device=self.device, dtype=torch.bool)
+        t = self._to_dev(tokens, torch.int32)
+        m = self._to_dev(tokens_mask, torch.uint8).to(torch.bool)
         t = torch.where(m, t, torch.zeros_like(t))                    # masked slots do not matter
         start = 0
         if self.prefix_reuse and self._kv_prompt is not None and self._kv_prompt[0].shape[0] == b:
@@ -425,8 +458,8 @@ class Model:
         if s >= self.bb.max_seq_len or s > max(self._max_prefill_rows, 2 * self._max_batch):
             raise ValueError(f"prompt of {s} rows exceeds the limits (max_seq_len {self.bb.max_seq_len}, max_prefill_rows {self._max_prefill_rows})")
         self._kv_prompt = None                                   # slot 0's cached prompt prefix no longer describes the caches
-        t = tokens.to(device=self.device, dtype=torch.int32).contiguous()
-        m = tokens_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        t = self._to_dev(tokens, torch.int32)
+        m = self._to_dev(tokens_mask, torch.uint8)
         p = torch.arange(s, device=self.device, dtype=torch.int32)
         out = torch.empty(self.config.audio_num_codebooks, dtype=torch.int32, device=self.device)
         with self._on_device():
@@ -443,8 +476,8 @@ class Model:
         if s >= self.bb.max_seq_len or s > max(self._max_prefill_rows, 2 * self._max_batch):
             raise ValueError(f"prompt of {s} rows exceeds the limits (max_seq_len {self.bb.max_seq_len}, max_prefill_rows {self._max_prefill_rows})")
         self._kv_prompt = None
-        t = tokens.to(device=self.device, dtype=torch.int32).contiguous()
-        m = tokens_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        t = self._to_dev(tokens, torch.int32)
+        m = self._to_dev(tokens_mask, torch.uint8)
         p = torch.arange(s, device=self.device, dtype=torch.int32)
         self._refill_keep = (t, m, p)                             # the position array is read by every advance call
         with self._on_device():

@@ -27,6 +27,9 @@ for S in 190 1334; do
     python tools/pmc_summary.py mfma $O/pfm_$S $O/pmc_mfma_util_S$S.json "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/prefill_prof.py $S 4 (round 4)" > /dev/null
     rm -rf $O/pf_$S $O/pfm_$S
 done
+R=$GRAFT_REPO_ROOT; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/mimi_prof -o mimi -- python3 $R/tools/mimi_prof.py > $R/$O/mimi_prof_under_rocprof.txt 2>&1)
+python3 tools/dbg/mimi_chunk_timeline.py $O/mimi_prof/mimi_results.db > $O/mimi_chunk10_timeline.txt 2>&1; rm -rf $O/mimi_prof
+timeout 300 python3 tools/mimi_prof.py 2>&1 | grep -v amdgpu.ids > $O/mimi_times.txt
 tools/sweep_batch.sh "1 2 4 8 16 32" > $O/batch_sweep.txt 2>&1
 timeout 300 python tools/persist_timeline.py > $O/persist_timeline.txt 2>&1
 timeout 300 python tools/persist_m_timeline.py 32 2>&1 | grep -v amdgpu.ids > $O/persist_m_timeline_b32.txt
