@@ -622,7 +622,7 @@ def main():
                                "frac": round((mimi_bytes + 2e6 * T) / (whole_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                      "chunk10": {"frames": 10, "ms": round(chunk_ms, 3), "achieved": round((mimi_bytes + 2e7) / (chunk_ms * 1e-3) / 1e9, 1),
                                  "frac": round((mimi_bytes + 2e7) / (chunk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                     "note": "latency-bound chain of ~85 small launches (DESIGN.md): < 3 % of end-to-end time and overlapped with the frame loop when streaming"}
+                     "note": "latency-bound chain of 74 small launches, the middle ~70 replayed from a hipGraph for chunks (DESIGN.md, profiles/r04/mimi_ab.txt): < 3 % of end-to-end time and overlapped with the frame loop when streaming"}
         mimi = {"frames": T, "decode_whole_ms": round(whole_ms, 3), "decode_stream10_ms": round(stream_ms, 3), "roofline": mimi_roof,
                 "ms_per_10_frame_chunk": round(stream_ms / max((T + 9) // 10, 1), 3),
                 "end_to_end_ms": round(gen_ms + whole_ms, 2),
