@@ -347,6 +347,36 @@ def test_prefix_kv_reuse_is_bit_identical(tiny):
     assert m.last_prefill_rows == 1 and torch.equal(again, cold)
 
 
+def test_prompt_inputs_from_the_host_equal_device_inputs(tiny):
+    """Model._to_dev: host prompt tensors are cast by one numpy pass into the model's pinned staging buffer and copied asynchronously
+    (no torch CPU kernel, no pageable copy).  Whatever the caller hands over -- int64 / int32, bool / uint8, contiguous or a strided
+    view, on the host or on the device -- the frame is the same; many prompts in a row wrap the staging buffer."""
+    shape, w, m = tiny
+    B, S = 2, 14
+    pr = [_tiny_prompt(S, 70 + b) for b in range(B)]
+    tok, msk = torch.stack([p[0] for p in pr]), torch.stack([p[1] for p in pr])
+    pos = torch.arange(S).unsqueeze(0).repeat(B, 1)
+
+    def frame(t, k, p):
+        m.reset_caches(); m.seed(3)
+        m.prefill(t, k, p)
+        return m.depth(B, 1.0, 1, commit=True).clone()
+
+    want = frame(tok.cuda(), msk.cuda(), pos.cuda())
+    wide_t = torch.zeros(B, S, 66, dtype=torch.long); wide_t[:, :, ::2] = tok          # a strided view of a wider host tensor
+    forms = [(tok, msk, pos), (tok.int(), msk.to(torch.uint8), pos.int()), (wide_t[:, :, ::2], msk, pos),
+             (tok, msk.cuda(), pos), (tok.cuda().int(), msk, pos.cuda())]
+    for t, k, p in forms:
+        assert torch.equal(frame(t, k, p), want)
+    for i in range(260):                                      # ~5 KB staged per prompt: more than once around the 1 MiB ring
+        m.reset_caches(); m.prefill(tok, msk, pos)
+    assert torch.equal(frame(tok, msk, pos), want)
+    big = torch.zeros(1, 200, 33, dtype=torch.long); big[0, :, 32] = 5
+    bm = torch.zeros(1, 200, 33, dtype=torch.bool); bm[0, :, 32] = True
+    m.reset_caches(); m.prefill(big, bm, torch.arange(200).unsqueeze(0))               # a larger prompt than anything staged so far
+    assert torch.equal(frame(tok, msk, pos), want)
+
+
 def test_prompt_too_long_raises(tiny):
     from sesameai.generator import Generator
     shape, w, m = tiny

@@ -53,6 +53,32 @@ def test_stateless_chunks_match_reference_stream_semantics(tiny_codec):
     _close(got[..., ::16], gold["chunks_stride16"], "stateless 10-frame chunks vs golden")
 
 
+def test_chunk_decodes_replayed_from_the_graph_equal_the_launch_chain(tiny_codec):
+    """A stateless decode of <= 32 frames replays its middle (everything between the code lookup and the output convolution) from
+    a hipGraph captured at the second decode of that length (mimi_engine.hip decode_one): the first call of a length runs the launch
+    chain, the later ones the graph -- same bits, for other codes too, with other lengths in between and from another stream."""
+    from oracle import mimi_ref as M
+    from sesameai.mimi import MimiCodec, mimi_tiny_args, synthetic_state_dict
+    s, w, codec = tiny_codec
+    g = torch.Generator().manual_seed(12)
+    a7, b7, c10 = (torch.randint(0, 2048, (1, 32, n), generator=g) for n in (7, 7, 10))
+    chain = MimiCodec(mimi_tiny_args(), synthetic_state_dict(mimi_tiny_args(), seed=4321), max_frames=64)
+    want_a = chain.decode(a7)                                      # a fresh handle's FIRST decode of a length: the launch chain
+    chain2 = MimiCodec(mimi_tiny_args(), synthetic_state_dict(mimi_tiny_args(), seed=4321), max_frames=64)
+    want_b = chain2.decode(b7)
+    codec.decode(a7); codec.decode(a7)                             # the second use captures: from here T = 7 is a replay on this handle
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        assert torch.equal(codec.decode(a7), want_a)
+        codec.decode(c10)                                          # another length in between (a graph of its own)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            got_b = codec.decode(b7)
+        side.synchronize()
+        assert torch.equal(got_b, want_b)
+    _close(want_a, M.decode(s, w, a7), "7-frame chunk vs oracle")
+
+
 def test_stateful_stream_equals_whole_decode(tiny_codec):
     """property: Mimi decode is strictly causal, so a stateful stream in ragged chunks
     (1, 2, 10, 3, ... frames) reproduces the whole-utterance decode."""
