@@ -84,6 +84,23 @@ class Generator:
         self._eos_poll = 8                     # frames launched between EOS polls
         self._mimi_stream = None               # side HIP stream for Mimi in generate_stream
 
+    def warm_up(self, temperature: float = 0.7, topk: int = 30) -> None:
+        """One short synthetic utterance through the streaming path and the whole-utterance path.  Everything a process does once --
+        torch's first device kernels of each kind, the HIP module load, the frame-step graph's capture (for THIS temperature / top-k),
+        the Mimi chunk graph, the side stream -- is paid here instead of by the first request: measured on an MI355X
+        (tools/dbg/first_chunk_breakdown.py), the first utterance of a process took 164 ms to its first chunk against 30 ms for
+        every later one.  ``load_csm_1b`` calls it (CSM_NO_WARMUP=1 skips it); the reference has no counterpart."""
+        if self._audio_tokenizer is None or self.device.type != "cuda":
+            return
+        g = torch.Generator().manual_seed(0)
+        ctx = [Segment(speaker=0, text=[11] * 40, audio_codes=torch.randint(0, 2048, (32, 60), generator=g))]
+        n = 2 * self._stream_buffer_size + 2
+        for _ in self.generate_stream([11] * 12, 0, ctx, max_audio_length_ms=n * FRAME_MS, temperature=temperature, topk=topk):
+            pass
+        self.generate([11] * 12, 0, ctx, max_audio_length_ms=4 * FRAME_MS, temperature=temperature, topk=topk)
+        self._model._kv_prompt = None                       # the synthetic prompt is nobody's prefix
+        torch.cuda.synchronize(self.device)
+
     # -- prompt assembly (generator.py:63-109) ------------------------------------------------
     def _text_ids(self, text: Union[str, Sequence[int]], speaker: int) -> List[int]:
         if not isinstance(text, str):
@@ -597,4 +614,7 @@ def load_csm_1b(device: str = "cuda", model_path: Optional[str] = None, mimi_pat
     model = Model.from_pretrained(model_path, device=device) if model_path else Model(csm_1b_args(), None, device=device)
     from .mimi import MimiCodec
     mimi = MimiCodec.from_pretrained(mimi_path, device=device)
-    return Generator(model, audio_tokenizer=mimi, max_batch_size=max_batch_size)
+    gen = Generator(model, audio_tokenizer=mimi, max_batch_size=max_batch_size)
+    if os.environ.get("CSM_NO_WARMUP") != "1":
+        gen.warm_up()
+    return gen
