@@ -180,6 +180,33 @@ def test_full_size_decode_vs_golden():
     _close(got[..., ::16], gold["chunks_stride16"], "full-size stateless chunks")
 
 
+def test_warm_up_leaves_no_trace_in_what_a_seeded_request_produces(tiny_codec):
+    """Generator.warm_up (called by load_csm_1b) runs a synthetic utterance through the streaming and the whole-utterance path so that
+    a process's one-time costs are not paid by the first request.  A request that seeds the sampler afterwards produces exactly what it
+    produces on a Generator that was never warmed, its whole prompt is prefilled (the synthetic prompt is nobody's prefix), and a
+    Generator without a codec skips the warm-up."""
+    from sesameai.generator import Generator, Segment
+    from sesameai.models import Model, csm_tiny_args
+    s, w, codec = tiny_codec
+    g = torch.Generator().manual_seed(2)
+    ctx = [Segment(speaker=1, text=torch.randint(0, 1000, (6,), generator=g).tolist(), audio_codes=torch.randint(0, 2048, (32, 9), generator=g))]
+    text = torch.randint(0, 1000, (5,), generator=g).tolist()
+    outs = []
+    for warm in (False, True):
+        model = Model(csm_tiny_args(), None, max_frames=64, max_prefill_rows=128)
+        gen = Generator(model, audio_tokenizer=codec)
+        if warm:
+            gen.warm_up()
+            assert model._kv_prompt is None
+        model.seed(5)
+        chunks = list(gen.generate_stream(text, 1, ctx, max_audio_length_ms=13 * 80, temperature=0.9, topk=50))
+        assert model.last_prefill_rows == 6 + 9 + 1 + 5
+        outs.append(torch.cat(chunks))
+    assert torch.equal(outs[0], outs[1])
+    bare = Generator(Model(csm_tiny_args(), None, max_frames=16, max_prefill_rows=128), audio_tokenizer=None)
+    bare.warm_up()                                                    # nothing to decode with: a no-op, not an error
+
+
 def test_generator_end_to_end_tiny(tiny_codec):
     """Generator.generate / generate_stream keep the reference's shapes: (n*1920,) fp32 audio."""
     from sesameai.generator import Generator, Segment
