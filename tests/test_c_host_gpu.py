@@ -1,0 +1,69 @@
+"""The C ABI driven from plain C (examples/c_host/csm_c_host.c: gcc, the HIP runtime and include/csm_hip.h -- no Python, no torch in
+the process) against the Python host on the same weights: the drop-in boundary is the shared library, not the shim."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "examples", "c_host", "csm_c_host")
+
+
+def _write_blob(path, model, tokens, mask):
+    """config, the prompt and every tensor of CsmWeights in declaration order (include/csm_hip.h), each as int64 byte count + data."""
+    def raw(t):
+        t = t.detach().cpu().contiguous()
+        return t.view(torch.uint8).numpy().tobytes() if t.dtype != torch.uint8 else t.numpy().tobytes()
+
+    layer = ("attn.q_proj.weight", "attn.k_proj.weight", "attn.v_proj.weight", "attn.output_proj.weight",
+             "mlp.w1.weight", "mlp.w2.weight", "mlp.w3.weight", "sa_norm.scale", "mlp_norm.scale")
+    names = ["text_embeddings.weight", "audio_embeddings.weight"]
+    names += [f"backbone.layers.{i}.{n}" for i in range(model.bb.num_layers) for n in layer] + ["backbone.norm.scale"]
+    names += [f"decoder.layers.{i}.{n}" for i in range(model.dec.num_layers) for n in layer] + ["decoder.norm.scale"]
+    names += ["projection.weight", "codebook0_head.weight", "audio_head_t", "bb_rope", "dec_rope"]
+    with open(path, "wb") as f:
+        f.write(b"CSMB")
+        f.write(bytes(model._cfg_struct()))
+        f.write(struct.pack("<i", tokens.shape[0]))
+        f.write(raw(tokens.to(torch.int32))); f.write(raw(mask.to(torch.uint8)))
+        for n in names:
+            b = raw(model._w[n])
+            f.write(struct.pack("<q", len(b))); f.write(b)
+
+
+def test_plain_c_host_produces_the_python_hosts_frames(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if not os.path.exists(HOST):
+        r = subprocess.run(["make", "-C", os.path.dirname(HOST)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    from sesameai.models import Model, csm_tiny_args, synthetic_state_dict
+    m = Model(csm_tiny_args(), synthetic_state_dict(csm_tiny_args(), seed=1234), max_frames=32, max_prefill_rows=64)
+    m.setup_caches(1)
+    g = torch.Generator().manual_seed(8)
+    S, n = 12, 9
+    tok = torch.zeros(S, 33, dtype=torch.long); msk = torch.zeros(S, 33, dtype=torch.bool)
+    tok[:5, 32] = torch.randint(0, 1000, (5,), generator=g); msk[:5, 32] = True
+    tok[5:, :32] = torch.randint(0, 2048, (S - 5, 32), generator=g); msk[5:, :32] = True
+    blob = str(tmp_path / "tiny.blob")
+    _write_blob(blob, m, tok, msk)
+    assert C.sizeof(type(m._cfg_struct())) == 2 * 28 + 12
+    # the Python host: the same calls through the shim
+    m.reset_caches(); m.seed(7)
+    m.prefill_prompt(tok.unsqueeze(0), msk.unsqueeze(0))
+    m.depth(1, 0.9, 50, commit=True)
+    for _ in range(n - 1):
+        m.step(1, 0.9, 50)
+    want, eos = m.read_frames(1)
+    # the C host, a process of its own (the system HIP runtime, no torch)
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD",)}
+    r = subprocess.run([HOST, blob, str(n)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    got = torch.tensor([[int(x) for x in ln.split()] for ln in lines[:n]], dtype=torch.int32)
+    assert lines[n] == f"eos_at {int(eos[0])}"
+    assert got.shape == (n, 32) and torch.equal(got, want[:, 0]), "the plain-C host and the Python host disagree"
