@@ -59,10 +59,10 @@ def test_create_rejects_bad_config_without_touching_the_gpu(lib):
 
 
 def test_plain_c_host_builds_against_the_header_and_the_library():
-    """examples/c_host/csm_c_host.c is the C ABI used from plain C (gcc -std=c11, include/csm_hip.h, -lcsm_hip): it must compile and
+    """examples/c_host/csm_c_host.c and mimi_c_host.c are the C ABI used from plain C (gcc -std=c11, include/csm_hip.h, -lcsm_hip): it must compile and
     link without a GPU; tests/test_c_host_gpu.py runs it beside the Python host."""
     import subprocess
     d = os.path.join(ROOT, "examples", "c_host")
     r = subprocess.run(["make", "-B", "-C", d], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert os.path.exists(os.path.join(d, "csm_c_host"))
+    assert os.path.exists(os.path.join(d, "csm_c_host")) and os.path.exists(os.path.join(d, "mimi_c_host"))

@@ -11,6 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "examples", "c_host", "csm_c_host")
+MIMI_HOST = os.path.join(ROOT, "examples", "c_host", "mimi_c_host")
 
 
 def _write_blob(path, model, tokens, mask):
@@ -67,3 +68,40 @@ def test_plain_c_host_produces_the_python_hosts_frames(tmp_path):
     got = torch.tensor([[int(x) for x in ln.split()] for ln in lines[:n]], dtype=torch.int32)
     assert lines[n] == f"eos_at {int(eos[0])}"
     assert got.shape == (n, 32) and torch.equal(got, want[:, 0]), "the plain-C host and the Python host disagree"
+
+
+def test_plain_c_codec_host_decodes_the_python_hosts_pcm(tmp_path):
+    """examples/c_host/mimi_c_host.c: include/mimi_hip.h from plain C.  The blob carries an image of the MimiWeights struct the shim
+    built (pointers = the shim's device addresses) and the tensors behind them; the C host re-points every field at its own copies,
+    decodes a 10-frame chunk three times (launch chain, capture, graph replay -- it checks they agree) and writes the PCM: the same
+    bytes as MimiCodec.decode in this process."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if not os.path.exists(MIMI_HOST):
+        r = subprocess.run(["make", "-C", os.path.dirname(MIMI_HOST)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    from sesameai.mimi import MimiCodec, mimi_tiny_args, synthetic_state_dict
+    sd = synthetic_state_dict(mimi_tiny_args(), seed=4321)
+    codec = MimiCodec(mimi_tiny_args(), sd, max_frames=16)
+    n0 = len(codec._keep)
+    cfg, w = codec._build(sd)                                      # a second image of the structs, with the tensors behind it in _keep[n0:]
+    tensors = codec._keep[n0:]
+    T = 10
+    codes = torch.randint(0, 2048, (1, 32, T), generator=torch.Generator().manual_seed(31))
+    blob, out = str(tmp_path / "codec.blob"), str(tmp_path / "out.pcm")
+    with open(blob, "wb") as f:
+        f.write(b"MIMB")
+        f.write(struct.pack("<ii", C.sizeof(cfg), C.sizeof(w)))
+        f.write(bytes(cfg)); f.write(bytes(w))
+        f.write(struct.pack("<i", len(tensors)))
+        for t in tensors:
+            b = t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes()
+            f.write(struct.pack("<Qq", t.data_ptr(), len(b))); f.write(b)
+        f.write(struct.pack("<i", T))
+        f.write(codes[0].to(torch.int32).contiguous().numpy().tobytes())
+    want = codec.decode(codes)[0, 0].cpu()
+    r = subprocess.run([MIMI_HOST, blob, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import numpy as np
+    got = torch.from_numpy(np.fromfile(out, dtype=np.float32))
+    assert got.shape == want.shape and torch.equal(got, want), f"max |d| {(got - want).abs().max().item():.3e}"
