@@ -106,6 +106,15 @@ def host_description(threads_used):
     return {"cpu_model": model, "logical_cpus": os.cpu_count(), "usable_cpus": usable, "cgroup_cpu_quota": cpu_quota(), "threads_used": threads_used}
 
 
+def device_pci_bus_id(index):
+    """"domain:bus:device" of a visible GPU from its device properties (no GPU work) + its uuid: what tells N ranks on N GPUs from N ranks on one."""
+    p = torch.cuda.get_device_properties(index)
+    try:
+        return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x} uuid {p.uuid}"
+    except AttributeError:
+        return None
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -137,55 +146,65 @@ def dominant_kernels(model, B, temperature, topk, reps=20):
 
 
 def cpu_worker(args):
-    """Child process: the oracle (CPU restatement of the reference's eager `-d cpu` bf16 graph)
-    on the same S=190 prompt; prints one JSON line per completed frame until the budget is spent."""
+    """Child process: the oracle (CPU restatement of the reference's eager `-d cpu` bf16 graph) on the headline's S=190 prompt
+    (BASELINE config 2) until the budget is spent, then on BASELINE config 1's shape (16 text tokens, no context, up to 25 frames =
+    2 s of audio; SURVEY.md 8d asks for both) on a smaller budget -- one process, so the 1.5 B weights are drawn once.  Prints one
+    JSON line per completed frame."""
     from oracle import csm_ref as C
     shape = C.csm_1b()
     w = C.make_weights(shape, seed=1234)
     m = C.OracleModel(shape, w)
     m.setup_caches(1)
-    tokens, mask = synthetic_prompt(args, 1, shape.text_vocab_size)
-    torch.manual_seed(0)
-    cur_t, cur_m = tokens, mask
-    pos = torch.arange(tokens.shape[1]).unsqueeze(0)
-    t0 = time.time()
-    n = 0
-    while time.time() - t0 < args.cpu_budget and n < args.cpu_frames:
-        s = m.generate_frame(cur_t, cur_m, pos, args.temperature, args.topk)
-        n += 1
-        print(json.dumps({"frames": n, "elapsed": time.time() - t0, "threads": torch.get_num_threads()}), flush=True)
-        cur_t = torch.cat([s.long(), torch.zeros(1, 1).long()], dim=1).unsqueeze(1)
-        cur_m = torch.cat([torch.ones_like(s).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
-        pos = pos[:, -1:] + 1
+    ids = torch.randint(0, shape.text_vocab_size, (16,), generator=torch.Generator().manual_seed(2025)).tolist()
+    t1, m1 = C.build_prompt([(ids, None)])
+    runs = [("config2", synthetic_prompt(args, 1, shape.text_vocab_size), args.cpu_budget, args.cpu_frames),
+            ("config1", (t1.unsqueeze(0), m1.unsqueeze(0)), min(args.cpu_budget, 8.0), 25)]
+    for name, (tokens, mask), budget, max_frames in runs:
+        torch.manual_seed(0)
+        m.reset_caches()
+        cur_t, cur_m = tokens, mask
+        pos = torch.arange(tokens.shape[1]).unsqueeze(0)
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < budget and n < max_frames:
+            s = m.generate_frame(cur_t, cur_m, pos, args.temperature, args.topk)
+            n += 1
+            print(json.dumps({"shape": name, "rows": int(tokens.shape[1]), "frames": n, "elapsed": time.time() - t0, "threads": torch.get_num_threads()}), flush=True)
+            cur_t = torch.cat([s.long(), torch.zeros(1, 1).long()], dim=1).unsqueeze(1)
+            cur_m = torch.cat([torch.ones_like(s).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
+            pos = pos[:, -1:] + 1
 
 
 def cpu_baseline(args):
-    """Runs cpu_worker in a child with a hard wall-clock limit (killed by PID if it overruns) and
-    turns its last progress line into the cpu_baseline object."""
+    """Runs cpu_worker in a child with a hard wall-clock limit (killed by PID if it overruns) and turns its progress lines into the
+    cpu_baseline object (the headline shape; `config1` = the same for BASELINE config 1's shape)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-budget", str(args.cpu_budget),
            "--cpu-frames", str(args.cpu_frames), "--temperature", str(args.temperature), "--topk", str(args.topk)]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(args.cpu_threads))
-    log(f"cpu baseline: oracle on {args.cpu_threads} host threads, budget {args.cpu_budget}s")
+    log(f"cpu baseline: oracle on {args.cpu_threads} host threads, budget {args.cpu_budget}s (+ the config-1 shape)")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
     try:
-        out, _ = proc.communicate(timeout=args.cpu_budget + 120)
+        out, _ = proc.communicate(timeout=2 * args.cpu_budget + 180)
     except subprocess.TimeoutExpired:
         proc.kill()
         out, _ = proc.communicate()
-    lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
-    if not lines:
-        return dict(value=None, unit="frames/s", cores=args.cpu_threads, kind="port", host=host_description(args.cpu_threads),
-                    sample="oracle did not finish one frame within the budget")
-    last = lines[-1]
-    first = lines[0]
-    decode = (last["frames"] - 1) / (last["elapsed"] - first["elapsed"]) if last["frames"] > 1 else None
-    return dict(value=round(last["frames"] / last["elapsed"], 3), unit="frames/s", cores=last["threads"], kind="port",
-                host=host_description(last["threads"]),
-                decode_only_frames_per_s=round(decode, 3) if decode else None,
-                sample=f"oracle/csm_ref.py (PyTorch-CPU bf16 restatement of the reference -d cpu graph), same S=190 prompt: "
-                       f"frame 0 incl. prefill {first['elapsed']:.2f}s, {last['frames']} frames in {last['elapsed']:.1f}s, "
-                       f"torch {torch.__version__}")
+    every = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+    def summarise(lines, what):
+        if not lines:
+            return dict(value=None, unit="frames/s", cores=args.cpu_threads, kind="port", sample=f"{what}: the oracle did not finish one frame within the budget")
+        first, last = lines[0], lines[-1]
+        decode = (last["frames"] - 1) / (last["elapsed"] - first["elapsed"]) if last["frames"] > 1 else None
+        return dict(value=round(last["frames"] / last["elapsed"], 3), unit="frames/s", cores=last["threads"], kind="port",
+                    decode_only_frames_per_s=round(decode, 3) if decode else None,
+                    sample=f"oracle/csm_ref.py (PyTorch-CPU bf16 restatement of the reference -d cpu graph), {what}: "
+                           f"frame 0 incl. prefill of {first['rows']} rows {first['elapsed']:.2f}s, {last['frames']} frames in {last['elapsed']:.1f}s, "
+                           f"torch {torch.__version__}")
+    res = summarise([l for l in every if l.get("shape") == "config2"], "same S=190 prompt as the headline (BASELINE config 2)")
+    res["host"] = host_description(res["cores"])
+    res["config1"] = summarise([l for l in every if l.get("shape") == "config1"], "BASELINE config 1 shape: 16 text tokens, no context, up to 25 frames")
+    return res
 
 
 def spawn_ranks(args, argv):
@@ -479,8 +498,11 @@ def main():
         cpu_worker(args)
         return
     q = cpu_quota()
-    if q and torch.get_num_threads() > q:
-        torch.set_num_threads(q)                   # host-side set-up (synthetic weights) on no more threads than the container may run
+    # host-side set-up (synthetic weights) on no more threads than the container may run -- and, with N ranks on the node, no more than
+    # this rank's SHARE of the quota: 8 ranks x 16 threads on a quota of 16 is the throttling DESIGN.md describes for one process
+    share = max(1, (q or (os.cpu_count() or 1)) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))
+    if torch.get_num_threads() > share:
+        torch.set_num_threads(share)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args, sys.argv[1:])            # never returns
@@ -514,6 +536,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == world, (dist.get_world_size(), world)
+        world = dist.get_world_size()              # n_gpus of the line = the ranks the process group really has
 
     from sesameai.models import Model, csm_1b_args, csm_tiny_args, state_dict_layout, synthetic_state_dict
     log(f"rank {rank}/{world}: building weights")
@@ -570,6 +594,7 @@ def main():
     wall = time.perf_counter() - t0
     log(f"timed {args.steps} frames: {wall * 1e3:.1f} ms")
     ev_ms = ev0.elapsed_time(ev1)          # HIP events on the stream the frame graph runs on
+    rank_wall = wall                       # this rank's own time; `wall` becomes the slowest rank's below
     if dist is not None:
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -698,6 +723,23 @@ def main():
     }
     if bcast is not None:
         out["weight_broadcast"] = bcast
+    if dist is not None:
+        # what makes the N > 1 line self-proving: how many ranks the process group really has and which physical GPU each one ran on
+        # (index + PCI bus id: N ranks on N distinct devices), every rank's own step time and frame count, its view of the broadcast
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "device_index": dev.index, "pci_bus_id": device_pci_bus_id(dev.index), "device_name": props.name,
+                "ms_per_step": round(rank_wall * 1e3 / args.steps, 4), "frames": int(B * args.steps),
+                "broadcast_GBps": bcast["csm_GBps"] if bcast else None, "host_threads": torch.get_num_threads()}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        out["ranks_seen"] = dist.get_world_size()
+        out["ranks"] = every
+        out["distinct_gpus"] = len({r["pci_bus_id"] or f"index {r['device_index']}" for r in every})
+        out["collective_backend"] = dist.get_backend()
+        try:
+            out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            out["rccl_version"] = None
     if world == 1 and B == 1 and not args.tiny and not args.no_extras and args.weights == "bf16":
         del model
         out["extras"] = extras_legs(args, margs, sd, dev)
@@ -712,12 +754,27 @@ def main():
         res["aggregate_frames_per_s"] = round(world * 32 * args.extra_steps / float(t4.item()), 1)
         res["slowest_rank_ms_per_step"] = round(float(t4.item()) * 1e3 / args.extra_steps, 4)
         out["extras"] = {"config4": res}
+    if dist is not None:
+        dist.barrier()                     # every rank is through its GPU work; from here on nobody holds a GPU busy
     if rank == 0:
-        # the oracle beside it, on this host's cores, after the timed region (the other ranks wait at the barrier below)
+        # the oracle beside it, on this host's cores, after the timed region.  The other ranks wait for it ASLEEP -- a key in the
+        # rendezvous store, polled with sleeps -- not in an RCCL barrier, whose waiters spin on host cores and GPU queues beside the
+        # CPU run that is being timed
         out["cpu_baseline"] = cpu_baseline(args) if not (args.no_cpu_baseline or args.tiny) else None
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
+        store = getattr(dist.distributed_c10d, "_get_default_store", lambda: None)()
+        if store is not None:
+            if rank == 0:
+                store.set("bench_line_printed", "1")
+            else:
+                while True:
+                    try:
+                        if store.check(["bench_line_printed"]):
+                            break
+                    except Exception:
+                        break
+                    time.sleep(0.5)
         dist.destroy_process_group()
 
 

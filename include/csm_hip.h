@@ -18,6 +18,7 @@
 #ifndef CSM_HIP_H
 #define CSM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -170,19 +171,33 @@ int csm_prefill_slot(csm_handle h, int slot, const int32_t* tokens, const uint8_
  * last row (an inject node in the frame-step graph; the slot's position stays for that one step and its EOS word restarts).
  *   csm_refill_begin:   embeds the prompt rows (tokens [S][33] / mask [S][33] / pos [S], dev; pos must stay valid until the refill
  *                       completes) and parks the slot: until completion its rows of the frame steps are placeholders whose frames
- *                       the caller ignores.  One refill at a time per handle (CSM_E_STATE otherwise).  Needs max_batch >= 3.
+ *                       the caller ignores and its position is HELD at S (however many steps the prompt takes, it never nears
+ *                       max_seq).  One refill at a time per handle (CSM_E_STATE otherwise).  Needs csm_refill_supported(h, max_batch).
  *   csm_refill_advance: runs up to max_layers more backbone layers of the pending prompt.  Returns 1 when the prompt is complete --
  *                       the NEXT csm_frame_step then yields the utterance's frame 0 in that slot's row, at that step's global frame
  *                       index -- 0 while layers remain, < 0 on error.  Call both on the stream that runs the frame steps.
+ *   csm_refill_supported: 1 when frame steps of B rows carry the inject node (the matrix-core decode path: B >= 3 by default,
+ *                       CSM_WIDE / CSM_WIDE_MIN move it), else 0 -- the ONE predicate begin, the frame step and the host share.
+ *                       While a refill is parked or waits to be sampled, csm_frame_step with a B for which this is 0 is refused
+ *                       (CSM_E_STATE) instead of stepping the slot like a generating one; csm_reset_slots / csm_prefill_slot on
+ *                       the slot whose prompt is still running are refused too, and drop a completed-but-unsampled refill.
  * The other slots' frames are bit-identical to an undisturbed run (their rows never see the refill).                          */
+int csm_refill_supported(csm_handle h, int B);
 int csm_refill_begin(csm_handle h, int slot, const int32_t* tokens, const uint8_t* mask, const int32_t* pos, int S, void* stream);
 int csm_refill_advance(csm_handle h, int max_layers, void* stream);
 
-/* Why there is no csm_broadcast_weights here (SURVEY.md 8b lists one): the multi-GPU layout is replicas with ONE start-up
- * broadcast of a flat weight blob and no per-step collective.  The communicator that does it belongs to
- * torch.distributed (backend "nccl" = RCCL over xGMI; sesameai/parallel.py), which owns the process's single RCCL instance; a
- * second communicator created by this library from its own copy of librccl would duplicate the bootstrap and the xGMI rings for
- * one collective that is not on the hot path.  The C ABI therefore takes device pointers that are already populated.            */
+/* Start-up weight broadcast (SURVEY.md 8b's csm_broadcast_weights; 8e: "one RCCL ncclBroadcast of the packed weight blob at start-up
+ * over xGMI ... no per-step collective").  The reference has no counterpart (it is single-GPU: every process downloads its own
+ * checkpoint, sesameai/generator.py:330-346); in the replica layout rank `root` holds the weights and every other
+ * rank's blob -- `bytes` bytes of device memory at the same layout -- is filled by ONE in-place ncclBroadcast on `stream`.
+ * The communicator is the CALLER's (an ncclComm_t made with ncclCommInitRank / ncclCommInitAll, passed as void*): this library does
+ * not link RCCL and never creates a communicator -- it resolves ncclBroadcast from the RCCL instance already loaded in the process
+ * (global scope, else the loaded librccl.so.1 by soname), i.e. the one the communicator belongs to, so a process never holds two
+ * RCCL instances / bootstraps / sets of xGMI rings.  CSM_E_STATE when no RCCL is loaded, CSM_E_HIP when the collective fails
+ * (csm_last_error(NULL) has the text).  Python hosts that use torch.distributed keep using dist.broadcast on the same blob
+ * (sesameai/parallel.py: torch owns that communicator and does not hand out the ncclComm_t); plain-C hosts call this
+ * (examples/c_host/csm_c_host.c).  The CsmWeights pointers handed to csm_create then point into the blob.      */
+int csm_broadcast_weights(void* dev_blob, size_t bytes, void* rccl_comm, int root, void* stream);
 
 /* History readback: frames [first, first + n) as [n][B][32] i32 into host memory (synchronises the stream);
  * eos_at[b] = global index of the first all-zero frame of sequence b, or -1.  The history is a RING of max_frames frames

@@ -22,6 +22,11 @@ Files (all torch.save'd dicts of small tensors):
                     segments), 2 frames; and a 1700-row prompt: the prompt frame (p = 1699) and one step frame (p = 1700).
   csm1b_cfg5b.pt    config 5 batched at B = 4 (four different 1334-row prompts), 2 frames of the batched oracle.
   csm1b_cfg5c.pt    config 5 at B = 32 (the batch SURVEY.md 8d names): top-8 logits / codes / margins only, prompts by seed.
+  csm1b_decisive.pt CSM-1B with the DECISIVE synthetic checkpoint (oracle.csm_ref.decisive_weights): the oracle's FREE-RUNNING greedy
+                    codes -- 64 frames at B = 1 for the 190-row and the 1334-row prompt, 16 frames at B = 32, twelve utterances of mixed
+                    lengths for the refilled batch -- each with bf16 and with fp8-dequantised weights, every row's top-1 / top-2 margin
+                    asserted >= 4 x the oracle's bf16-vs-fp32 gap on that run; + the Mimi oracle's PCM of the first clip.
+  tiny_decisive.pt  the same for the tiny shapes (full logits of the first frames kept).
 """
 from __future__ import annotations
 
@@ -132,6 +137,99 @@ def frames_golden_batch(shape: C.CsmShape, weights, toks, msks, n_frames: int):
                 margin=torch.stack(margin))
 
 
+@torch.inference_mode()
+def free_run(shape: C.CsmShape, weights, toks, msks, n_frames: int, what: str):
+    """The oracle's FREE-RUNNING greedy loop (generator.py:283-294 with topk = 1) on B equal-length prompts, beside an fp32 oracle that is
+    fed the bf16 oracle's codes: codes [n][B][32], the smallest top-1 / top-2 margin and the largest bf16-vs-fp32 logit gap per frame.
+    Asserts what the decisive checkpoint is for: every decision's margin >= 4 x the gap, and the trajectory the construction implies."""
+    if toks.dim() == 2:
+        toks, msks = toks.unsqueeze(0), msks.unsqueeze(0)
+    B = toks.shape[0]
+    m = C.OracleModel(shape, weights); m.setup_caches(B)
+    m32 = C.OracleModel(shape, {k: v.float() for k, v in weights.items()}, dtype=torch.float32); m32.setup_caches(B)
+    cur_t, cur_m = toks.long(), msks
+    pos = torch.arange(toks.size(1)).unsqueeze(0).repeat(B, 1)
+    codes, margins, gaps = [], [], []
+    t0 = time.time()
+    for f in range(n_frames):
+        tr, tr32 = C.FrameTrace(), C.FrameTrace()
+        s = m.generate_frame(cur_t, cur_m, pos, 1.0, 1, greedy=True, trace=tr)
+        m32.generate_frame(cur_t, cur_m, pos, 1.0, 1, greedy=True, forced=s, trace=tr32)
+        lg, lg32 = torch.stack(tr.logits, 0).float(), torch.stack(tr32.logits, 0)       # [32][B][V]
+        top2 = torch.topk(lg, 2, dim=-1)[0]
+        margin, gap = (top2[..., 0] - top2[..., 1]), (lg - lg32).abs().amax(dim=-1)
+        assert bool((margin >= 4.0 * gap.max()).all()), f"{what} frame {f}: margin {float(margin.min()):.3f} < 4 x gap {float(gap.max()):.4f}"
+        assert not bool((s == 0).all(dim=1).any()), "an all-zero (EOS) frame"
+        codes.append(s.clone()); margins.append(margin.min()); gaps.append(gap.max())
+        cur_t = torch.cat([s.long(), torch.zeros(B, 1).long()], dim=1).unsqueeze(1)
+        cur_m = torch.cat([torch.ones_like(s).bool(), torch.zeros(B, 1).bool()], dim=1).unsqueeze(1)
+        pos = pos[:, -1:] + 1
+    codes = torch.stack(codes)
+    print(f"  {what}: {n_frames} frames x {B} in {time.time() - t0:.0f}s, smallest margin {float(min(margins)):.3f}, largest gap "
+          f"{float(max(gaps)):.4f} ({float(min(margins)) / float(max(gaps)):.0f} x)", flush=True)
+    return dict(codes=codes.to(torch.int16), min_margin=torch.stack(margins), max_gap=torch.stack(gaps))
+
+
+def decisive_many_prompts(shape: C.CsmShape):
+    """Twelve prompts of mixed lengths and per-utterance frame limits for the continuously refilled batch of 8."""
+    spec = [(2100 + i, (8 + 5 * i) % 37 + 4, (17 * i) % 90 + 6, 6 + i % 5, 12 + (7 * i) % 23) for i in range(12)]
+    return [(bench_prompt(shape, seed, 1, ct, cf, gt), lim) for seed, ct, cf, gt, lim in spec]
+
+
+def decisive_golden(shape: C.CsmShape, seed: int, full: bool):
+    gold = dict(weight_seed=seed)
+    w = C.make_weights(shape, seed=seed, flavour="decisive")
+    for tag, wts in (("bf16", w), ("fp8", None)):
+        if wts is None:
+            wts = C.fp8_dequantized(w)
+        if full:
+            n1, n32 = 64, 16
+            p190 = bench_prompt(shape, 2025)
+            p1334 = bench_prompt(shape, 5000, segments=10, ctx_text=30, ctx_frames=100)
+            b32 = [bench_prompt(shape, 2025 + b) for b in range(32)]
+        else:
+            n1, n32 = 24, 8
+            p190 = toy_prompt(shape, 11, 6, 5)
+            p1334 = toy_prompt(shape, 12, 20, 60)
+            b32 = [toy_prompt(shape, 100 + b, 6, 5) for b in range(5)]
+        for name, (tok, msk) in (("s190", p190), ("s1334", p1334)):
+            g = free_run(shape, wts, tok, msk, n1, f"{tag} {name}")
+            want = C.decisive_expected_codes(shape, seed, int(tok[-1, 32]), n1)
+            assert torch.equal(g["codes"][:, 0].to(torch.int32), want), "the oracle left the trajectory the construction implies"
+            g["prompt_rows"] = tok.shape[0]
+            gold[f"{tag}_{name}"] = g
+        gold[f"{tag}_b32"] = free_run(shape, wts, torch.stack([p[0] for p in b32]), torch.stack([p[1] for p in b32]), n32, f"{tag} b32")
+        if tag == "bf16":
+            many = []
+            for i, ((tok, msk), lim) in enumerate(decisive_many_prompts(shape)):
+                g = free_run(shape, wts, tok, msk, lim, f"{tag} many[{i}] S={tok.shape[0]}")
+                many.append(g["codes"][:, 0].clone())
+            gold["bf16_many"] = many
+    return decisive_finish(gold, w, full)
+
+
+DECISIVE_CHECKSUM_NAMES = ["text_embeddings.weight", "audio_embeddings.weight", "codebook0_head.weight", "audio_head", "projection.weight",
+                           "backbone.layers.7.attn.output_proj.weight", "backbone.layers.15.mlp.w2.weight", "decoder.layers.3.mlp.w2.weight"]
+
+
+def decisive_finish(gold, w, full: bool):
+    """What the golden carries beside the codes: checksums of the re-derived tensors (the GPU test builds the checkpoint with the
+    product's own generator and must get the same ones) and, full size, the Mimi oracle's PCM of the first clip -- whole
+    (generator.py:299) and as the stateless 10-frame chunks generate_stream yields (generator.py:119-210; every 4th sample kept)."""
+    names = [n for n in DECISIVE_CHECKSUM_NAMES if n in w]
+    gold["weight_checksum_names"] = names
+    gold["weight_checksum"] = torch.stack([w[n].float().abs().sum() for n in names])
+    if full:
+        s = M.mimi_full()
+        mw = M.make_weights(s, seed=4321)
+        codes = gold["bf16_s190"]["codes"][:, 0].long().t().unsqueeze(0)            # (1, 32, T)
+        gold["pcm_s190"] = M.decode(s, mw, codes)[0, 0].clone()
+        gold["pcm_chunks_stride"] = 4
+        gold["pcm_s190_chunks"] = M.decode_stateless_chunks(s, mw, codes, 10)[0, 0][::4].clone()
+        gold["mimi_weight_seed"] = 4321
+    return gold
+
+
 def sampler_cases():
     g = torch.Generator().manual_seed(77)
     V = 2051
@@ -182,6 +280,15 @@ def main():
                             pcm_tail=whole[..., -4096:].clone(),
                             chunks_stride16=chunks[..., ::16].clone(),
                             rms=whole.pow(2).mean().sqrt()), os.path.join(OUT, f"mimi_{name}.pt"))
+    if want("tinydecisive"):
+        torch.save(decisive_golden(C.csm_tiny(), 1234, full=False), os.path.join(OUT, "tiny_decisive.pt"))
+    if want("decisive"):
+        torch.save(decisive_golden(C.csm_1b(), 1234, full=True), os.path.join(OUT, "csm1b_decisive.pt"))
+    if a.only == "decisivefinish":          # re-derive the checksums / PCM of existing files without re-running the trajectories
+        for fname, shape, full in (("tiny_decisive.pt", C.csm_tiny(), False), ("csm1b_decisive.pt", C.csm_1b(), True)):
+            path = os.path.join(OUT, fname)
+            gold = torch.load(path)
+            torch.save(decisive_finish(gold, C.make_weights(shape, seed=int(gold["weight_seed"]), flavour="decisive"), full), path)
     if want("csm1b"):
         shape = C.csm_1b()
         t0 = time.time()

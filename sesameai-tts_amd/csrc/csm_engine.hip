@@ -81,6 +81,7 @@ struct CsmModel {
     int* fresh;                         // [max_batch] device flags: the slot's next frame step yields its frame 0 from rf_last
     bf16_t *rf_h, *rf_xn, *rf_last;     // [max_rows][d_bb] x 2, [max_batch][2 d_bb] final-normed last prompt row per slot (dec_in layout)
     int rf_slot, rf_S, rf_layer;        // pending refill: slot (-1 = none), prompt rows, next layer to run
+    int rf_fresh_slot;                  // slot whose completed refill waits for a frame step to sample its frame 0 (-1 = none)
     const int* rf_pos;                  // the caller's position array of the pending refill (dev, valid until the refill completes)
     int device;                         // the GPU this handle lives on (csm_generate_frame_s1 makes it current itself)
     int host_frames;                    // frames launched since reset (host mirror); the history is a ring of max_frames rows
@@ -870,6 +871,11 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
     return hipSuccess;
 }
 
+// ONE predicate for the refill beside the frame loop: a frame step of B rows carries the inject node -- and therefore honours
+// the slots' fresh / parked flags in k_advance -- exactly when this holds; csm_refill_begin, csm_refill_supported and csm_frame_step use it too.
+static inline bool refill_beside_ok(const CsmModel* m, int B) { return m->wide_path && B >= m->wide_min && B <= m->max_batch; }
+static inline bool frame_injects(const CsmModel* m, int B) { return m->rf_last != nullptr && refill_beside_ok(m, B); }
+
 static hipError_t launch_advance(CsmModel* m, int B, const int* fed, int pos_inc, hipStream_t st) {
     AdvanceArgs a;
     a.frame = m->frame; a.B = B; a.ncb = m->cfg.n_codebooks; a.bstride = m->max_batch; a.history = m->history;
@@ -877,7 +883,7 @@ static hipError_t launch_advance(CsmModel* m, int B, const int* fed, int pos_inc
     a.cur_mask = m->cur_mask; a.cur_pos = m->cur_pos; a.rng = m->rng; a.out_frame = nullptr; a.fed = fed; a.pos_inc = pos_inc;
     a.max_seq = m->cfg.backbone.max_seq; a.overflow = m->n_frames + 1;
     a.err0 = m->p_state + 1; a.err1 = m->b_state + 1;
-    a.fresh = pos_inc ? m->fresh : nullptr;
+    a.fresh = (pos_inc && frame_injects(m, B)) ? m->fresh : nullptr;        // only a step that carried the inject node consumes the flags
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(256), 0, st, a);
     return hipGetLastError();
 }
@@ -1244,7 +1250,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     ALLOC(m->frame_save, (size_t)ncb * 4);
     ALLOC(m->fresh, (size_t)max_batch * 4);
     HIPCHK((CsmModel*)nullptr, hipMemset(m->fresh, 0, (size_t)max_batch * 4));
-    m->rf_h = m->rf_xn = m->rf_last = nullptr; m->rf_slot = -1; m->rf_S = 0; m->rf_layer = 0; m->rf_pos = nullptr;
+    m->rf_h = m->rf_xn = m->rf_last = nullptr; m->rf_slot = -1; m->rf_fresh_slot = -1; m->rf_S = 0; m->rf_layer = 0; m->rf_pos = nullptr;
     ALLOC(m->dec_pos, (size_t)(ncb + 1) * 2 * max_batch * 4);
     ALLOC(m->slot_scratch, (size_t)max_batch * 4);
     ALLOC(m->p_state, 16);
@@ -1352,6 +1358,40 @@ extern "C" void csm_destroy(csm_handle m) {
 
 extern "C" const char* csm_last_error(csm_handle m) { return m ? m->err.c_str() : g_create_err.c_str(); }
 
+// ---------------------------------------------------------------------------------------
+// start-up weight broadcast on a communicator the CALLER owns (SURVEY.md 8b export list; 8e: one ncclBroadcast of the packed blob,
+// no per-step collective).  This library does not link RCCL: the entry point is resolved, at the first call, from the RCCL instance
+// that is ALREADY in the process -- the one that made the caller's communicator (a C host linked with -lrccl: the global scope; a
+// torch process: torch's bundled librccl.so.1, found by soname without loading anything) -- so there is never a second instance.
+// ---------------------------------------------------------------------------------------
+#include <dlfcn.h>
+typedef int (*nccl_broadcast_fn)(const void* sendbuff, void* recvbuff, size_t count, int datatype, int root, void* comm, hipStream_t stream);
+typedef const char* (*nccl_errstr_fn)(int);
+static void* rccl_symbol(const char* name) {
+    void* f = dlsym(RTLD_DEFAULT, name);
+    if (f) return f;
+    for (const char* so : {"librccl.so.1", "librccl.so"}) {
+        void* h = dlopen(so, RTLD_NOLOAD | RTLD_NOW);           // only an instance that is already loaded
+        if (h && (f = dlsym(h, name))) return f;
+    }
+    return nullptr;
+}
+extern "C" int csm_broadcast_weights(void* dev_blob, size_t bytes, void* rccl_comm, int root, void* stream) {
+    if (!dev_blob || !rccl_comm || root < 0) return fail(nullptr, CSM_E_INVALID, "csm_broadcast_weights: null blob / communicator or negative root");
+    static nccl_broadcast_fn bcast = (nccl_broadcast_fn)rccl_symbol("ncclBroadcast");
+    if (!bcast) return fail(nullptr, CSM_E_STATE, "csm_broadcast_weights: no RCCL instance is loaded in this process (the caller creates the communicator, "
+                                                  "so its librccl must already be here)");
+    if (bytes == 0) return CSM_OK;
+    const int rc = bcast(dev_blob, dev_blob, bytes, /*ncclUint8*/ 1, root, rccl_comm, (hipStream_t)stream);     // in place: root sends, the others receive
+    if (rc != 0) {
+        static nccl_errstr_fn es = (nccl_errstr_fn)rccl_symbol("ncclGetErrorString");
+        static std::string msg;
+        msg = std::string("csm_broadcast_weights: ncclBroadcast failed: ") + (es ? es(rc) : "?");
+        return fail(nullptr, CSM_E_HIP, msg.c_str());
+    }
+    return CSM_OK;
+}
+
 // After a launch that gave up (bounded spin timed out) stale granules may carry tags the next launch would accept: move the
 // tag epoch far ahead and clear the error word, so the handle is usable again after csm_reset.
 __global__ void k_persist_recover(uint32_t* state) {
@@ -1368,7 +1408,7 @@ extern "C" int csm_reset(csm_handle m, void* stream) {
     HIPCHK(m, hipMemsetAsync(m->cur_pos, 0, (size_t)m->max_batch * 4, st));
     HIPCHK(m, hipMemsetAsync(m->eos_at, 0xff, (size_t)m->max_batch * 4, st));
     HIPCHK(m, hipMemsetAsync(m->fresh, 0, (size_t)m->max_batch * 4, st));
-    m->host_frames = 0; m->have_last = false; m->rf_slot = -1;
+    m->host_frames = 0; m->have_last = false; m->rf_slot = -1; m->rf_fresh_slot = -1;
     return CSM_OK;
 }
 
@@ -1429,7 +1469,7 @@ extern "C" int csm_copy_frame(csm_handle m, int B, int32_t* out_frame, void* str
 
 __global__ void k_inject_fresh(const int* fresh, const bf16_t* rf_last, bf16_t* dec_in, int stride, int d) {
     const int b = blockIdx.x;
-    if (fresh[b] == 0) return;
+    if (fresh[b] != 1) return;                         // 0 = generating, 2 = parked (its prompt is still running): nothing to inject
     for (int i = threadIdx.x; i < d / 8; i += blockDim.x)
         reinterpret_cast<uint4*>(dec_in + (long)b * stride)[i] = reinterpret_cast<const uint4*>(rf_last + (long)b * stride)[i];
 }
@@ -1438,7 +1478,7 @@ static hipError_t enqueue_frame(CsmModel* m, int B, float temperature, int topk,
     hipError_t e;
     if ((e = launch_embed(m, m->cur_tokens, m->cur_mask, B, st)) != hipSuccess) return e;
     if ((e = run_stack(m, m->bb, m->h, m->q, m->att, m->act, B, 1, m->cur_pos, -1, st)) != hipSuccess) return e;
-    if (m->rf_last != nullptr && B >= m->wide_min && m->wide_path) {
+    if (frame_injects(m, B)) {
         // slots whose prompt was prefilled beside the frame loop take their backbone output from that prompt's last row (one block per
         // slot; a no-op unless the slot's flag is up).  Only handles that have used csm_refill_begin carry this node.
         hipLaunchKernelGGL(k_inject_fresh, dim3(B), dim3(256), 0, st, m->fresh, m->rf_last, m->dec_in, 2 * m->cfg.backbone.dim, m->cfg.backbone.dim);
@@ -1451,7 +1491,11 @@ static hipError_t enqueue_frame(CsmModel* m, int B, float temperature, int topk,
 extern "C" int csm_frame_step(csm_handle m, int B, float temperature, int topk, int use_graph, void* stream) {
     if (!m || B < 1 || B > m->max_batch) return fail(m, CSM_E_INVALID, "csm_frame_step: bad batch");
     if (!(temperature > 0.f) || topk < 1) return fail(m, CSM_E_INVALID, "csm_frame_step: temperature must be > 0 and topk >= 1");
+    if ((m->rf_slot >= 0 || m->rf_fresh_slot >= 0) && !frame_injects(m, B))
+        return fail(m, CSM_E_STATE, "csm_frame_step: a refill beside the frame loop is pending and a step of this batch size does not take the matrix-core path "
+                                    "(csm_refill_supported(h, B) == 0): its parked / fresh slot would be stepped like a generating one");
     hipStream_t st = (hipStream_t)stream;
+    if (m->rf_fresh_slot >= 0 && m->rf_fresh_slot < B) m->rf_fresh_slot = -1;       // this step samples the joined utterance's frame 0
     if (!use_graph) {
         HIPCHK(m, enqueue_frame(m, B, temperature, topk, st));
     } else {
@@ -1504,13 +1548,18 @@ __global__ void k_copy_i32(const int* __restrict__ src, int* __restrict__ dst, i
 extern "C" int csm_generate_frame_s1(csm_handle m, const int64_t* tokens, const uint8_t* mask, const int64_t* pos, int B,
                                      float temperature, int topk, int32_t* out_frame, void* stream) {
     if (!m || !tokens || !mask || !pos || !out_frame || B < 1 || B > m->max_batch) return fail(m, CSM_E_INVALID, "csm_generate_frame_s1: bad argument");
+    // everything csm_frame_step would refuse is refused BEFORE the step inputs are overwritten
+    if (!(temperature > 0.f) || topk < 1) return fail(m, CSM_E_INVALID, "csm_generate_frame_s1: temperature must be > 0 and topk >= 1");
+    if ((m->rf_slot >= 0 || m->rf_fresh_slot >= 0) && !frame_injects(m, B)) return csm_frame_step(m, B, temperature, topk, 1, stream);   // (reports the state error)
     int dev = m->device;
     (void)hipGetDevice(&dev);
-    if (dev != m->device) HIPCHK(m, hipSetDevice(m->device));
+    if (dev != m->device && hipSetDevice(m->device) != hipSuccess) return fail(m, CSM_E_HIP, "csm_generate_frame_s1: cannot make the handle's device current");
     hipStream_t st = (hipStream_t)stream;
+    int rc = CSM_OK;
     hipLaunchKernelGGL(k_stage_s1, dim3(1), dim3(256), 0, st, (const long long*)tokens, mask, (const long long*)pos,
                        B * (m->cfg.n_codebooks + 1), B, m->cur_tokens, m->cur_mask, m->cur_pos, m->cfg.backbone.max_seq, m->n_frames + 1);
-    int rc = csm_frame_step(m, B, temperature, topk, 1, stream);
+    if (hipGetLastError() != hipSuccess) rc = fail(m, CSM_E_HIP, "csm_generate_frame_s1: staging launch failed");
+    if (rc == CSM_OK) rc = csm_frame_step(m, B, temperature, topk, 1, stream);
     if (rc == CSM_OK) {
         // (k_advance, the graph's last node, has already turned the codes of a launch that gave up into -1 in m->frame)
         hipLaunchKernelGGL(k_copy_i32, dim3(1), dim3(256), 0, st, m->frame, out_frame, B * m->cfg.n_codebooks);
@@ -1523,10 +1572,10 @@ extern "C" int csm_generate_frame_s1(csm_handle m, const int64_t* tokens, const 
 // ---------------------------------------------------------------------------------------
 // per-slot reset / refill of a live batch (csm_reset(handle, batch_slots, n))
 // ---------------------------------------------------------------------------------------
-__global__ void k_reset_slots(const int* slots, int n, int max_batch, int* cur_pos, int* eos_at) {
+__global__ void k_reset_slots(const int* slots, int n, int max_batch, int* cur_pos, int* eos_at, int* fresh) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int b = slots[i];
-        if (b >= 0 && b < max_batch) { cur_pos[b] = 0; eos_at[b] = -1; }
+        if (b >= 0 && b < max_batch) { cur_pos[b] = 0; eos_at[b] = -1; fresh[b] = 0; }
     }
 }
 // frame 0 of a refilled slot (frame row 0 = the scratch row the slot's depth pass ran on) -> the slot's step inputs, its EOS word, the
@@ -1560,10 +1609,14 @@ __global__ void k_stage_slot(int* frame, const int* frame_save, int ncb, int slo
 extern "C" int csm_reset_slots(csm_handle m, const int32_t* slots, int n, void* stream) {
     if (!m || !slots || n < 0 || n > m->max_batch) return fail(m, CSM_E_INVALID, "csm_reset_slots: bad argument");
     if (n == 0) return CSM_OK;
+    for (int i = 0; i < n; ++i) {
+        if (m->rf_slot >= 0 && slots[i] == m->rf_slot) return fail(m, CSM_E_STATE, "csm_reset_slots: the slot's refill beside the frame loop is still running (csm_refill_advance)");
+        if (slots[i] == m->rf_fresh_slot) m->rf_fresh_slot = -1;
+    }
     hipStream_t st = (hipStream_t)stream;
     int* d = m->slot_scratch;
     HIPCHK(m, hipMemcpyAsync(d, slots, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_reset_slots, dim3(1), dim3(64), 0, st, d, n, m->max_batch, m->cur_pos, m->eos_at);
+    hipLaunchKernelGGL(k_reset_slots, dim3(1), dim3(64), 0, st, d, n, m->max_batch, m->cur_pos, m->eos_at, m->fresh);
     HIPCHK(m, hipGetLastError());
     HIPCHK(m, hipStreamSynchronize(st));             // `slots` is host memory of the caller
     return CSM_OK;
@@ -1574,7 +1627,10 @@ extern "C" int csm_prefill_slot(csm_handle m, int slot, const int32_t* tokens, c
     if (!m || !tokens || !mask || !pos) return fail(m, CSM_E_INVALID, "csm_prefill_slot: null argument");
     if (slot < 0 || slot >= m->max_batch || S < 1 || S > m->max_rows) return fail(m, CSM_E_INVALID, "csm_prefill_slot: slot / S outside the limits given to csm_create");
     if (!(temperature > 0.f) || topk < 1) return fail(m, CSM_E_INVALID, "csm_prefill_slot: temperature must be > 0 and topk >= 1");
+    if (slot == m->rf_slot) return fail(m, CSM_E_STATE, "csm_prefill_slot: the slot's refill beside the frame loop is still running (csm_refill_advance)");
     hipStream_t st = (hipStream_t)stream;
+    if (slot == m->rf_fresh_slot) m->rf_fresh_slot = -1;
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, st, m->fresh + slot, 0, 1);      // a completed-but-unsampled refill of this slot is dropped
     // the prompt's rows run as a batch of ONE sequence whose K/V land in the slot's part of the backbone caches; h, last_h and the depth
     // pass use scratch row 0 (every per-frame workspace is dead between frame steps)
     m->bb.slot_off = (long)slot * m->cfg.backbone.n_kv_heads * m->bb.cache_len * m->bb.hd;
@@ -1601,7 +1657,7 @@ extern "C" int csm_refill_begin(csm_handle m, int slot, const int32_t* tokens, c
     if (!m || !tokens || !mask || !pos) return fail(m, CSM_E_INVALID, "csm_refill_begin: null argument");
     if (slot < 0 || slot >= m->max_batch || S < 1 || S > m->max_rows) return fail(m, CSM_E_INVALID, "csm_refill_begin: slot / S outside the limits given to csm_create");
     if (m->rf_slot >= 0) return fail(m, CSM_E_STATE, "csm_refill_begin: a refill is already in progress (finish it with csm_refill_advance)");
-    if (!m->wide_path || m->max_batch < m->wide_min) return fail(m, CSM_E_STATE, "csm_refill_begin: needs the matrix-core decode path (max_batch >= 3); use csm_prefill_slot");
+    if (!refill_beside_ok(m, m->max_batch)) return fail(m, CSM_E_STATE, "csm_refill_begin: needs the matrix-core decode path (csm_refill_supported); use csm_prefill_slot");
     hipStream_t st = (hipStream_t)stream;
     const int dbb = m->cfg.backbone.dim;
     if (m->rf_last == nullptr) {
@@ -1614,7 +1670,11 @@ extern "C" int csm_refill_begin(csm_handle m, int slot, const int32_t* tokens, c
     HIPCHK(m, launch_embed(m, tokens, mask, S, st, m->rf_h));
     // parked: until the prompt is complete the slot's row of the frame steps is a placeholder at positions >= S (its K/V land beyond the prompt's)
     hipLaunchKernelGGL(k_set_prefill_state, dim3(1), dim3(256), 0, st, pos, 1, S, m->cur_pos + slot, m->cfg.backbone.max_seq, m->n_frames + 1);
+    // ... and the frame steps HOLD it there (flag 2 = parked: k_advance neither advances it nor tests it against max_seq), however many
+    // steps the prompt's layers take
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, st, m->fresh + slot, 2, 1);
     HIPCHK(m, hipGetLastError());
+    if (slot == m->rf_fresh_slot) m->rf_fresh_slot = -1;
     m->rf_slot = slot; m->rf_S = S; m->rf_layer = 0; m->rf_pos = pos;
     return CSM_OK;
 }
@@ -1635,9 +1695,11 @@ extern "C" int csm_refill_advance(csm_handle m, int max_layers, void* stream) {
     hipLaunchKernelGGL(k_set_prefill_state, dim3(1), dim3(256), 0, st, m->rf_pos, 1, S, m->cur_pos + slot, m->cfg.backbone.max_seq, m->n_frames + 1);
     hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, st, m->fresh + slot, 1, 1);
     HIPCHK(m, hipGetLastError());
-    m->rf_slot = -1; m->rf_pos = nullptr;
+    m->rf_slot = -1; m->rf_pos = nullptr; m->rf_fresh_slot = slot;
     return 1;
 }
+
+extern "C" int csm_refill_supported(csm_handle m, int B) { return m && B >= 1 && refill_beside_ok(m, B) ? 1 : 0; }
 
 extern "C" int csm_num_frames(csm_handle m) { return m ? m->host_frames : 0; }
 

@@ -434,8 +434,9 @@ struct AdvanceArgs {
     int max_seq;          // backbone positions are [0, max_seq)
     int* overflow;        // device flag: a step ran at a position >= max_seq (csm_read_frames -> CSM_E_TOO_LONG)
     const uint32_t *err0, *err1;   // optional give-up words of the all-CU launches: non-zero -> this frame's codes are invalid, recorded as -1
-    int* fresh;           // optional [B]: non-zero = this frame is FRAME 0 of an utterance whose prompt was prefilled beside the frame loop
-                          // (csm_refill_*): its backbone row of this step was a placeholder, so the position stays, the EOS word restarts
+    int* fresh;           // optional [B]: 1 = this frame is FRAME 0 of an utterance whose prompt was prefilled beside the frame loop
+                          // (csm_refill_*): its backbone row of this step was a placeholder, so the position stays, the EOS word restarts;
+                          // 2 = parked (the prompt is still running): position held, never tested against max_seq
 };
 
 static __global__ __launch_bounds__(256) void k_advance(const AdvanceArgs a) {
@@ -458,11 +459,13 @@ static __global__ __launch_bounds__(256) void k_advance(const AdvanceArgs a) {
     for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
         a.cur_tokens[b * (a.ncb + 1) + a.ncb] = 0;
         a.cur_mask[b * (a.ncb + 1) + a.ncb] = 0;
-        const bool fresh = a.fresh != nullptr && a.fresh[b] != 0;
-        if (fresh) { a.eos_at[b] = -1; a.fresh[b] = 0; }
+        const int flag = a.fresh != nullptr ? a.fresh[b] : 0;             // 1 = this frame is the slot's frame 0, 2 = parked (placeholder row)
+        if (flag == 1) { a.eos_at[b] = -1; a.fresh[b] = 0; }
         if (nz[b] == 0 && a.eos_at[b] < 0) a.eos_at[b] = n;
-        if (a.pos_inc && a.cur_pos[b] >= a.max_seq) *a.overflow = 1;      // the step that just ran used this position
-        if (!fresh) a.cur_pos[b] += a.pos_inc;
+        if (flag == 0) {                                                  // a parked / joining slot keeps its position: its row was a placeholder
+            if (a.pos_inc && a.cur_pos[b] >= a.max_seq) *a.overflow = 1;  // the step that just ran used this position
+            a.cur_pos[b] += a.pos_inc;
+        }
     }
     if (threadIdx.x == 0) { *a.n_frames = n + 1; a.rng[1] += 1; }
 }

@@ -75,8 +75,10 @@ SIGNATURES = {
     "csm_generate_frame_s1": (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp]),
     "csm_reset_slots": (_i, [_vp, _vp, _i, _vp]),
     "csm_prefill_slot": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp]),
+    "csm_refill_supported": (_i, [_vp, _i]),
     "csm_refill_begin": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
     "csm_refill_advance": (_i, [_vp, _i, _vp]),
+    "csm_broadcast_weights": (_i, [_vp, C.c_size_t, _vp, _i, _vp]),
     "csm_num_frames": (_i, [_vp]),
     "csm_read_frames": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "csm_frames_dev": (_vp, [_vp]),

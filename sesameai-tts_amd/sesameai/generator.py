@@ -99,6 +99,9 @@ class Generator:
             pass
         self.generate([11] * 12, 0, ctx, max_audio_length_ms=4 * FRAME_MS, temperature=temperature, topk=topk)
         self._model._kv_prompt = None                       # the synthetic prompt is nobody's prefix
+        # the warm-up's frames advanced the Philox step counter: put the noise stream back where a process without the warm-up
+        # (CSM_NO_WARMUP=1) has it, so the two produce the same audio for the same requests
+        self._model.seed(getattr(self._model, "_seed_value", 0))
         torch.cuda.synchronize(self.device)
 
     # -- prompt assembly (generator.py:63-109) ------------------------------------------------
@@ -258,7 +261,7 @@ class Generator:
         poll = poll or self._eos_poll
         B = min(self._max_batch, len(prompts))
         beside = getattr(m, "supports_refill_beside_the_loop", None)
-        if B >= 3 and beside is not None and beside() and getattr(self, "refill_beside_the_loop", True):
+        if beside is not None and beside(B) and getattr(self, "refill_beside_the_loop", True):
             yield from self._iter_codes_refilling_beside_the_loop(prompts, limits, temperature, topk, poll, B)
             return
         pending = deque(range(len(prompts)))
@@ -505,12 +508,21 @@ class AudioStreamWriter:
     ``write_file`` at the end) with a bounded footprint: every chunk is appended to the OPEN file as it arrives and
     ``write_file`` only patches the two RIFF size fields and closes -- a 90 s utterance never sits in memory as a list of
     tensors, and a run that dies half-way leaves the audio produced so far on disk.  No chunk, no file (the reference
-    returns before ``torchaudio.save`` then).  ``add_chunk`` may be called from another thread than ``write_file``."""
+    returns before ``torchaudio.save`` then).  ``add_chunk`` may be called from another thread than ``write_file``.
+
+    Until ``write_file`` the header carries the streaming placeholder 0xFFFFFFFF in both size fields ("length unknown": players
+    read to the end of the file), so a writer that is abandoned -- dropped, garbage-collected, the process killed -- leaves a WAV
+    that still plays; ``close()`` / ``with`` / ``__del__`` finalise it like ``write_file``.  The reference's public ``audio_chunks``
+    list is kept as an attribute for callers that look at it, but stays EMPTY here (the chunks are in the file); ``chunks_written``
+    counts them."""
+
+    _UNKNOWN = 0xFFFFFFFF
 
     def __init__(self, filename, sample_rate):
         self.filename = filename
         self.sample_rate = sample_rate
         self.lock = threading.Lock()
+        self.audio_chunks: List[torch.Tensor] = []       # reference attribute; not filled (see the class docstring)
         self.chunks_written = 0
         self._file = None
         self._data_bytes = 0
@@ -520,7 +532,9 @@ class AudioStreamWriter:
         with self.lock:
             if self._file is None:
                 self._file = open(self.filename, "wb")
-                self._file.write(_wav_float32_header(self.sample_rate, 0))
+                hdr = bytearray(_wav_float32_header(self.sample_rate, 0))
+                hdr[4:8] = struct.pack("<I", self._UNKNOWN); hdr[40:44] = struct.pack("<I", self._UNKNOWN)
+                self._file.write(bytes(hdr))
             self._file.write(pcm)
             self._data_bytes += len(pcm)
             self.chunks_written += 1
@@ -533,6 +547,21 @@ class AudioStreamWriter:
             f.seek(4); f.write(struct.pack("<I", 36 + self._data_bytes))
             f.seek(40); f.write(struct.pack("<I", self._data_bytes))
             f.close()
+
+    close = write_file
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.write_file()
+        return False
+
+    def __del__(self):
+        try:
+            self.write_file()
+        except Exception:
+            pass
 
 
 class _ChunkPlayer:

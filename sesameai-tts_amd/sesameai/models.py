@@ -125,10 +125,11 @@ def state_dict_layout(args: ModelArgs) -> List[Tuple[str, Tuple[int, ...]]]:
     return out
 
 
-def synthetic_state_dict(args: ModelArgs, seed: int = 1234, std: float = 0.02) -> Dict[str, torch.Tensor]:
+def synthetic_state_dict(args: ModelArgs, seed: int = 1234, std: float = 0.02, flavour: str = "bench") -> Dict[str, torch.Tensor]:
     """Random-init weights of the true shapes (no checkpoint can be downloaded here):
     N(0, std^2) fp32 -> bf16 from one seeded CPU generator in ``state_dict_layout`` order,
-    norm scales = 1."""
+    norm scales = 1.  ``flavour="decisive"``: the same draws re-arranged by
+    ``_decisive_checkpoint`` into a checkpoint whose greedy decisions are far from ties."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     sd: Dict[str, torch.Tensor] = {}
     for name, shp in state_dict_layout(args):
@@ -137,7 +138,49 @@ def synthetic_state_dict(args: ModelArgs, seed: int = 1234, std: float = 0.02) -
         else:
             t = torch.empty(shp, dtype=torch.float32).normal_(0.0, std, generator=g)
         sd[name] = t.to(torch.bfloat16)
+    if flavour == "decisive":
+        return _decisive_checkpoint(args, sd, seed)
+    if flavour != "bench":
+        raise ValueError(f"unknown synthetic flavour {flavour!r}")
     return sd
+
+
+def _decisive_checkpoint(args: ModelArgs, sd: Dict[str, torch.Tensor], seed: int) -> Dict[str, torch.Tensor]:
+    """A synthetic checkpoint that talks: random weights give near-uniform logits, so greedy decoding is a sequence of near-ties and
+    two correct bf16 implementations drift apart within a frame.  Here each head reads back one embedding: codebook0_head's rows are
+    the LAST codebook's embedding rows in a seeded order (the backbone's input is the sum of a frame's 32 embeddings, reference
+    sesameai/models.py:156-157, so frame t's last code names frame t+1's first), audio_head[i-1]'s columns are
+    projection @ (codebook i-1's embedding rows) in a seeded order (the decoder's input at step i is the projected embedding of code i-1,
+    models.py:170-181), text rows carry one last-codebook entry so the prompt frame decides as clearly, embeddings are 8x (the last
+    codebook 32x) and the o- / down-projections 0.5x so a row's residual stream keeps its embedding in front of what the layers add.
+    Every op still runs on every shape; every greedy decision is one logit several units above the rest, so free-running greedy codes
+    are a checkable statement (tests/test_decisive_gpu.py; same construction, written independently, in oracle/csm_ref.py)."""
+    bf = torch.bfloat16
+    V, ncb = args.audio_vocab_size, args.audio_num_codebooks
+    live = min(2048, V)                                     # Mimi's codebook size: CSM's extra logit rows stay random and small
+    pg = torch.Generator(device="cpu").manual_seed(seed * 1_000_003 + 17)
+    order = [torch.randperm(live, generator=pg) for _ in range(ncb)]
+    out = dict(sd)
+    for name in sd:
+        if name.endswith(("attn.output_proj.weight", "mlp.w2.weight")):
+            out[name] = (sd[name].float() * 0.5).to(bf)
+    audio = (sd["audio_embeddings.weight"].float() * 8.0).to(bf)
+    lo = (ncb - 1) * V
+    audio[lo:lo + live] = (audio[lo:lo + live].float() * 4.0).to(bf)
+    out["audio_embeddings.weight"] = audio
+    named = audio[lo:lo + live]
+    which = (torch.arange(args.text_vocab_size) * 40503) % live
+    out["text_embeddings.weight"] = (sd["text_embeddings.weight"].float() * 8.0 + named[which].float()).to(bf)
+    c0 = sd["codebook0_head.weight"].clone()
+    c0[:live] = (named[order[0]].float() / 32.0).to(bf)
+    out["codebook0_head.weight"] = c0
+    proj_t = sd["projection.weight"].float().t()
+    heads = sd["audio_head"].clone()
+    for i in range(1, ncb):
+        src = audio[(i - 1) * V:(i - 1) * V + live][order[i]].float()
+        heads[i - 1, :, :live] = ((src @ proj_t).t() / 8.0).to(bf)
+    out["audio_head"] = heads
+    return out
 
 
 MATRIX_SUFFIXES = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "output_proj.weight", "w1.weight", "w2.weight", "w3.weight")
@@ -350,6 +393,7 @@ class Model:
         with self._on_device():
             check(lib.csm_seed(self._h, seed, _stream_ptr()), self._h)
         self._seeded = True
+        self._seed_value = int(seed)
 
     def _to_dev(self, x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
         """A prompt tensor on the device in the dtype the C ABI reads.  A host tensor is cast by ONE single-threaded numpy pass straight
@@ -494,8 +538,12 @@ class Model:
             self._refill_keep = None
         return rc == 1
 
-    def supports_refill_beside_the_loop(self) -> bool:
-        return self._max_batch >= 3
+    def supports_refill_beside_the_loop(self, batch: Optional[int] = None) -> bool:
+        """Whether frame steps of ``batch`` rows (default: the handle's max batch) honour a refill beside the loop -- the engine's own
+        predicate (csm_refill_supported: the matrix-core decode path, which CSM_WIDE / CSM_WIDE_MIN can move or switch off)."""
+        if not self._h:
+            return False
+        return bool(lib.csm_refill_supported(self._h, int(self._max_batch if batch is None else batch)))
 
     def depth(self, batch: int, temperature: float, topk: int, *, forced: Optional[torch.Tensor] = None,
               noise: Optional[torch.Tensor] = None, want_logits: bool = False, commit: bool = True):

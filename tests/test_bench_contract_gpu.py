@@ -52,6 +52,19 @@ def test_bench_self_launches_its_ranks_when_no_launcher_is_present():
     assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) / d["value"] < 0.02      # two replicas' frames / max-over-ranks time
     wb = d["weight_broadcast"]
     assert wb["csm_bytes"] > 0 and wb["csm_ms"] > 0 and wb["csm_GBps"] > 0
+    _check_rank_records(d, 2)
+
+
+def _check_rank_records(d, n):
+    """The N > 1 line proves itself: the rank count is the process group's, every rank reports the device it ran
+    on (index + PCI id), its own step time / frames / broadcast rate and its share of the host's threads."""
+    assert d["ranks_seen"] == n == d["n_gpus"] and len(d["ranks"]) == n and sorted(r["rank"] for r in d["ranks"]) == list(range(n))
+    for r in d["ranks"]:
+        assert r["ms_per_step"] > 0 and r["frames"] == d["steps"] * d["config"]["batch_per_gpu"] and r["pci_bus_id"]
+        assert r["ms_per_step"] <= d["ms_per_step"] * 1.001, "value is priced on the SLOWEST rank"
+        assert r["broadcast_GBps"] > 0 and r["host_threads"] >= 1
+    assert d["distinct_gpus"] == 1, "BENCH_SHARE_GPU0: both ranks sit on GPU 0 (on a real node this is N)"
+    assert d["collective_backend"] == "gloo"
 
 
 def test_two_full_size_ranks_carry_the_config4_leg_and_honest_kernel_entries():
@@ -72,6 +85,7 @@ def test_two_full_size_ranks_carry_the_config4_leg_and_honest_kernel_entries():
     assert abs(c4["aggregate_frames_per_s"] - 2 * 32 * 1000.0 / c4["slowest_rank_ms_per_step"]) / c4["aggregate_frames_per_s"] < 0.02
     wb = d["weight_broadcast"]
     assert wb["csm_bytes"] > 3e9 and wb["mimi_bytes"] > 1e8 and wb["csm_ms"] > 0 and wb["mimi_ms"] > 0
+    _check_rank_records(d, 2)
     assert isinstance(d["roofline"]["dominant_kernels"], list)
 
 

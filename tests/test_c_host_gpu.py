@@ -66,7 +66,7 @@ def test_plain_c_host_produces_the_python_hosts_frames(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = r.stdout.strip().splitlines()
     got = torch.tensor([[int(x) for x in ln.split()] for ln in lines[:n]], dtype=torch.int32)
-    assert lines[n] == f"eos_at {int(eos[0])}"
+    assert lines[n] == f"eos_at {int(eos[0])}" and lines[n + 1].startswith("replicas 1 broadcast_bytes ")
     assert got.shape == (n, 32) and torch.equal(got, want[:, 0]), "the plain-C host and the Python host disagree"
 
 
@@ -105,3 +105,35 @@ def test_plain_c_codec_host_decodes_the_python_hosts_pcm(tmp_path):
     import numpy as np
     got = torch.from_numpy(np.fromfile(out, dtype=np.float32))
     assert got.shape == want.shape and torch.equal(got, want), f"max |d| {(got - want).abs().max().item():.3e}"
+
+
+def test_weight_broadcast_on_a_communicator_the_caller_owns():
+    """csm_broadcast_weights (include/csm_hip.h): the library links no RCCL and creates no communicator -- it resolves
+    ncclBroadcast from the instance already in the process.  Here the caller is this test: a one-rank ncclComm_t made through ctypes on
+    the librccl torch has loaded (RTLD_NOLOAD: nothing new is loaded), one in-place broadcast of a 64 MB blob on a side stream, the
+    bytes intact; a null communicator is CSM_E_INVALID with a message.  (N ranks: examples/c_host/csm_c_host.c with CSM_C_HOST_GPUS=N,
+    and torch.distributed's own broadcast on the Python side.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sesameai import _abi
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    rccl = C.CDLL("librccl.so.1", mode=4 | 2)                                   # RTLD_NOLOAD | RTLD_NOW
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        blob = torch.randint(-2**31, 2**31 - 1, (1 << 24,), dtype=torch.int32, device="cuda")
+        want = blob.clone()
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        _abi.check(_abi.lib.csm_broadcast_weights(blob.data_ptr(), blob.numel() * 4, comm, 0, side.cuda_stream))
+        side.synchronize()
+        assert torch.equal(blob, want)
+        rc = _abi.lib.csm_broadcast_weights(blob.data_ptr(), 16, None, 0, side.cuda_stream)
+        assert rc == -1 and b"communicator" in _abi.lib.csm_last_error(None)
+    finally:
+        rccl.ncclCommDestroy(comm)

@@ -1006,6 +1006,71 @@ def test_continuous_batching_beside_the_loop_through_the_generator(tiny):
     m.reset_caches()
 
 
+def test_refill_gates_share_one_predicate_and_a_parked_slot_holds_its_position(monkeypatch):
+    """ADVICE r4 (medium + low).  csm_refill_begin, the frame step's inject node, k_advance's use of the slots' flags and the host's
+    choice of the refill path now share ONE predicate (csm_refill_supported): with CSM_WIDE_MIN above the running batch a frame step used
+    to consume the fresh flag without ever injecting the prompt's last row (frame 0 silently sampled from the placeholder), and with
+    CSM_WIDE=0 iter_codes_continuous raised instead of falling back to csm_prefill_slot.  A parked slot's position is HELD while its prompt
+    runs (it used to advance every step and could trip the sticky overflow flag for the whole batch); csm_reset_slots / csm_prefill_slot on
+    the slot whose refill is running are refused."""
+    from sesameai.generator import Generator
+    from sesameai.models import Model, csm_tiny_args, synthetic_state_dict
+    sd = synthetic_state_dict(csm_tiny_args(), seed=1234)
+    monkeypatch.setenv("CSM_WIDE_MIN", "4")
+    m = Model(csm_tiny_args(), sd, max_frames=64, max_prefill_rows=256)
+    m.setup_caches(4)
+    assert m.supports_refill_beside_the_loop() and m.supports_refill_beside_the_loop(4) and not m.supports_refill_beside_the_loop(3)
+    pr = [_tiny_prompt(12, 70 + b) for b in range(4)]
+    new_t, new_m = _tiny_prompt(9, 97)
+
+    def fill(prompts):
+        m.reset_caches(); m.seed(3)
+        for b, (t, mk) in enumerate(prompts):
+            m.refill_begin(b, t, mk)
+            while not m.refill_advance(16):
+                pass
+    fill([pr[0], (new_t, new_m), pr[2], pr[3]])
+    with pytest.raises(RuntimeError, match="CSM_E_STATE"):
+        m.step(3, 1.0, 1)                                     # three rows take the GEMV path here: the fresh slots would be stepped as they are
+    m.step(4, 1.0, 1)
+    want0 = m.read_frames(4)[0][0, 1]                         # the new utterance's frame 0 when it starts with the batch
+    fill(pr)
+    m.step(4, 1.0, 1)
+    m.refill_begin(1, new_t, new_m)
+    with pytest.raises(RuntimeError, match="CSM_E_STATE"):
+        m.step(3, 1.0, 1)
+    with pytest.raises(RuntimeError, match="CSM_E_STATE"):
+        m.reset_slots([1])
+    with pytest.raises(RuntimeError, match="CSM_E_STATE"):
+        m.refill_slot(1, new_t, new_m, 1.0, 1)
+    for k in range(300):                                      # 9 + 300 > max_seq_len = 256: the parked position must not move
+        m.step(4, 1.0, 1)
+        if k % 100 == 99:
+            m.reset_slots([0, 2, 3])                          # (the generating slots would run out of positions themselves)
+    m.read_frames(4, m.num_frames() - 1, 1)                   # CSM_E_TOO_LONG here before the fix
+    while not m.refill_advance(1):
+        m.step(4, 1.0, 1)
+    m.step(4, 1.0, 1)
+    got0 = m.read_frames(4, m.num_frames() - 1, 1)[0][0, 1]
+    assert torch.equal(got0, want0), "the joined utterance's frame 0 differs from the same prompt's frame 0 at the start of a batch"
+    # a batch the predicate rules out takes the csm_prefill_slot path by itself
+    gen = Generator.__new__(Generator)
+    gen._model, gen._max_batch, gen._eos_poll, gen.device = m, 3, 4, m.device
+    prompts = [_tiny_prompt(6 + 2 * i, 500 + i) for i in range(5)]
+    got = gen.generate_codes_continuous(prompts, 5, 1.0, 1)
+    assert all(g.shape == (5, 32) for g in got)
+    del m
+    monkeypatch.setenv("CSM_WIDE", "0")
+    m2 = Model(csm_tiny_args(), sd, max_frames=64, max_prefill_rows=256)
+    m2.setup_caches(4)
+    assert not m2.supports_refill_beside_the_loop()
+    with pytest.raises(RuntimeError, match="CSM_E_STATE"):
+        m2.refill_begin(0, new_t, new_m)
+    gen._model, gen._max_batch = m2, 4
+    got2 = gen.generate_codes_continuous(prompts, 5, 1.0, 1)     # raised CSM_E_STATE before the fix
+    assert all(g.shape == (5, 32) for g in got2)
+
+
 def test_slot_refills_draw_from_their_own_noise_streams(tiny):
     """under stochastic sampling every slot refilled between the same two frame steps drew frame 0 from the SAME
     Philox stream (step counter not advanced, sequence index 0), so N copies of one prompt started with identical frames, and slot 0's

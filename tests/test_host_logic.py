@@ -459,7 +459,7 @@ class _ScriptedSlotsBeside:
         self.advance_calls, self.calls_between_steps, self.resets = [], [], []
 
     def setup_caches(self, b): pass
-    def supports_refill_beside_the_loop(self): return True
+    def supports_refill_beside_the_loop(self, batch=None): return True
 
     def reset_caches(self):
         self.hist, self.cur, self.eos, self.pending, self._since_step = [], {}, {}, None, []
