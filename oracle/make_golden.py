@@ -218,7 +218,7 @@ def decisive_finish(gold, w, full: bool):
     (generator.py:299) and as the stateless 10-frame chunks generate_stream yields (generator.py:119-210; every 4th sample kept)."""
     names = [n for n in DECISIVE_CHECKSUM_NAMES if n in w]
     gold["weight_checksum_names"] = names
-    gold["weight_checksum"] = torch.stack([w[n].float().abs().sum() for n in names])
+    gold["weight_checksum"] = torch.stack([w[n].view(torch.int16).to(torch.int64).sum() for n in names])    # exact, order-free
     if full:
         s = M.mimi_full()
         mw = M.make_weights(s, seed=4321)

@@ -159,6 +159,27 @@ static hipError_t launch_gemv_mt(const GemvArgs& a, int units, hipStream_t st) {
     return hipGetLastError();
 }
 
+// The two load-time table builds (csm_create): the production kernel's arithmetic with the token rows split over blockIdx.y
+// (k_gemv<..., MSPLIT = true>), so the launch fills the chip instead of 128-256 blocks walking every row.  which: 0 = plain store at
+// K = 2048 (proj_emb = projection(audio_embeddings)); 1 = norm + q|k|v + RoPE at K = 1024, hd 128 (layer-0 table), fp8 = its e4m3 stream.
+static hipError_t launch_gemv_msplit(int which, bool fp8, GemvArgs a, hipStream_t st) {
+    const int units = which == 0 ? (a.N + 1) / 2 : (a.N + 1) / 2;         // R = 2 weight rows per wave in both forms
+    const int blocks = (units + 3) / 4;
+    int ny = (2048 + blocks - 1) / blocks;                                 // ~8 blocks per CU
+    a.m_chunk = ((a.M + ny - 1) / ny + 3) / 4 * 4;
+    ny = (a.M + a.m_chunk - 1) / a.m_chunk;
+    const dim3 grid(blocks, ny);
+    if (which == 0) {
+        const size_t smem = (size_t)4 * 4 * 512 * 2 + 64;
+        hipLaunchKernelGGL((k_gemv<4, 4, 2, PRO_PLAIN, EPI_STORE, 64, 0, true>), grid, dim3(256), smem, st, a);
+    } else {
+        const size_t smem = (size_t)4 * 2 * 512 * 2 + 64;
+        if (fp8) hipLaunchKernelGGL((k_gemv<4, 2, 2, PRO_NORM, EPI_QKV_ROPE, 128, 1, true>), grid, dim3(256), smem, st, a);
+        else hipLaunchKernelGGL((k_gemv<4, 2, 2, PRO_NORM, EPI_QKV_ROPE, 128, 0, true>), grid, dim3(256), smem, st, a);
+    }
+    return hipGetLastError();
+}
+
 // kind: 0 = plain store, 1 = plain + residual, 2 = norm + store (head), 3 = norm + qkv/rope, 4 = norm + swiglu,
 //       5 = fused depth-decoder attention + residual (hd 128, <= 32 keys)
 //       6 = fused split-K attention merge + residual (hd 64)
@@ -416,7 +437,7 @@ static bool flash_ok(const Stack& S) { return S.hd == 64 && S.d.n_heads % S.d.n_
 static hipError_t launch_attn_auto(const Stack& S, const AttnArgs& t, bool prompt, hipStream_t st) {
     if (flash_ok(S) && t.nsplit == 1 && (prompt || t.rows_per_seq >= FLASH_MIN_ROWS)) {
         dim3 grid((t.M / t.rows_per_seq) * ((t.rows_per_seq + 31) / 32), t.KV);
-        hipLaunchKernelGGL((k_attn_flash<64>), grid, dim3(256), 0, st, t);
+        hipLaunchKernelGGL((k_attn_flash<64, AF_NG>), grid, dim3(256 * AF_NG), 0, st, t);
         return hipGetLastError();
     }
     return launch_attn(S.hd, t, st);
@@ -1019,7 +1040,8 @@ static hipError_t build_qkv0_table(CsmModel* m) {
             a.w0 = (const bf16_t*)S.w8[0].wq; a.w1 = (const bf16_t*)S.w8[0].wk; a.w2 = (const bf16_t*)S.w8[0].wv;
             a.s0 = (const float*)S.w8s[0].wq; a.s1 = (const float*)S.w8s[0].wk; a.s2 = (const float*)S.w8s[0].wv;
         }
-        e = f8 ? launch_gemv8(3, dd, S.hd, a, nullptr) : launch_gemv(3, dd, S.hd, a, nullptr);
+        e = (dd == 1024 && S.hd == 128) ? launch_gemv_msplit(1, f8, a, nullptr)
+                                        : (f8 ? launch_gemv8(3, dd, S.hd, a, nullptr) : launch_gemv(3, dd, S.hd, a, nullptr));
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(k_gather_kv_rows, dim3(1024), dim3(256), 0, nullptr, kt, vt, V, c.decoder.n_kv_heads, S.cache_len, S.hd, cb + 1,
                            S.nq, tab);
@@ -1309,7 +1331,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
         memset(&a, 0, sizeof a);
         a.x = (const bf16_t*)w->audio_emb; a.x_row_stride = dbb; a.M = ncb * cfg->audio_vocab;
         a.w0 = (const bf16_t*)w->projection; a.N = dd; a.out = m->proj_emb; a.ldo = dd; a.nt = 0;
-        HIPCHK((CsmModel*)nullptr, launch_gemv(0, dbb, 0, a, nullptr));
+        HIPCHK((CsmModel*)nullptr, dbb == 2048 ? launch_gemv_msplit(0, false, a, nullptr) : launch_gemv(0, dbb, 0, a, nullptr));
     }
     HIPCHK((CsmModel*)nullptr, hipDeviceSynchronize());
     m->qkv0_tab = nullptr;
@@ -1906,7 +1928,7 @@ extern "C" int csm_op_attn(int M, int rows_per_seq, int H, int KV, int head_dim,
     if (nsplit < 1) {
         if (head_dim != 64 || H % KV != 0 || (H / KV) % 4 != 0) return CSM_E_INVALID;
         dim3 grid((M / rows_per_seq) * ((rows_per_seq + 31) / 32), KV);
-        hipLaunchKernelGGL((k_attn_flash<64>), grid, dim3(256), 0, (hipStream_t)stream, t);
+        hipLaunchKernelGGL((k_attn_flash<64, AF_NG>), grid, dim3(256 * AF_NG), 0, (hipStream_t)stream, t);
         e = hipGetLastError();
     } else e = launch_attn(head_dim, t, (hipStream_t)stream);
     if (e != hipSuccess) { g_create_err = std::string("csm_op_attn: ") + hipGetErrorString(e); return CSM_E_HIP; }

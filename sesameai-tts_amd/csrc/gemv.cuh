@@ -59,6 +59,8 @@ struct GemvArgs {
     const float *s0, *s1, *s2;
     // wide-M decode steps: `out` (SwiGLU) is written in operand order (xp_off)
     int out_packed;
+    // MSPLIT instantiations only (table builds at csm_create: M = tens of thousands of rows): rows per blockIdx.y, a multiple of MT
+    int m_chunk;
 #ifdef GEMV_PF_HOOKS   // tools/microbench/pfchain_bench.hip only (measured: every prefetch form made the chain slower)
     // Optional L2 prefetch of the NEXT launch's weights: workgroups blockIdx.x >= work_blocks (when pf[0].base != nullptr)
     // do no GEMV work; they read the byte regions the next launch's workgroups will stream (region b' of matrix i =
@@ -327,7 +329,10 @@ __device__ __forceinline__ void stage_x(bf16_t* xs, float* red, const GemvArgs& 
 
 // R = weight rows per wave.  EPI_QKV_ROPE: R == 2 (one interleaved RoPE pair).
 // EPI_SWIGLU: R == 2*P, rows [0,P) are gate rows i..i+P-1 and [P,2P) the matching up rows.
-template <int MT, int KITERS, int R, int PRO, int EPI, int HD, int WT = 0>
+// MSPLIT (round 5): blockIdx.y takes the token rows [y * m_chunk, (y + 1) * m_chunk) -- for the two load-time table builds, whose 65,632 /
+// 2,051 rows every block used to walk alone, 4 at a time (96 ms of GPU time per csm_create).  Same lane / k mapping and the same
+// per-row arithmetic: the same bits.  Without it the constants below fold and the decode-step instantiations are unchanged.
+template <int MT, int KITERS, int R, int PRO, int EPI, int HD, int WT = 0, bool MSPLIT = false>
 __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     constexpr int K = KITERS * 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -341,6 +346,8 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * 4 + wave;              // one unit = R weight rows
+    const int m_begin = MSPLIT ? (int)blockIdx.y * a.m_chunk : 0;
+    const int m_end = MSPLIT ? (m_begin + a.m_chunk < a.M ? m_begin + a.m_chunk : a.M) : a.M;
 
     // ---- resolve this wave's R weight rows (nullptr = past the end) ------------------------
     constexpr int WS = WT == 1 ? 1 : 2;                   // bytes per weight
@@ -416,11 +423,11 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     if constexpr (EPI == EPI_RESID) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            rpre[r] = (lane < MT && lane < a.M && orow[r] < a.N) ? bf2f(a.resid[(long)lane * a.ldo + orow[r]]) : 0.f;
+            rpre[r] = (lane < MT && m_begin + lane < m_end && orow[r] < a.N) ? bf2f(a.resid[(long)(m_begin + lane) * a.ldo + orow[r]]) : 0.f;
     }
     if constexpr (EPI == EPI_QKV_ROPE) {
-        if (lane < MT && lane < a.M) {
-            ppre = row_pos(a, lane);
+        if (lane < MT && m_begin + lane < m_end) {
+            ppre = row_pos(a, m_begin + lane);
             if (orow[0] < a.nq + a.nkv) {
                 const int e = (orow[0] < a.nq ? orow[0] : orow[0] - a.nq) % HD;
                 cspre = reinterpret_cast<const uint32_t*>(a.rope)[(long)ppre * (HD / 2) + e / 2];
@@ -428,8 +435,8 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
         }
     }
 
-    for (int m0 = 0; m0 < a.M; m0 += MT) {
-        if (m0 > 0) __syncthreads();
+    for (int m0 = m_begin; m0 < m_end; m0 += MT) {
+        if (m0 > m_begin) __syncthreads();
         if constexpr (PRO == PRO_ATTN) stage_attn<MT, KITERS>(xs, red + 16, a, m0);
         else if constexpr (PRO == PRO_COMBINE) stage_combine<MT, KITERS>(xs, a, m0);
         else stage_x<MT, KITERS, PRO == PRO_NORM>(xs, red, a, m0);
@@ -473,14 +480,14 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 #pragma clang fp contract(off)
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            if (lane != m || m0 + m >= a.M) continue;
+            if (lane != m || m0 + m >= m_end) continue;
             const long mrow = m0 + m;
             if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if (orow[r] >= a.N) continue;
                     float y = round_bf(acc[m][r]);
-                    if (EPI == EPI_RESID) y = y + (m0 == 0 ? rpre[r] : bf2f(a.resid[mrow * a.ldo + orow[r]]));
+                    if (EPI == EPI_RESID) y = y + (m0 == m_begin ? rpre[r] : bf2f(a.resid[mrow * a.ldo + orow[r]]));
                     a.out[mrow * a.ldo + orow[r]] = f2bf(y);
                 }
             } else if constexpr (EPI == EPI_SWIGLU) {
@@ -497,11 +504,11 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
                 const int row = orow[0];
                 if (row >= a.N) continue;
                 float v0 = round_bf(acc[m][0]), v1 = round_bf(acc[m][1]);
-                const int p = m0 == 0 ? ppre : row_pos(a, mrow);    // clamped: the host guards length
+                const int p = m0 == m_begin ? ppre : row_pos(a, mrow);    // clamped: the host guards length
                 const int b = (int)(mrow / a.rows_per_seq);
                 if (row < a.nq + a.nkv) {                 // q or k: interleaved Llama3-scaled RoPE
                     const int e = (row < a.nq ? row : row - a.nq) % HD;
-                    const uint32_t cs = m0 == 0 ? cspre : reinterpret_cast<const uint32_t*>(a.rope)[(long)p * (HD / 2) + e / 2];
+                    const uint32_t cs = m0 == m_begin ? cspre : reinterpret_cast<const uint32_t*>(a.rope)[(long)p * (HD / 2) + e / 2];
                     const float c = lo2f(cs), s = hi2f(cs);
                     const float o0 = v0 * c - v1 * s;
                     const float o1 = v1 * c + v0 * s;

@@ -174,11 +174,11 @@ def _decisive_checkpoint(args: ModelArgs, sd: Dict[str, torch.Tensor], seed: int
     c0 = sd["codebook0_head.weight"].clone()
     c0[:live] = (named[order[0]].float() / 32.0).to(bf)
     out["codebook0_head.weight"] = c0
-    proj_t = sd["projection.weight"].float().t()
+    proj_t = sd["projection.weight"].double().t()               # fp64 products, rounded once: the same bits on every host
     heads = sd["audio_head"].clone()
     for i in range(1, ncb):
-        src = audio[(i - 1) * V:(i - 1) * V + live][order[i]].float()
-        heads[i - 1, :, :live] = ((src @ proj_t).t() / 8.0).to(bf)
+        src = audio[(i - 1) * V:(i - 1) * V + live][order[i]].double()
+        heads[i - 1, :, :live] = ((src @ proj_t).t() / 8.0).float().to(bf)
     out["audio_head"] = heads
     return out
 

@@ -55,7 +55,7 @@ def decisive():
     from sesameai.models import csm_1b_args, synthetic_state_dict
     gold = torch.load(os.path.join(GOLD, "csm1b_decisive.pt"))
     sd = synthetic_state_dict(csm_1b_args(), seed=int(gold["weight_seed"]), flavour="decisive")
-    got = torch.stack([sd[k].float().abs().sum() for k in gold["weight_checksum_names"]])
+    got = torch.stack([sd[k].view(torch.int16).to(torch.int64).sum() for k in gold["weight_checksum_names"]])
     assert torch.equal(got, gold["weight_checksum"]), "the product's decisive checkpoint is not the one the oracle's codes were generated with"
     return gold, sd
 
@@ -242,7 +242,8 @@ def test_plain_c_host_is_bit_exact(decisive, tmp_path):
     finally:
         os.unlink(blob)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    lines = r.stdout.strip().splitlines()
+    # (RCCL may print a version banner on stdout when the host makes its communicator: keep the host's own lines)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln[:1].isdigit() or ln[:1] == "-" or ln.startswith(("eos_at", "replicas"))]
     got = torch.tensor([[int(x) for x in ln.split()] for ln in lines[:n]], dtype=torch.int32)
     assert lines[n] == "eos_at -1"
     assert torch.equal(got, want)

@@ -19,7 +19,7 @@ def test_product_and_oracle_build_the_same_decisive_checkpoint():
     same = [k for k in w if torch.equal(w[k], base[k])]
     assert any("q_proj" in k for k in same) and not any(k in same for k in ("codebook0_head.weight", "audio_head", "audio_embeddings.weight"))
     gold = torch.load(os.path.join(GOLD, "tiny_decisive.pt"))
-    got = torch.stack([sd[k].float().abs().sum() for k in gold["weight_checksum_names"]])
+    got = torch.stack([sd[k].view(torch.int16).to(torch.int64).sum() for k in gold["weight_checksum_names"]])
     assert torch.equal(got, gold["weight_checksum"])
 
 

@@ -588,13 +588,28 @@ def test_audio_stream_writer_appends_incrementally_and_patches_the_sizes_on_clos
     f = tmp_path / "inc.wav"
     w = AudioStreamWriter(str(f), 24_000)
     w.add_chunk(torch.arange(100, dtype=torch.float32))
-    assert f.exists() and w.chunks_written == 1 and not hasattr(w, "audio_chunks")     # on disk already, no list of tensors kept
+    assert f.exists() and w.chunks_written == 1 and w.audio_chunks == []               # on disk already, no list of tensors kept
+    w._file.flush()
+    raw = f.read_bytes()                                             # while open: "length unknown" placeholders, a WAV players read to its end
+    assert struct.unpack("<I", raw[4:8])[0] == 0xFFFFFFFF and struct.unpack("<I", raw[40:44])[0] == 0xFFFFFFFF and len(raw) == 444
     w.add_chunk(torch.arange(100, 150, dtype=torch.bfloat16))
     w.write_file()
     raw = f.read_bytes()
     assert struct.unpack("<I", raw[4:8])[0] == 36 + 600 and struct.unpack("<I", raw[40:44])[0] == 600 and len(raw) == 644
     assert np.array_equal(np.frombuffer(raw[44:], dtype="<f4"), np.arange(150, dtype=np.float32))
     w.write_file()                                                   # idempotent
+    # a writer that is dropped without write_file: finalised by the context manager / the destructor, handle closed
+    g = tmp_path / "dropped.wav"
+    with AudioStreamWriter(str(g), 24_000) as w2:
+        w2.add_chunk(torch.ones(10))
+    assert struct.unpack("<I", g.read_bytes()[40:44])[0] == 40 and w2._file is None
+    h = tmp_path / "collected.wav"
+    w3 = AudioStreamWriter(str(h), 24_000)
+    w3.add_chunk(torch.ones(7))
+    del w3
+    import gc
+    gc.collect()
+    assert struct.unpack("<I", h.read_bytes()[40:44])[0] == 28
 
 
 def test_rope_table_fp32_tensor_form_vs_the_double_form_over_the_positions_each_stack_reads():
