@@ -1409,14 +1409,15 @@ def test_csm1b_config5_batch32_fp8_long_context_vs_golden(csm1b):
     assert len(bad) <= 0.08 * B * 32 and n_cmp >= B * 8
 
 
-def test_csm1b_prompt_to_pcm_composed_vs_oracle(csm1b):
-    """north_star: "outputs match the reference -d cpu path on identical text+voice prompts within a stated PCM/float tolerance
-    (bit-exact for codebook indices under greedy)" -- the COMPOSED path, end to end.  BASELINE config 2's prompt given as the
-    reference gives it (a voice-prompt Segment + the text to speak) -> Generator.generate (prompt assembly, prefill, hipGraph frame
-    loop, Mimi decode on the GPU), greedy, 10 frames, against csm_ref (frames, reference loop generator.py:283-294) + mimi_ref
-    (PCM, generator.py:299) run live on this host.  Codes: the frame in which the two trajectories part must part at a codebook where the
-    oracle's margin is inside NEAR_TIE x gap.  PCM (tolerance 2e-5 x the clip's peak): generate()'s samples are mimi_ref's decode of the codes
-    the frame loop produced, and -- Mimi being strictly causal -- the samples of the frames identical to the oracle's are the oracle pipeline's."""
+def test_csm1b_prompt_to_pcm_composed_on_the_bench_checkpoint(csm1b):
+    """The composed path on the N(0, 0.02^2) BENCH checkpoint: BASELINE config 2's prompt given as the reference gives it (a voice-prompt
+    Segment + the text to speak) -> Generator.generate (prompt assembly, prefill, hipGraph frame loop, Mimi decode on the GPU), greedy, 10
+    frames, against csm_ref run live on this host.  What this checkpoint can carry: the prompt assembly is the golden prompt's; the frame in
+    which the free-running trajectories part parts at a codebook where the oracle's margin is inside NEAR_TIE x gap (with near-uniform logits
+    23 % of the oracle's rows are such near-ties, so they part within a frame or two); and generate()'s samples are mimi_ref's decode of the
+    codes the frame loop produced (2e-5 x peak).  The statement north_star makes -- codes bit-exact under greedy and PCM within tolerance of
+    the reference pipeline, over whole clips -- is tested on the DECISIVE checkpoint: tests/test_decisive_gpu.py (64 frames, zero excused rows).
+    (Round 4's version also compared PCM 'over the frames identical to the oracle's' -- zero frames on this checkpoint, a vacuous branch: gone.)"""
     from oracle import csm_ref as C, mimi_ref as M
     from sesameai.generator import Generator, Segment
     from sesameai.mimi import MimiArgs, MimiCodec, synthetic_state_dict as mimi_sd
@@ -1426,7 +1427,6 @@ def test_csm1b_prompt_to_pcm_composed_vs_oracle(csm1b):
     noise = float(g2["bf16_vs_fp32_gap"].max())
     tok, msk = g2["prompt_tokens"], g2["prompt_mask"]                      # = bench.py's config-2 prompt (asserted in the config-2 test)
     n_frames = 10
-    # the same prompt in the reference's terms: Segment(speaker, text ids, audio codes) + text ids
     ctx = [Segment(speaker=1, text=tok[:40, 32].tolist(), audio_codes=tok[40:165, :32].t().contiguous())]
     text = tok[166:, 32].tolist()
     model = Model(csm_1b_args(), sd, max_frames=32, max_prefill_rows=256)
@@ -1434,44 +1434,33 @@ def test_csm1b_prompt_to_pcm_composed_vs_oracle(csm1b):
     gen = Generator(model, audio_tokenizer=codec)
     pt, pm = gen._build_prompt(text, 1, ctx)
     assert torch.equal(pt.cpu(), tok) and torch.equal(pm.cpu(), msk), "prompt assembly differs from the golden prompt"
-    seen = []
     frames = gen.generate_codes(pt, pm, n_frames, 1.0, 1)[:, 0]            # [n][32] -- what generate() decodes
     pcm = gen.generate(text, 1, ctx, max_audio_length_ms=n_frames * 80, temperature=1.0, topk=1).cpu()
     assert pcm.shape == (n_frames * 1920,)
-    # the oracle, live
     shape = C.csm_1b()
     om = C.OracleModel(shape, C.make_weights(shape, seed=1234)); om.setup_caches(1)
     cur_t, cur_m, pos = tok.unsqueeze(0), msk.unsqueeze(0), torch.arange(tok.shape[0]).unsqueeze(0)
-    ref, margins = [], []
+    n_same = n_frames
     for f in range(n_frames):
         tr = C.FrameTrace()
         sf = om.generate_frame(cur_t, cur_m, pos, 1.0, 1, greedy=True, trace=tr)
-        top2 = torch.topk(torch.stack(tr.logits, 0)[:, 0].float(), 2, dim=-1)[0]
-        ref.append(sf[0]); margins.append(top2[:, 0] - top2[:, 1])
+        if not torch.equal(sf[0], frames[f]):
+            top2 = torch.topk(torch.stack(tr.logits, 0)[:, 0].float(), 2, dim=-1)[0]
+            _same_until_a_near_tie(frames[f], sf[0], top2[:, 0] - top2[:, 1], noise, f"composed run, frame {f}")
+            n_same = f
+            break
         cur_t = torch.cat([sf.long(), torch.zeros(1, 1).long()], dim=1).unsqueeze(1)
         cur_m = torch.cat([torch.ones_like(sf).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
         pos = pos[:, -1:] + 1
-    ref = torch.stack(ref)
-    n_same = int((ref == frames).all(dim=1).float().cumprod(0).sum())
-    # With seeded random weights the logits are nearly uniform: 23 % of the oracle's rows have a top-1 / top-2 margin inside 0.5 x gap (2-4 bf16
-    # ulps of a logit), so a free-running frame stays identical with probability ~0.3 and the trajectories part within a frame or two -- at a
-    # near-tie, which is what is asserted: the frame in which the codes part must part at a row whose oracle margin is inside NEAR_TIE x gap.
-    if n_same < n_frames:
-        _same_until_a_near_tie(frames[n_same], ref[n_same], margins[n_same], noise, f"composed run, frame {n_same}")
     ms, mw = M.mimi_full(), M.make_weights(M.mimi_full(), seed=4321)
-    # PCM, composed: what generate() returned must be mimi_ref's decode of the codes the frame loop produced (all 10 frames) ...
     # (random weights can pick one of CSM's three codes beyond Mimi's 2,048-entry codebooks; the product clamps them -- mimi_hip.h,
     #  test_codes_beyond_codebook_are_clamped -- where the reference's embedding lookup would raise: the oracle gets them clamped)
-    top = 2047
-    want_own = M.decode(ms, mw, frames.t().unsqueeze(0).long().clamp(max=top))[0, 0]
+    want_own = M.decode(ms, mw, frames.t().unsqueeze(0).long().clamp(max=2047))[0, 0]
     peak = float(want_own.abs().max())
     err_own = float((pcm - want_own).abs().max())
-    # ... and, Mimi being strictly causal, the samples of the frames that are identical to the oracle's are the reference pipeline's samples
-    want = M.decode(ms, mw, ref.t().unsqueeze(0).long().clamp(max=top))[0, 0]   # csm_ref codes -> mimi_ref PCM: the reference -d cpu path's output
-    err_ref = float((pcm[: n_same * 1920] - want[: n_same * 1920]).abs().max()) if n_same else 0.0
-    print(f"composed prompt -> PCM: {n_same} of {n_frames} frames identical to the live oracle before the first near-tie parts them; "
-          f"PCM vs mimi_ref on the same codes: max|d| = {err_own:.3e} = {err_own / peak:.2e} of peak {peak:.3f}; vs the oracle pipeline over the identical frames: {err_ref:.3e}")
-    assert err_own <= 2e-5 * peak and err_ref <= 2e-5 * peak
+    print(f"composed prompt -> PCM (bench checkpoint): {n_same} of {n_frames} frames identical to the live oracle before a near-tie parts them; "
+          f"PCM vs mimi_ref on the same codes: max|d| = {err_own:.3e} = {err_own / peak:.2e} of peak {peak:.3f}")
+    assert err_own <= 2e-5 * peak
 
 
 @pytest.mark.parametrize("B", [1, 8])
