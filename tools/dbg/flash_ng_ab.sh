@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 AB=sesameai-tts_amd/lib/ab/libcsm_hip_ng1.so
 for rep in 1 2; do
   for lib in "$AB" ""; do
-    tag=$([ -n "$lib" ] && echo "AF_NG=1" || echo "AF_NG=2 (shipped)")
+    tag=$([ -n "$lib" ] && echo "round-4 order" || echo "shipped")
     for S in 190 700 1334; do
       echo -n "[$tag] "; CSM_HIP_LIB=$lib python tools/prefill_prof.py $S 12 2>&1 | tail -1
     done

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r05a}; mkdir -p $O
 timeout 1800 python -m pytest tests -m gpu -q -s > $O/gpu_tests_full.txt 2>&1
-tail -4 $O/gpu_tests_full.txt > $O/gpu_tests.txt
+grep -E "passed|failed" $O/gpu_tests_full.txt | tail -2 > $O/gpu_tests.txt
 grep -E "dlogit|excused|identical|\[parity\]|\[decisive\]|composed" $O/gpu_tests_full.txt | cut -c1-400 > $O/parity_margins.txt
 timeout 900 python bench.py > $O/final_bench.json 2> $O/bench_default.err
 prof() {   # prof <name> <bench args...>: kernel stats + FETCH_SIZE pass of one bench configuration
