@@ -29,6 +29,12 @@ static thread_local std::string g_mimi_err;
 
 #define MAX_TAPS 16
 
+// K-split workspace of a handle (mimi_create): partial tiles [MIMI_KSPLIT][cap_rows][cap_cols] fp32 + one ticket per output tile
+#define MIMI_KSPLIT 8                   // default number of K slices (MIMI_KSPLIT=n in the environment: 0 = off, 2 / 4 / 8; measured: profiles/r05/mimi_ksplit_ab.txt)
+#define MIMI_KSPLIT_MAX 8
+#define MIMI_KSPLIT_MIN_ITERS 64        // deep products only: (taps * C_in / 32) iterations, e.g. the K = 2048 linear (64), the 7-tap 512 -> 1024 conv (112)
+struct KSplitWs { float* part; int* ticket; long cap_rows; int cap_cols, n_tickets, ksplit; };
+
 struct GemmArgs {
     const float* x; long ldx;       // A row for output time t, tap j: x + (t * in_stride + shift0 + j * dshift) * ldx
     int in_stride;                  // 1, or the stride of a down-sampling conv
@@ -47,6 +53,10 @@ struct GemmArgs {
     // [0,d) -> rope_q[t] with RoPE, [d,2d) -> rope_k[rope_offset + t] with RoPE, [2d,3d) -> rope_v[rope_offset + t]; head_dim 64,
     // interleaved pairs (the partner channel sits in the neighbouring lane)
     float *rope_q, *rope_k, *rope_v; const float* rope_freqs; int rope_offset, rope_d;
+    // K split over blockIdx.z (round 5; phases == 1 only): block (tile, ks) runs iterations [ks, ks + 1) * iters / ksplit, parks its fp32
+    // partial tile in kpart[ks][T_in][C_out] with write-through stores, and the LAST of a tile's ksplit blocks to arrive adds the
+    // partials in ks order and runs the epilogue.  ksplit is a function of (taps, C_in) alone: streaming == whole decode, bit for bit.
+    int ksplit; float* kpart; int* kticket;
 };
 
 __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expf(v) - 1.0f; }
@@ -73,7 +83,8 @@ template <bool ELU>
 __global__ __launch_bounds__(64 * G32_NW) void k_gemm32(const GemmArgs a) {
     __shared__ float red[G32_NW][16][64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 32, p = blockIdx.z;
+    const int ks = a.ksplit > 1 ? (int)blockIdx.z : 0;
+    const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 32, p = a.ksplit > 1 ? 0 : (int)blockIdx.z;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -84,7 +95,8 @@ __global__ __launch_bounds__(64 * G32_NW) void k_gemm32(const GemmArgs a) {
     const int kchunks = a.C_in / 32, iters = a.taps * kchunks;
     const int arow0 = trow * a.in_stride + a.shift0;
     const float* const wrow = a.w + ((long)p * a.taps * a.C_out + nrow) * a.C_in + h * 16;
-    for (int it = wave; it < iters; it += G32_NW) {
+    const int it_lo = a.ksplit > 1 ? ks * (iters / a.ksplit) : 0, it_hi = a.ksplit > 1 ? it_lo + iters / a.ksplit : iters;
+    for (int it = it_lo + wave; it < it_hi; it += G32_NW) {
         const int j = it / kchunks, kc = (it - j * kchunks) * 32;
         int arow = arow0 + j * a.dshift;
         bool use = trow_ok;
@@ -119,6 +131,60 @@ __global__ __launch_bounds__(64 * G32_NW) void k_gemm32(const GemmArgs a) {
     // C/D map of the 32x32 tile: col = lane & 31 (channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (time);
     // wave g finishes registers 4g .. 4g+3
     const int ch = n0 + r;
+    float part4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.ksplit > 1) {
+        // park this K slice's partial tile (waves 0..3: registers 4w..4w+3, as in the epilogue), then take a ticket: the tile's last
+        // block reduces.  Write-through (sc1) stores + vmcnt(0) before the ticket, sc1 loads after it: the guide's counter hand-off.
+        if (wave < 4 && ch < a.C_out) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int reg = wave * 4 + i;
+                const int t = t0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < G32_NW; ++w) sum += red[w][reg][lane];      // fixed order
+                if (t < a.T_in) {
+                    float* dst = a.kpart + ((long)ks * a.T_in + t) * a.C_out + ch;
+                    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dst), "v"(sum) : "memory");
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ int s_last;
+        if (threadIdx.x == 0) {
+            int* tk = a.kticket + blockIdx.y * gridDim.x + blockIdx.x;
+            const int got = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = got == a.ksplit - 1;
+            if (s_last) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        }
+        __syncthreads();
+        if (!s_last) return;
+        if (wave < 4 && ch < a.C_out) {
+            float pv[4][MIMI_KSPLIT_MAX];                                            // every load in flight, ONE wait
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int reg = wave * 4 + i;
+                const int t = min(t0 + (reg & 3) + 8 * (reg >> 2) + 4 * h, a.T_in - 1);
+#pragma unroll
+                for (int q = 0; q < MIMI_KSPLIT_MAX; ++q) {
+                    pv[i][q] = 0.f;
+                    if (q < a.ksplit) {
+                        const float* src = a.kpart + ((long)q * a.T_in + t) * a.C_out + ch;
+                        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(pv[i][q]) : "v"(src) : "memory");
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float acc4 = 0.f;
+#pragma unroll
+                for (int q = 0; q < MIMI_KSPLIT_MAX; ++q) { asm volatile("" : "+v"(pv[i][q])); if (q < a.ksplit) acc4 += pv[i][q]; }     // slice order: deterministic whoever arrived last
+                part4[i] = acc4;
+            }
+        }
+    }
     if (ch >= a.C_out || wave >= 4) return;
     const float bias = a.bias ? a.bias[ch] : 0.f;
     const float cs = a.col_scale ? a.col_scale[ch] : 1.f;
@@ -128,8 +194,11 @@ __global__ __launch_bounds__(64 * G32_NW) void k_gemm32(const GemmArgs a) {
         const int t = t0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         if (t >= a.T_in) continue;
         float sum = 0.f;
+        if (a.ksplit > 1) sum = part4[i];
+        else {
 #pragma unroll
-        for (int w = 0; w < G32_NW; ++w) sum += red[w][reg][lane];          // fixed order
+            for (int w = 0; w < G32_NW; ++w) sum += red[w][reg][lane];          // fixed order
+        }
         const long orow = (long)t * a.phases + p;
         float v = sum + bias;
         if (a.rope_q) {                                                 // (whole 32-channel tiles: every lane of the half-wave is here)
@@ -343,6 +412,7 @@ struct HBuf {            // activation buffer with `hist` rows of left context i
     float* row0() const { return base + (long)hist * C; }
 };
 
+
 struct MimiDecoder {
     MimiConfig cfg;
     MimiWeights w;
@@ -353,6 +423,7 @@ struct MimiDecoder {
     HBuf u[MIMI_MAX_STAGES], xj[MIMI_MAX_STAGES];
     float *r1[MIMI_MAX_STAGES];
     float *tok, *ln, *q, *att, *ffn, *kc, *vc;
+    KSplitWs ksw = {nullptr, nullptr, 0, 0, 0, 0};
     hipStream_t cap_stream = nullptr;   // graph capture of decode_middle
     hipGraphExec_t mid_exec[65] = {};   // by T (stateless decodes of up to MIMI_GRAPH_MAX_T frames)
     int mid_uses[65] = {};
@@ -413,6 +484,19 @@ extern "C" int mimi_create(const MimiConfig* cfg, const MimiWeights* w, int max_
     A4(m->tok, T2 * d); A4(m->ln, T2 * d); A4(m->q, T2 * d); A4(m->att, T2 * d);
     A4(m->ffn, T2 * (cfg->tr_ffn > cfg->codebook_size ? cfg->tr_ffn : cfg->codebook_size));   // also the RVQ score buffer
     A4(m->kc, (long)cfg->tr_layers * m->cap_tokens * d); A4(m->vc, (long)cfg->tr_layers * m->cap_tokens * d);
+    {   // K-split workspace (k_gemm32): the deep products' partial tiles and tile tickets.  MIMI_KSPLIT=0 in the environment: no split.
+        const char* ev = getenv("MIMI_KSPLIT");
+        const int want = ev ? atoi(ev) : MIMI_KSPLIT;
+        if (want == 2 || want == 4 || want == 8) {
+            m->ksw.ksplit = want;
+            const int ccap = cfg->n_filters << cfg->n_stages;                         // widest output of a split product (conv_in); >= hidden
+            m->ksw.cap_rows = T2; m->ksw.cap_cols = ccap > d ? ccap : d;
+            m->ksw.n_tickets = (int)((T2 + 31) / 32) * ((m->ksw.cap_cols + 31) / 32);
+            A4(m->ksw.part, (long)want * m->ksw.cap_rows * m->ksw.cap_cols);
+            MCHK((MimiDecoder*)nullptr, hipMalloc((void**)&m->ksw.ticket, (size_t)m->ksw.n_tickets * 4));
+            MCHK((MimiDecoder*)nullptr, hipMemset(m->ksw.ticket, 0, (size_t)m->ksw.n_tickets * 4));
+        }
+    }
 #undef A4
     MCHK((MimiDecoder*)nullptr, hipDeviceSynchronize());
     *out = m;
@@ -423,7 +507,7 @@ extern "C" void mimi_destroy(mimi_handle m) {
     if (!m) return;
     (void)hipFree(m->rvq.base); (void)hipFree(m->a0.base); (void)hipFree(m->s0.base);
     for (int j = 0; j < m->cfg.n_stages; ++j) { (void)hipFree(m->u[j].base); (void)hipFree(m->xj[j].base); (void)hipFree(m->r1[j]); }
-    void* ps[] = {m->tok, m->ln, m->q, m->att, m->ffn, m->kc, m->vc};
+    void* ps[] = {m->tok, m->ln, m->q, m->att, m->ffn, m->kc, m->vc, m->ksw.part, m->ksw.ticket};
     for (void* p : ps) (void)hipFree(p);
     for (hipGraphExec_t g : m->mid_exec) if (g) (void)hipGraphExecDestroy(g);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
@@ -460,7 +544,7 @@ struct RopeOut { float *q, *k, *v; const float* freqs; int offset, d; };
 static hipError_t gemm(hipStream_t st, const float* x, long ldx, long T_in, const float* w, const float* bias, int C_in,
                        int C_out, int taps, int phases, const int* shifts, int elu_in, int act_out, const float* col_scale,
                        const float* resid, long ldr, float* out, long ldo, int in_stride = 1, int edge = 0, int row_lo = 0,
-                       int row_hi = 0, const RopeOut* rope = nullptr) {
+                       int row_hi = 0, const RopeOut* rope = nullptr, const KSplitWs* ksw = nullptr) {
     GemmArgs a;
     memset(&a, 0, sizeof a);
     if (rope) { a.rope_q = rope->q; a.rope_k = rope->k; a.rope_v = rope->v; a.rope_freqs = rope->freqs; a.rope_offset = rope->offset; a.rope_d = rope->d; }
@@ -471,6 +555,13 @@ static hipError_t gemm(hipStream_t st, const float* x, long ldx, long T_in, cons
     for (int j = 0; j < taps; ++j) if (shifts[j] != a.shift0 + j * a.dshift) return hipErrorInvalidValue;   // (every convolution here is an arithmetic progression of taps)
     a.act_out = act_out; a.col_scale = col_scale; a.resid = resid; a.ldr = ldr; a.out = out; a.ldo = ldo;
     dim3 grid((unsigned)((T_in + 31) / 32), (unsigned)((C_out + 31) / 32), (unsigned)phases);
+    // (the choice depends on the product's shape alone, never on T_in: a streamed chunk and the whole clip sum in the same order)
+    const int iters = taps * (C_in / 32);
+    if (ksw != nullptr && ksw->part != nullptr && phases == 1 && rope == nullptr && iters >= MIMI_KSPLIT_MIN_ITERS && iters % ksw->ksplit == 0) {
+        if (T_in > ksw->cap_rows || C_out > ksw->cap_cols || (long)grid.x * grid.y > ksw->n_tickets) return hipErrorInvalidValue;
+        a.ksplit = ksw->ksplit; a.kpart = ksw->part; a.kticket = ksw->ticket;
+        grid.z = (unsigned)ksw->ksplit;
+    }
     if (elu_in) hipLaunchKernelGGL(k_gemm32<true>, grid, dim3(64 * G32_NW), 0, st, a);
     else hipLaunchKernelGGL(k_gemm32<false>, grid, dim3(64 * G32_NW), 0, st, a);
     return hipGetLastError();
@@ -521,7 +612,7 @@ static int decode_middle(MimiDecoder* m, int T, hipStream_t st) {
         hipLaunchKernelGGL(k_layernorm, dim3((unsigned)T2), dim3(64), 0, st, m->tok, d, L.ln2_w, L.ln2_b, c.norm_eps, m->ln);
         MCHK(m, gemm(st, m->ln, d, T2, L.lin1, nullptr, d, c.tr_ffn, 1, 1, &zero, 0, 1, nullptr, nullptr, 0, m->ffn, c.tr_ffn));
         float* dst = (l + 1 < c.tr_layers) ? m->tok : m->a0.row0();
-        MCHK(m, gemm(st, m->ffn, c.tr_ffn, T2, L.lin2, nullptr, c.tr_ffn, d, 1, 1, &zero, 0, 0, L.ls2, m->tok, d, dst, d));
+        MCHK(m, gemm(st, m->ffn, c.tr_ffn, T2, L.lin2, nullptr, c.tr_ffn, d, 1, 1, &zero, 0, 0, L.ls2, m->tok, d, dst, d, 1, 0, 0, 0, nullptr, &m->ksw));
         MCHK(m, hipGetLastError());
     }
     // 4. SEANet decoder
@@ -529,7 +620,7 @@ static int decode_middle(MimiDecoder* m, int T, hipStream_t st) {
     for (int j = 0; j < c.kernel; ++j) shifts[j] = j - (c.kernel - 1);
     const MimiConv& ci = m->w.conv_in;
     MCHK(m, gemm(st, m->a0.row0(), d, T2, ci.w, ci.bias, ci.c_in, ci.c_out, ci.taps, 1, shifts, 0, 0, nullptr, nullptr, 0,
-                 m->s0.row0(), ci.c_out));
+                 m->s0.row0(), ci.c_out, 1, 0, 0, 0, nullptr, &m->ksw));
     const float* xin = m->s0.row0();
     int Cin = ci.c_out;
     long Tj = T2;

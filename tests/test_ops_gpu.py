@@ -513,11 +513,12 @@ def test_sampler_golden(abi):
         assert (frame[:, :7] == -1).all() and (frame[:, 8:] == -1).all()
 
 
-@pytest.mark.parametrize("V", [2051, 1000])
+@pytest.mark.parametrize("V", [2051, 1000, 2056, 2100])
 def test_sampler_random_parameters_vs_oracle(abi, V):
     """Random (temperature, top-k) pairs, logits on a coarse bf16 grid (many exact ties at the kth value): the HIP
     sampler must pick the oracle's index given the oracle's Exp(1) noise.  Integer-exact except where one
-    probability sits within a bf16 ulp of the decision (fp32 order of <= k exp-sums), as in the golden cases."""
+    probability sits within a bf16 ulp of the decision (fp32 order of <= k exp-sums), as in the golden cases.
+    V = 2051 / 2056 / 2100: a second 2,048-logit row with 3 / 8 / 52 live logits; V = 1000: one row."""
     from oracle.csm_ref import sample_topk
     g = torch.Generator().manual_seed(V)
     B, ldl = 64, 2560
