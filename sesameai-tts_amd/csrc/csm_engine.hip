@@ -24,7 +24,6 @@
 #include "dec_persist.cuh"
 #include "dec_persist_m.cuh"
 #include "bb_block.cuh"
-#include "bb_stack.cuh"
 
 #define BB_NSPLIT_MAX 8
 #define PART_ROWS 32
@@ -104,9 +103,6 @@ struct CsmModel {
     uint4* b_w2t;                       // [layers] W2 re-tiled, 256 * 4 * 2048 pieces each
     uint4* b_w2t8;                      // fp8 mode: [layers] e4m3 W2 re-tiled, 256 * 2 * 2048 pieces each
     bool bb_layer8;                     // fp8 mode: the one-launch layer streams the e4m3 bytes (k_bb_layer<true>)
-    bool bb_stack;                      // all layers in ONE launch (bb_stack.cuh: k_bb_stack; env CSM_BB_STACK)
-    BbStackLayer* b_stack_tab;          // [layers] its per-layer pointers
-    dp_u64* bg_x;                       // [8][1024] the residual row between two layers
     uint32_t* b_state;                  // [0] tag epoch, [1] give-up code
     uint4 *p_w2s, *p_w13p;              // [4 layers] re-tiled W2 / packed W1|W3, constant layer stride
     bf16_t *p_wsm, *p_norms;            // [4][2560][1024] q|k|v|o rows, [4][2][1024] norm scales
@@ -641,21 +637,6 @@ static hipError_t run_stack(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf16_t*
         nsplit = nsplit < 1 ? 1 : (nsplit > BB_NSPLIT_MAX ? BB_NSPLIT_MAX : nsplit);
     }
     hipError_t e;
-    if (&S == &m->bb && M == 1 && m->bb_stack && !m->bb_disabled && pos != nullptr && S.slot_off == 0) {
-        // every layer of the batch-1 step in ONE launch (bb_stack.cuh)
-        BbStackArgs T;
-        memset(&T, 0, sizeof T);
-        T.layers = m->b_stack_tab; T.n_layers = S.d.n_layers; T.rope = S.rope; T.h = h; T.pos = pos; T.smax = S.cache_len; T.eps = S.d.norm_eps;
-        T.gQ = m->bg_q; T.gA = m->bg_a; T.gS = m->bg_s; T.gH = m->bg_h; T.gP = m->bg_p; T.gX = m->bg_x;
-        T.err = m->b_state + 1; T.epoch = m->b_state; T.poll_sleep = m->persist ? m->p_poll : 1;
-        T.stamps = m->p_stamps != nullptr ? m->p_stamps + 5312 : nullptr;                                // (timeline build only: layer 8)
-        static const int credit = getenv("CSM_BB_STACK_CREDIT") ? atoi(getenv("CSM_BB_STACK_CREDIT")) : 0;
-#define BS_LAUNCH(c_) do { if (S.w8 != nullptr) hipLaunchKernelGGL((k_bb_stack<true, c_>), dim3(DP_NB), dim3(512), BS_LDS_BYTES, st, T); \
-                           else hipLaunchKernelGGL((k_bb_stack<false, c_>), dim3(DP_NB), dim3(512), BS_LDS_BYTES, st, T); } while (0)
-        if (credit == 4) BS_LAUNCH(4); else if (credit == 8) BS_LAUNCH(8); else if (credit == 12) BS_LAUNCH(12); else if (credit == 16) BS_LAUNCH(16);
-        else if (credit == 24) BS_LAUNCH(24); else if (credit < 0) BS_LAUNCH(-1); else BS_LAUNCH(0);
-        return hipGetLastError();
-    }
     for (int l = 0; l < S.d.n_layers; ++l) {
         const CsmLayerWeights& w = S.lw[l];
         bf16_t* kc = S.kc + (long)l * S.layer_stride + S.slot_off;
@@ -1209,38 +1190,6 @@ static void setup_bb_block(CsmModel* m) {
     m->bb_allocs = A.ptrs;
     m->bb_allocs.insert(m->bb_allocs.end(), L.ptrs.begin(), L.ptrs.end());
     if (f8) { m->b_w2t8 = w2t; m->bb_layer8 = true; } else { m->b_w2t = w2t; m->bb_layer = true; }
-    // ... and all layers in one launch
-    const char* ev3 = getenv("CSM_BB_STACK");
-    if (!(ev3 && ev3[0] == '1')) return;
-    bool fits_stack = true;
-#define BS_FITS(c_) fits_stack = fits_stack && (f8 ? all_cu_launch_fits(k_bb_stack<true, c_>, BS_LDS_BYTES, "one-launch backbone (fp8)") : all_cu_launch_fits(k_bb_stack<false, c_>, BS_LDS_BYTES, "one-launch backbone"))
-    BS_FITS(0); BS_FITS(4); BS_FITS(8); BS_FITS(12); BS_FITS(16); BS_FITS(24); BS_FITS(-1);
-    if (!fits_stack) return;
-    OptAllocs T;
-    T.small(m, &m->bg_x, (size_t)DP_NREP * 1024 * 8);
-    T.get(&m->b_stack_tab, sizeof(BbStackLayer) * (size_t)bc.n_layers);
-    if (!T.ok) { T.drop(); note_fallback("one-launch backbone", "allocation failed"); return; }
-    std::vector<BbStackLayer> tab((size_t)bc.n_layers);
-    for (int l = 0; l < bc.n_layers; ++l) {
-        BbStackLayer& t = tab[(size_t)l];
-        memset(&t, 0, sizeof t);
-        const CsmLayerWeights& w = m->w.bb[l];
-        t.wq = w.wq; t.wk = w.wk; t.wv = w.wv; t.wo = w.wo; t.w1 = w.w1; t.w3 = w.w3;
-        t.sa_norm = (const bf16_t*)w.sa_norm; t.mlp_norm = (const bf16_t*)w.mlp_norm;
-        t.kc = m->bb.kc + (long)l * m->bb.layer_stride; t.vc = m->bb.vc + (long)l * m->bb.layer_stride;
-        t.w2t = w2t + (size_t)l * per_layer;
-        if (f8) {
-            const CsmLayerWeights &w8 = m->w.bb8[l], &s8 = m->w.bb8s[l];
-            t.wq = w8.wq; t.wk = w8.wk; t.wv = w8.wv; t.wo = w8.wo; t.w1 = w8.w1; t.w3 = w8.w3;
-            t.sq = (const float*)s8.wq; t.sk = (const float*)s8.wk; t.sv = (const float*)s8.wv; t.so = (const float*)s8.wo;
-            t.s1 = (const float*)s8.w1; t.s3 = (const float*)s8.w3; t.s2 = (const float*)s8.w2;
-        }
-    }
-    if (hipMemcpy(m->b_stack_tab, tab.data(), sizeof(BbStackLayer) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipGetLastError(); T.drop(); note_fallback("one-launch backbone", "table upload failed"); return;
-    }
-    m->bb_allocs.insert(m->bb_allocs.end(), T.ptrs.begin(), T.ptrs.end());
-    m->bb_stack = true;
 }
 
 extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_batch, int max_rows, int max_frames,
@@ -1392,7 +1341,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     }
     // ---- all-CU launches (persistent depth decoders, one-launch backbone layers): optional fast paths.  Anything that
     //      fails here (shape, device, occupancy, allocation) leaves the flag off and the launch chain in charge.
-    m->persist = false; m->persist_m = false; m->p_stamps = nullptr; m->bb_block = false; m->bb_layer = false; m->bb_stack = false; m->persist_disabled = false; m->bb_disabled = false;
+    m->persist = false; m->persist_m = false; m->p_stamps = nullptr; m->bb_block = false; m->bb_layer = false; m->persist_disabled = false; m->bb_disabled = false;
     // the B = 1 launches' small exchange buffers (granule replicas: 18..96 KB each) come from ONE 2 MB-aligned slab at 4 KB steps instead of
     // wherever hipMalloc's sub-allocator has room -- same placement in every process (A/B: k_bb_layer 32.2..32.8 -> 31.9 us before the
     // scalar-load fix, within the noise after it; kept for the determinism).  CSM_XSLAB=0: separate allocations.

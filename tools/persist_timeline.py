@@ -105,15 +105,9 @@ def main():
         nm = ["entry (wave 0)", "q|k|v pair published (wave 0)", "attention vector in LDS (gather wave)", "o-proj rows published (wave 0)", "h1 in LDS (gather wave)",
               "gate/up done (wave 0)", "gate/up done (gather wave)", "h values exchanged (wave 0)", "W2 slice in LDS (wave 0)", "W2 slice in LDS (gather wave)",
               "partials published (wave 0)", "partials published (gather wave)", "rows written (gather wave)"]
-        stacked = float(bl[13]) > 0          # k_bb_stack (CSM_BB_STACK=1): all layers in one launch; times from "layer 8's input row in LDS"
-        if stacked:
-            nm[0] = "q|k|v rows in LDS: counted wait over (wave 0)"
-            nm += ["input row in LDS (wave 0 past the flag)", "next layer's input row in LDS (gather wave)", "next layer's requests issued (wave 0)"]
-        ref = float(bl[13]) if stacked else float(bl[0])
-        print("   one-launch backbone (k_bb_stack), workgroup 100, layer 8, us after its input row:" if stacked else
-              "   whole-backbone-layer launch (k_bb_layer), workgroup 100, layer 8, us after entry:")
+        print("   whole-backbone-layer launch (k_bb_layer), workgroup 100, layer 8, us after entry:")
         for i, n_ in enumerate(nm):
-            print(f"      {n_:52s} {float(bl[i]) - ref:6.2f}")
+            print(f"      {n_:44s} {float(bl[i] - bl[0]):6.2f}")
     whole = float(t[n_steps - 2, 19] - t[2, 19]) / (n_steps - 4)
     print(f"   step period measured directly: {whole:.2f} us")
 
