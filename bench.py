@@ -17,6 +17,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 `cpu_baseline` objects.  Inputs are resident in HBM before the timed region.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -756,6 +757,9 @@ def main():
         out["extras"] = {"config4": res}
     if dist is not None:
         dist.barrier()                     # every rank is through its GPU work; from here on nobody holds a GPU busy
+        # RCCL prints a version banner through C stdio, which on a pipe is flushed at process exit -- AFTER the JSON line.  Flush it here, on
+        # every rank, so that the line below is the last thing this job writes to stdout
+        ctypes.CDLL(None).fflush(None)
     if rank == 0:
         # the oracle beside it, on this host's cores, after the timed region.  The other ranks wait for it ASLEEP -- a key in the
         # rendezvous store, polled with sleeps -- not in an RCCL barrier, whose waiters spin on host cores and GPU queues beside the

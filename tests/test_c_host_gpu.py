@@ -138,3 +138,4 @@ def test_weight_broadcast_on_a_communicator_the_caller_owns():
         assert rc == -1 and b"communicator" in _abi.lib.csm_last_error(None)
     finally:
         rccl.ncclCommDestroy(comm)
+        C.CDLL(None).fflush(None)          # RCCL's version banner sits in C stdio's buffer: out now, into this test's captured output, not after pytest's summary line
