@@ -530,9 +530,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # BENCH_RCCL_WORLD1=1 (debug only): a ONE-rank RCCL process group on a 1-GPU box, and the N > 1 control flow on it (blob broadcasts,
+    # barriers, the all-gathered rank records, the config-4 leg) -- the real backend's calls, which the gloo twin mode never makes
+    multi = world > 1 or os.environ.get("BENCH_RCCL_WORLD1") == "1"
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        for k_, v_ in (("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k_, v_)
         if share0:
             dist.init_process_group("gloo")
         else:
@@ -546,7 +551,7 @@ def main():
     B = args.batch
     # ---- weights: rank 0 seeds them, the others receive one RCCL broadcast over xGMI --------
     bcast = None
-    if world > 1:
+    if multi:
         from sesameai.parallel import broadcast_state_dict, broadcast_flat
         stats = {}
         sd = broadcast_state_dict(margs, synthetic_state_dict(margs, seed=1234) if rank == 0 else None, dev, stats=stats)
@@ -610,7 +615,7 @@ def main():
     if not args.tiny and not args.no_mimi:
         from sesameai.mimi import MimiArgs, MimiCodec
         mimi_sd = None
-        if world > 1:                                  # rank 0 seeds the codec's weights too; one more flat broadcast
+        if multi:                                      # rank 0 seeds the codec's weights too; one more flat broadcast
             from sesameai.mimi import synthetic_state_dict as mimi_synthetic
             from sesameai.parallel import broadcast_named
             st_m = {}
@@ -741,10 +746,10 @@ def main():
             out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             out["rccl_version"] = None
-    if world == 1 and B == 1 and not args.tiny and not args.no_extras and args.weights == "bf16":
+    if not multi and B == 1 and not args.tiny and not args.no_extras and args.weights == "bf16":
         del model
         out["extras"] = extras_legs(args, margs, sd, dev)
-    elif world > 1 and not args.tiny and not args.no_extras and args.weights == "bf16":
+    elif multi and not args.tiny and not args.no_extras and args.weights == "bf16":
         # ---- BASELINE config 4: B = 32 per GPU on every rank (batch 32 x N sharded over the N GPUs, no per-step collective);
         #      aggregate = all ranks' frames / the slowest rank's time, like `value`
         del model

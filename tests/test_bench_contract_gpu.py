@@ -89,6 +89,27 @@ def test_two_full_size_ranks_carry_the_config4_leg_and_honest_kernel_entries():
     assert isinstance(d["roofline"]["dominant_kernels"], list)
 
 
+def test_the_multi_rank_control_flow_on_a_real_rccl_process_group_of_one_rank():
+    """BENCH_RCCL_WORLD1=1: the N > 1 control flow of bench.py (flat-blob weight broadcast, barriers, all-gathered rank records, max over
+    ranks) on an RCCL process group -- one rank, because the box has one GPU; the gloo twin mode above never calls RCCL.  The JSON line is
+    the LAST line of stdout: RCCL's version banner, which C stdio would flush at process exit, is flushed before it."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_RCCL_WORLD1"] = "1"
+    env["MASTER_PORT"] = "29547"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tiny", "--steps", "6", "--warmup", "2",
+                        "--ctx-text", "5", "--ctx-frames", "8", "--gen-text", "4", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    d = json.loads(lines[-1])                                      # (anything RCCL printed comes before it)
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["collective_backend"] == "nccl" and d["rccl_version"]
+    assert d["distinct_gpus"] == 1 and d["ranks"][0]["pci_bus_id"] and d["ranks"][0]["ms_per_step"] > 0
+    wb = d["weight_broadcast"]
+    assert wb["csm_bytes"] > 0 and wb["csm_ms"] > 0 and "nccl" in wb["collective"]
+
+
 def test_single_gpu_line_names_the_kernels_it_timed():
     """N = 1, CSM-1B: `roofline.dominant_kernels` must be the launches of the timed frame step -- the persistent depth decoder and
     the one-launch backbone layer -- timed live in the run, and `extras` must carry config 3 (with ITS kernel), the
