@@ -126,7 +126,9 @@ int csm_depth(csm_handle h, int B, float temperature, int topk, const int32_t* f
  * frame (kept on device) is embedded with mask [1 x32, 0] at the internal position, one
  * backbone step, csm_depth, position += 1, frame appended to the history, EOS flag
  * (all 32 codes == 0, generator.py:285) accumulated per sequence.  No host sync; the whole
- * step is captured once into a hipGraph and replayed.
+ * step is captured once into a hipGraph and replayed.  Up to 4 captured steps are kept per handle, keyed on
+ * (B, topk, temperature) and replaced least-recently-used first: callers that alternate sampling parameters or batch
+ * sizes (tts_service.py:175 uses 0.9/50, :266 0.8/40) replay, they do not capture again.
  * Batch 1 on the CSM-1B shapes: codebooks 2..31 and every backbone attention block run as launches of 256 workgroups
  * that must all be resident at once (csrc/dec_persist.cuh, csrc/bb_block.cuh).  Drive ONE frame loop per GPU (batch, or
  * one process per GPU); two loops sharing a GPU can starve each other, which ends -- after a bounded 50 ms spin, never a
@@ -198,6 +200,14 @@ int csm_refill_advance(csm_handle h, int max_layers, void* stream);
  * (sesameai/parallel.py: torch owns that communicator and does not hand out the ncclComm_t); plain-C hosts call this
  * (examples/c_host/csm_c_host.c).  The CsmWeights pointers handed to csm_create then point into the blob.      */
 int csm_broadcast_weights(void* dev_blob, size_t bytes, void* rccl_comm, int root, void* stream);
+
+/* What this handle runs, as one line of text: weight stream, the kernels of a batch-1 / batched backbone step, of the depth decoder and of
+ * prompts, the frame-graph cache, and every CSM_* / MIMI_* switch set in the environment.  Writes at most n - 1 characters + NUL into buf (may
+ * be NULL) and returns the length the whole text needs.  The reference has no counterpart (it has one eager path); bench.py records it with
+ * every number it prints (config.paths).                                                                                              */
+int csm_describe(csm_handle h, char* buf, int n);
+/* Lists on stderr, once per process, the environment names under CSM_ / MIMI_ that no switch reads (csm_create calls it).           */
+void csm_warn_unknown_switches(void);
 
 /* History readback: frames [first, first + n) as [n][B][32] i32 into host memory (synchronises the stream);
  * eos_at[b] = global index of the first all-zero frame of sequence b, or -1.  The history is a RING of max_frames frames

@@ -59,6 +59,10 @@ int csm_debug_persist_stamps(csm_handle h, uint64_t* host, int n_words);
  * (bf16 stream), bit 4 one-launch backbone layer (e4m3 stream, fp8 mode).                                                        */
 int csm_debug_fast_paths(csm_handle h);
 
+/* How many frame-step graphs the handle has captured + instantiated since csm_create.  csm_frame_step keeps up to 4 captured steps in an
+ * LRU keyed on (batch, top-k, temperature): revisiting a key replays, it does not capture again (tests/test_frame_gpu.py).              */
+int csm_debug_graph_captures(csm_handle h);
+
 /* Measurement hook of bench.py (roofline.dominant_kernels): times, on the handle's current state after at least one frame
  * step, `reps` back-to-back launches of (a) the persistent depth-decoder launch for batch B -- csrc/dec_persist.cuh at B = 1,
  * csrc/dec_persist_m.cuh at B = 2..32 -- and (b) a batch-1 backbone decode step (16 one-launch layers, csrc/bb_block.cuh),

@@ -75,7 +75,9 @@ typedef struct MimiWeights {
 
 typedef struct MimiDecoder* mimi_handle;
 
-/* max_frames = longest code sequence one call (or one stream) will carry. */
+/* max_frames = longest code sequence one call (or one stream) will carry.
+ * A handle's workspaces (activations, K-split partial tiles and their arrival tickets, the stream's history) are shared by all of its
+ * calls: drive ONE HIP stream per handle at a time (a side-stream chunk decode and a whole-clip decode need two handles).            */
 int  mimi_create(const MimiConfig* cfg, const MimiWeights* w, int max_frames, int reserved, mimi_handle* out);
 void mimi_destroy(mimi_handle h);
 const char* mimi_last_error(mimi_handle h);

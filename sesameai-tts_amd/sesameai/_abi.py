@@ -84,6 +84,8 @@ SIGNATURES = {
     "csm_frames_dev": (_vp, [_vp]),
     "csm_last_h_dev": (_vp, [_vp]),
     "csm_bytes_per_frame": (C.c_double, [_vp, _i, C.c_double]),
+    "csm_describe": (_i, [_vp, C.c_char_p, _i]),
+    "csm_warn_unknown_switches": (None, []),
     # include/csm_hip_ops.h
     "csm_op_gemv": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _f, _vp, _vp, _vp, _vp, _vp, _l, _vp, _l, _i,
                          _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -93,6 +95,7 @@ SIGNATURES = {
     "csm_op_sample": (_i, [_i, _i, _i, _vp, _f, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "csm_debug_persist_stamps": (_i, [_vp, _vp, _i]),
     "csm_debug_fast_paths": (_i, [_vp]),
+    "csm_debug_graph_captures": (_i, [_vp]),
     "csm_debug_time_kernels": (_i, [_vp, _i, _i, _f, _i, _vp, _vp]),
 }
 

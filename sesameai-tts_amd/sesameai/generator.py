@@ -84,12 +84,14 @@ class Generator:
         self._eos_poll = 8                     # frames launched between EOS polls
         self._mimi_stream = None               # side HIP stream for Mimi in generate_stream
 
-    def warm_up(self, temperature: float = 0.7, topk: int = 30) -> None:
+    def warm_up(self, temperature: float = 0.7, topk: int = 30, also=((0.8, 40), (0.9, 50))) -> None:
         """One short synthetic utterance through the streaming path and the whole-utterance path.  Everything a process does once --
         torch's first device kernels of each kind, the HIP module load, the frame-step graph's capture (for THIS temperature / top-k),
         the Mimi chunk graph, the side stream -- is paid here instead of by the first request: measured on an MI355X
         (tools/dbg/first_chunk_breakdown.py), the first utterance of a process took 164 ms to its first chunk against 30 ms for
-        every later one.  ``load_csm_1b`` calls it (CSM_NO_WARMUP=1 skips it); the reference has no counterpart."""
+        every later one.  ``load_csm_1b`` calls it (CSM_NO_WARMUP=1 skips it); the reference has no counterpart.
+        ``also``: further (temperature, top-k) pairs whose frame-step graphs are captured too -- the engine keeps 4 captured steps per
+        handle (csm_frame_step), and the reference's callers use 0.8 / 40 (tts_service.py:266) and 0.9 / 50 (:175) beside 0.7 / 30."""
         if self._audio_tokenizer is None or self.device.type != "cuda":
             return
         g = torch.Generator().manual_seed(0)
@@ -98,6 +100,9 @@ class Generator:
         for _ in self.generate_stream([11] * 12, 0, ctx, max_audio_length_ms=n * FRAME_MS, temperature=temperature, topk=topk):
             pass
         self.generate([11] * 12, 0, ctx, max_audio_length_ms=4 * FRAME_MS, temperature=temperature, topk=topk)
+        for (t, k) in also or ():
+            if (float(t), int(k)) != (float(temperature), int(topk)):
+                self._model.step(1, float(t), int(k))       # one more frame on the warm-up's state: captures that key's graph
         self._model._kv_prompt = None                       # the synthetic prompt is nobody's prefix
         # the warm-up's frames advanced the Philox step counter: put the noise stream back where a process without the warm-up
         # (CSM_NO_WARMUP=1) has it, so the two produce the same audio for the same requests

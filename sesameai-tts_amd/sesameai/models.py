@@ -75,10 +75,8 @@ def csm_tiny_2k_args() -> ModelArgs:
 # ----------------------------------------------------------------------------------------
 # host-side tables and weights
 # ----------------------------------------------------------------------------------------
-def llama3_rope_table(f: LlamaFlavor) -> torch.Tensor:
-    """[max_seq][hd/2][2] (cos, sin) of torchtune's Llama3ScaledRoPE (low/high freq factors 1/4,
-    old context 8192), built in fp32 on the host and rounded to bf16 like the reference's
-    ``model.to(dtype=bf16)`` rounds the registered buffer (sesameai/generator.py:343)."""
+def llama3_rope_theta(f: LlamaFlavor) -> torch.Tensor:
+    """Llama3ScaledRoPE's per-pair frequencies (fp32): base^(-2i/hd), long wavelengths divided by the scale factor."""
     hd = f.head_dim
     theta = 1.0 / (f.rope_base ** (torch.arange(0, hd, 2)[: hd // 2].float() / hd))
     old_len, lo, hi = 8192, 1.0, 4.0
@@ -92,7 +90,14 @@ def llama3_rope_table(f: LlamaFlavor) -> torch.Tensor:
         else:
             smooth = (old_len / wl - lo) / (hi - lo)
             scaled.append((1 - smooth) * fr / f.scale_factor + smooth * fr)
-    theta = torch.tensor(scaled, dtype=theta.dtype)
+    return torch.tensor(scaled, dtype=theta.dtype)
+
+
+def llama3_rope_table(f: LlamaFlavor) -> torch.Tensor:
+    """[max_seq][hd/2][2] (cos, sin) of torchtune's Llama3ScaledRoPE (low/high freq factors 1/4,
+    old context 8192), built in fp32 on the host and rounded to bf16 like the reference's
+    ``model.to(dtype=bf16)`` rounds the registered buffer (sesameai/generator.py:343)."""
+    theta = llama3_rope_theta(f)
     idx = torch.einsum("i,j->ij", torch.arange(f.max_seq_len, dtype=theta.dtype), theta).float()
     return torch.stack([torch.cos(idx), torch.sin(idx)], dim=-1).to(torch.bfloat16)
 
@@ -140,12 +145,18 @@ def synthetic_state_dict(args: ModelArgs, seed: int = 1234, std: float = 0.02, f
         sd[name] = t.to(torch.bfloat16)
     if flavour == "decisive":
         return _decisive_checkpoint(args, sd, seed)
+    if flavour.split(":")[0] == "decisive_copy":
+        f = flavour.split(":")
+        if len(f) not in (1, 3):
+            raise ValueError(f"decisive_copy flavour is 'decisive_copy' or 'decisive_copy:<layer>:<lag>', got {flavour!r}")
+        n_layers = FLAVORS[args.backbone_flavor].num_layers
+        return _decisive_copy_checkpoint(args, sd, seed, int(f[1]) if len(f) == 3 else n_layers // 2, int(f[2]) if len(f) == 3 else 3)
     if flavour != "bench":
         raise ValueError(f"unknown synthetic flavour {flavour!r}")
     return sd
 
 
-def _decisive_checkpoint(args: ModelArgs, sd: Dict[str, torch.Tensor], seed: int) -> Dict[str, torch.Tensor]:
+def _decisive_checkpoint(args: ModelArgs, sd: Dict[str, torch.Tensor], seed: int, last_gain: float = 4.0) -> Dict[str, torch.Tensor]:
     """A synthetic checkpoint that talks: random weights give near-uniform logits, so greedy decoding is a sequence of near-ties and
     two correct bf16 implementations drift apart within a frame.  Here each head reads back one embedding: codebook0_head's rows are
     the LAST codebook's embedding rows in a seeded order (the backbone's input is the sum of a frame's 32 embeddings, reference
@@ -166,20 +177,88 @@ def _decisive_checkpoint(args: ModelArgs, sd: Dict[str, torch.Tensor], seed: int
             out[name] = (sd[name].float() * 0.5).to(bf)
     audio = (sd["audio_embeddings.weight"].float() * 8.0).to(bf)
     lo = (ncb - 1) * V
-    audio[lo:lo + live] = (audio[lo:lo + live].float() * 4.0).to(bf)
+    audio[lo:lo + live] = (audio[lo:lo + live].float() * last_gain).to(bf)
     out["audio_embeddings.weight"] = audio
     named = audio[lo:lo + live]
     which = (torch.arange(args.text_vocab_size) * 40503) % live
     out["text_embeddings.weight"] = (sd["text_embeddings.weight"].float() * 8.0 + named[which].float()).to(bf)
     c0 = sd["codebook0_head.weight"].clone()
-    c0[:live] = (named[order[0]].float() / 32.0).to(bf)
+    c0[:live] = (named[order[0]].float() / (8.0 * last_gain)).to(bf)
     out["codebook0_head.weight"] = c0
-    proj_t = sd["projection.weight"].double().t()               # fp64 products, rounded once: the same bits on every host
-    heads = sd["audio_head"].clone()
+    out["audio_head"] = _chained_audio_heads(args, sd["audio_head"], audio, sd["projection.weight"], order)
+    return out
+
+
+def _chained_audio_heads(args: ModelArgs, heads: torch.Tensor, audio: torch.Tensor, projection: torch.Tensor, order) -> torch.Tensor:
+    """audio_head[i-1][:, v] = projection @ (codebook i-1's embedding row order[i][v]) / 8: step i of the depth decoder names the code that
+    step i-1 fed it (models.py:170-181)."""
+    V, ncb = args.audio_vocab_size, args.audio_num_codebooks
+    live = min(2048, V)
+    proj_t = projection.double().t()                            # fp64 products, rounded once: the same bits on every host
+    heads = heads.clone()
     for i in range(1, ncb):
         src = audio[(i - 1) * V:(i - 1) * V + live][order[i]].double()
-        heads[i - 1, :, :live] = ((src @ proj_t).t() / 8.0).float().to(bf)
-    out["audio_head"] = heads
+        heads[i - 1, :, :live] = ((src @ proj_t).t() / 8.0).float().to(torch.bfloat16)
+    return heads
+
+
+def _decisive_copy_checkpoint(args: ModelArgs, sd: Dict[str, torch.Tensor], seed: int, layer: int, lag: int) -> Dict[str, torch.Tensor]:
+    """The decisive checkpoint with the frame-to-frame decision moved INTO one backbone layer's attention, so that the free-running
+    greedy codes depend on what the KV cache holds (the plain decisive checkpoint is memoryless: frame t+1 follows from frame t's last
+    code through one row's residual stream, whatever attention does).  Every backbone row carries a large tag on 16 coordinates (added
+    to codebook 0's embedding rows and to the text rows: a row holds exactly one of the two); layer ``layer``'s q / k read nothing but
+    the tag, into the 8 fastest rotary pairs, the key side turned by ``lag`` positions, so the softmax is one-hot on the row ``lag``
+    back; its v / o projections carry a random image of THAT row into the current one, tall enough to lead the residual stream, and
+    codebook0_head's rows are the images of the last codebook's embedding rows: c0(t+1) names the last code of the row ``lag`` back, read
+    through the RoPE'd cached K and the cached V (reference path: sesameai/models.py:154-158 inside the loop of generator.py:283-294).
+    The projection loses the tag direction (the depth decoder never sees it) and the decoder's chain of heads is the decisive one.
+    Same construction as oracle/csm_ref.py decisive_copy_weights, written on its own; tests assert tensor equality."""
+    bf = torch.bfloat16
+    bb = FLAVORS[args.backbone_flavor]
+    V, ncb, d, hd = args.audio_vocab_size, args.audio_num_codebooks, bb.embed_dim, bb.head_dim
+    nh, nkv = bb.num_heads, bb.num_kv_heads
+    if not (0 <= layer < bb.num_layers and 1 <= lag < bb.max_seq_len):
+        raise ValueError(f"decisive_copy: layer {layer} / lag {lag} outside the backbone's {bb.num_layers} layers / {bb.max_seq_len} positions")
+    TAG, PAIRS, SHARP, LAST, LOGIT = 256.0, 8, 16.0, 8.0, 4.0
+    live = min(2048, V)
+    out = _decisive_checkpoint(args, sd, seed, last_gain=LAST)
+    pg = torch.Generator(device="cpu").manual_seed(seed * 1_000_003 + 17)
+    order = [torch.randperm(live, generator=pg) for _ in range(ncb)]
+    tg = torch.Generator(device="cpu").manual_seed(seed * 1_000_003 + 29)
+    tag = torch.zeros(d, dtype=torch.float64)
+    tag[torch.arange(16) * (d // 16) + 3] = (torch.randint(0, 2, (16,), generator=tg).double() * 2 - 1) / 4.0       # unit vector
+    strip = lambda m: m - (m @ tag)[:, None] * tag[None, :]                    # rows made orthogonal to the tag
+    out["projection.weight"] = strip(sd["projection.weight"].double()).float().to(bf)
+    out["audio_head"] = _chained_audio_heads(args, sd["audio_head"], out["audio_embeddings.weight"], out["projection.weight"], order)
+    audio = out["audio_embeddings.weight"].clone()
+    audio[:V] = (audio[:V].double() + TAG * tag).float().to(bf)
+    out["audio_embeddings.weight"] = audio
+    out["text_embeddings.weight"] = (out["text_embeddings.weight"].double() + TAG * tag).float().to(bf)
+    # tag . rmsnorm(row): the row's mean square is the tag's plus 31 embeddings at 8 x 0.02 and one at 8 x that
+    row_rms = math.sqrt(TAG * TAG / d + (8.0 * 0.02) ** 2 * ((ncb - 1) + LAST * LAST))
+    seen = TAG / row_rms
+    theta = llama3_rope_theta(bb).double()[:PAIRS]
+    drop = float((1.0 - torch.cos(theta)).sum())                              # what a neighbour of the target row loses, per unit of q.k
+    amp = math.sqrt(SHARP * math.sqrt(hd) / (drop * seen * seen))
+    Lp = f"backbone.layers.{layer}.attn."
+    q = torch.zeros(nh, hd, d, dtype=torch.float64)
+    k = torch.zeros(nkv, hd, d, dtype=torch.float64)
+    for j in range(PAIRS):
+        q[:, 2 * j] = amp * tag
+        k[:, 2 * j] = amp * math.cos(lag * float(theta[j])) * tag
+        k[:, 2 * j + 1] = amp * math.sin(lag * float(theta[j])) * tag
+    out[Lp + "q_proj.weight"] = q.reshape(nh * hd, d).float().to(bf)
+    out[Lp + "k_proj.weight"] = k.reshape(nkv * hd, d).float().to(bf)
+    out[Lp + "v_proj.weight"] = strip(sd[Lp + "v_proj.weight"].double()).float().to(bf)
+    wv, wo = out[Lp + "v_proj.weight"].double(), sd[Lp + "output_proj.weight"].double()
+    rows = out["audio_embeddings.weight"][(ncb - 1) * V:(ncb - 1) * V + live][order[0]].double()
+    image = (rows @ wv.t()).view(live, nkv, 1, hd).expand(live, nkv, nh // nkv, hd).reshape(live, nh * hd) @ wo.t()
+    size = image.norm(dim=1, keepdim=True)
+    gain = 2.0 ** round(math.log2(TAG * row_rms / float(size.mean())))        # the image stands as tall as the tag; a power of two
+    out[Lp + "output_proj.weight"] = (wo * gain).float().to(bf)
+    c0 = sd["codebook0_head.weight"].clone()
+    c0[:live] = (image / size * (LOGIT * math.sqrt(5.0) / math.sqrt(d))).float().to(bf)
+    out["codebook0_head.weight"] = c0
     return out
 
 
@@ -631,6 +710,18 @@ class Model:
     def fast_paths(self) -> int:
         """bit mask of the all-CU launches this handle runs (include/csm_hip_ops.h csm_debug_fast_paths)."""
         return int(lib.csm_debug_fast_paths(self._h))
+
+    def describe(self) -> str:
+        """One line of text: which kernels this handle runs and which CSM_* / MIMI_* switches are set (csm_describe)."""
+        self._require()
+        n = lib.csm_describe(self._h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib.csm_describe(self._h, buf, n + 1)
+        return buf.value.decode()
+
+    def graph_captures(self) -> int:
+        """frame-step graphs captured since setup_caches (include/csm_hip_ops.h csm_debug_graph_captures)."""
+        return int(lib.csm_debug_graph_captures(self._h))
 
     def bytes_per_frame(self, batch: int, p_mean: float) -> float:
         return lib.csm_bytes_per_frame(self._h, batch, float(p_mean))

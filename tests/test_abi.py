@@ -66,3 +66,16 @@ def test_plain_c_host_builds_against_the_header_and_the_library():
     r = subprocess.run(["make", "-B", "-C", d], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert os.path.exists(os.path.join(d, "csm_c_host")) and os.path.exists(os.path.join(d, "mimi_c_host"))
+
+
+def test_a_mistyped_switch_is_reported_once_on_stderr():
+    """CSM_* / MIMI_* switches are read with getenv at create time; a name no switch reads would silently leave the default in force.  The first
+    csm_create / mimi_create of a process lists such names once (include/csm_hip.h csm_warn_unknown_switches)."""
+    import subprocess, sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from sesameai import _abi; h = ctypes.c_void_p(None);"
+            "_abi.lib.csm_create(None, None, 1, 8, 8, ctypes.byref(h)); _abi.lib.csm_create(None, None, 1, 8, 8, ctypes.byref(h))") % os.path.join(ROOT, "sesameai-tts_amd")
+    env = dict(os.environ, CSM_PERSITS="0", MIMI_KSPLITT="4", CSM_PERSIST="1", CSM_QUIET="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stderr.splitlines() if "no switch reads" in ln]
+    assert len(lines) == 1 and "CSM_PERSITS" in lines[0] and "MIMI_KSPLITT" in lines[0] and "CSM_PERSIST " not in lines[0] + " " and "CSM_QUIET" not in lines[0]

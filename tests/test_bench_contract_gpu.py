@@ -55,6 +55,36 @@ def test_bench_self_launches_its_ranks_when_no_launcher_is_present():
     _check_rank_records(d, 2)
 
 
+def test_eight_ranks_start_rendezvous_and_report_rehearsal():
+    """The driver's 8-GPU run, rehearsed on this box's one GPU (never a measurement): `python bench.py --gpus 8 --tiny`
+    with BENCH_SHARE_GPU0=1 -- the GPU-free parent hosts the rendezvous store and starts eight rank processes, which build their process
+    group (gloo), receive the weight blob, step, all-gather their records and wait for rank 0's line.  Eight rank records, each with its
+    share of the host's threads (quota // 8, at least 1), the JSON line LAST on stdout, the whole thing inside two minutes."""
+    import time
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, ROOT)
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_SHARE_GPU0"] = "1"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--tiny", "--steps", "4", "--warmup", "1",
+                        "--ctx-text", "5", "--ctx-frames", "8", "--gen-text", "4", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    wall = time.time() - t0
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["config"]["parallelism"] == "replicas x8"
+    _check_rank_records(d, 8)
+    quota = bench.cpu_quota() or os.cpu_count() or 1
+    want_threads = max(1, min(quota, os.cpu_count() or quota) // 8)
+    assert all(r["host_threads"] <= max(1, want_threads) for r in d["ranks"]), ([r["host_threads"] for r in d["ranks"]], want_threads)
+    print(f"\n[8 ranks] start -> line in {wall:.1f} s; host threads per rank {sorted({r['host_threads'] for r in d['ranks']})} (quota {quota}); "
+          f"slowest rank {d['ms_per_step']:.2f} ms/step")
+    assert wall < 120, f"eight tiny ranks took {wall:.0f} s"
+
+
 def _check_rank_records(d, n):
     """The N > 1 line proves itself: the rank count is the process group's, every rank reports the device it ran
     on (index + PCI id), its own step time / frames / broadcast rate and its share of the host's threads."""
@@ -97,7 +127,6 @@ def test_the_multi_rank_control_flow_on_a_real_rccl_process_group_of_one_rank():
         pytest.skip("no GPU")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["BENCH_RCCL_WORLD1"] = "1"
-    env["MASTER_PORT"] = "29547"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tiny", "--steps", "6", "--warmup", "2",
                         "--ctx-text", "5", "--ctx-frames", "8", "--gen-text", "4", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=900, env=env)
