@@ -119,6 +119,11 @@ struct CsmModel {
     std::vector<void*> persist_allocs, bb_allocs;   // device memory of the optional all-CU launches
     char* xslab; size_t xslab_used, xslab_align;     // the small exchange buffers of the B = 1 all-CU launches live in one 2 MB-aligned slab (placement under our control)
     bool persist_disabled, bb_disabled;             // a launch gave up once: the chain runs from then on (the buffers stay: error words are still read)
+    // experiment (CSM_BB_PREFETCH=n, off by default): while the latency-bound kernels of a batched backbone layer run (q|k|v,
+    // split-key attention, o-proj, finisher: ~30 us with HBM nearly idle), n blocks on a SECOND stream touch that layer's gate/up/down weights
+    // (100 MB) so that the two MLP kernels find them in the 256 MB Infinity Cache; forked and joined with events (graph branches under capture)
+    int bb_prefetch;
+    hipStream_t pf_stream; hipEvent_t pf_fork[CSM_MAX_LAYERS], pf_join[CSM_MAX_LAYERS];
     bool have_last;                     // prefill or a frame step has produced h for csm_depth
     int last_S;                         // rows per sequence of the h buffer feeding csm_depth
     // captured frame steps: a small LRU keyed on (batch, top-k, temperature) -- a service whose requests alternate sampling parameters or
@@ -438,6 +443,25 @@ static hipError_t launch_attn(int hd, const AttnArgs& a, hipStream_t st, bool co
     return hipGetLastError();
 }
 
+// touch [p, p + n16) 16-byte pieces with ordinary (cache-allocating) loads; the value is folded into a store that never happens
+__global__ __launch_bounds__(256) void k_touch(const uint4* __restrict__ p0, long n0, const uint4* __restrict__ p1, long n1, const uint4* __restrict__ p2, long n2, uint32_t* sink) {
+    uint32_t acc = 0;
+    const long stride = (long)gridDim.x * blockDim.x, t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4* ps[3] = {p0, p1, p2};
+    const long ns[3] = {n0, n1, n2};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const uint4* p = ps[q];
+        long i = t;
+        for (; i + 3 * stride < ns[q]; i += 4 * stride) {            // four loads in flight per thread; one 16-byte piece per 128-byte line would do,
+            const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];   // but whole lines keep the access coalesced
+            acc ^= a.x ^ b.y ^ c.z ^ d.w;
+        }
+        for (; i < ns[q]; i += stride) acc ^= p[i].x;
+    }
+    if (acc == 0x9e3779b9u && sink != nullptr) *sink = acc;
+}
+
 // ---------------------------------------------------------------------------------------
 // one Llama stack over M token rows (in place on h)
 // ---------------------------------------------------------------------------------------
@@ -555,6 +579,16 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         // layer 0 normalises h directly; later layers got xn from the previous down-projection's finisher.
         // (layer 0 of a depth-decoder step >= 2: q/k/v were gathered from the precomputed table by the sampler)
         int kg = 1;
+        const bool pf = m->bb_prefetch > 0 && &S == &m->bb && !prompt && rows_per_seq == 1 && !f8 && l_begin == 0 && l_end == S.d.n_layers;
+        if (pf) {
+            if ((e = hipEventRecord(m->pf_fork[l], st)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(m->pf_stream, m->pf_fork[l], 0)) != hipSuccess) return e;
+            const long n13 = (long)((S.d.ffn + 31) / 32) * (d / 64) * 256, n2 = (long)((d + 31) / 32) * (S.d.ffn / 64) * 256;     // 16-byte pieces of the packed copies
+            hipLaunchKernelGGL(k_touch, dim3(m->bb_prefetch), dim3(256), 0, m->pf_stream, (const uint4*)pk.w1, n13, (const uint4*)pk.w3, n13, (const uint4*)pk.w2, n2,
+                               (uint32_t*)nullptr);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if ((e = hipEventRecord(m->pf_join[l], m->pf_stream)) != hipSuccess) return e;
+        }
         {
         if (!(l == 0 && qkv0_done)) {
             if (l == 0 && !x_normed && (e = launch_rmsnorm_rows(h, d, 0, M, d, (const bf16_t*)w.sa_norm, S.d.norm_eps, att, d, st, xp0)) != hipSuccess) return e;
@@ -595,6 +629,7 @@ static hipError_t run_stack_wide(CsmModel* m, Stack& S, bf16_t* h, bf16_t* q, bf
         if (e != hipSuccess) return e;
         if ((e = launch_resid_norm(h, m->slab, kg, M, d, 1, 0, M, (const bf16_t*)w.mlp_norm, S.d.norm_eps, att, d, st, prompt, xp)) != hipSuccess) return e;
         }
+        if (pf && (e = hipStreamWaitEvent(st, m->pf_join[l], 0)) != hipSuccess) return e;       // join: the MLP kernels start once the layer's weights were touched
         memset(&a, 0, sizeof a);
         a.x = att; a.x_row_stride = d; a.M = M; a.w0 = (const bf16_t*)pk.w1; a.w1 = (const bf16_t*)pk.w3; a.N = S.d.ffn;
         a.out = act; a.ldo = S.d.ffn; a.out_packed = xp;
@@ -1214,7 +1249,7 @@ static void setup_bb_block(CsmModel* m) {
 // can be re-run; none is needed in production.  A name under those prefixes that is NOT in the table selects nothing -- a typo would silently
 // leave the default in force -- so the first csm_create / mimi_create of a process lists such names once on stderr.
 static const char* const KNOWN_SWITCHES[] = {
-    "CSM_ATTN_MERGE", "CSM_BB_BLOCK", "CSM_BB_LAYER", "CSM_C_HOST_GPUS", "CSM_DEC_MLP_NT", "CSM_FP8_WIDE", "CSM_FUSE_DEC_ATTN", "CSM_G128_GATEUP_ROWS",
+    "CSM_ATTN_MERGE", "CSM_BB_BLOCK", "CSM_BB_LAYER", "CSM_BB_PREFETCH", "CSM_C_HOST_GPUS", "CSM_DEC_MLP_NT", "CSM_FP8_WIDE", "CSM_FUSE_DEC_ATTN", "CSM_G128_GATEUP_ROWS",
     "CSM_G128_MIN_ROWS", "CSM_G128_ROWTILES", "CSM_G256_MIN_ROWS", "CSM_G64_MAX_BLOCKS", "CSM_KEEP_FAST_PATHS", "CSM_MMT_MIN_ROWS", "CSM_MMT_OPS",
     "CSM_PERSIST", "CSM_PERSIST_FAULT", "CSM_PERSIST_M", "CSM_PERSIST_M_MAX", "CSM_PERSIST_M_TRICKLE", "CSM_PERSIST_POLL", "CSM_PERSIST_TRICKLE",
     "CSM_QKV0_TABLE", "CSM_QUIET", "CSM_SLAB_K", "CSM_WIDE", "CSM_WIDE_MIN", "CSM_XPACK", "CSM_XPACK_PROMPT", "CSM_XSLAB", "MIMI_GRAPH_MAX_T", "MIMI_KSPLIT",
@@ -1268,6 +1303,15 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     m->graph_clock = 0; m->graph_captures = 0; m->cap_stream = nullptr;
     m->pk8_c0_head = nullptr; m->pk8_audio_head = nullptr; m->bb.has_pk8 = false; m->dec.has_pk8 = false;
     m->host_frames = 0; m->have_last = false; m->last_S = 1;
+    m->bb_prefetch = 0; m->pf_stream = nullptr;
+    { const char* ev = getenv("CSM_BB_PREFETCH"); if (ev && atoi(ev) > 0) m->bb_prefetch = atoi(ev); }
+    if (m->bb_prefetch > 0) {
+        HIPCHK((CsmModel*)nullptr, hipStreamCreateWithFlags(&m->pf_stream, hipStreamNonBlocking));
+        for (int l = 0; l < cfg->backbone.n_layers; ++l) {
+            HIPCHK((CsmModel*)nullptr, hipEventCreateWithFlags(&m->pf_fork[l], hipEventDisableTiming));
+            HIPCHK((CsmModel*)nullptr, hipEventCreateWithFlags(&m->pf_join[l], hipEventDisableTiming));
+        }
+    }
     { const char* ev = getenv("CSM_FUSE_DEC_ATTN"); m->fuse_dec_attn = !(ev && ev[0] == '0'); }
     { const char* ev = getenv("CSM_WIDE"); m->wide_path = !(ev && ev[0] == '0'); }
     { const char* ev = getenv("CSM_WIDE_MIN"); m->wide_min = ev && atoi(ev) > 0 ? atoi(ev) : WIDE_MIN_ROWS; }
@@ -1418,6 +1462,10 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
 extern "C" void csm_destroy(csm_handle m) {
     if (!m) return;
     drop_frame_graphs(m);
+    if (m->pf_stream) {
+        for (int l = 0; l < m->cfg.backbone.n_layers; ++l) { (void)hipEventDestroy(m->pf_fork[l]); (void)hipEventDestroy(m->pf_join[l]); }
+        (void)hipStreamDestroy(m->pf_stream);
+    }
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     void* ptrs[] = {m->bb.kc, m->bb.vc, m->dec.kc, m->dec.vc, m->h, m->q, m->att, m->act, m->part, m->attn_ctr, m->dec_in, m->proj_emb, m->slab,
                     m->hdec, m->qd, m->attd, m->actd, m->logits, m->frame, m->cur_tokens, m->cur_mask, m->cur_pos,

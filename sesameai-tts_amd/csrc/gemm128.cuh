@@ -133,6 +133,21 @@ __global__ __launch_bounds__(256, MI <= 2 ? 2 : 1) void k_gemm128(const GemvArgs
 #pragma unroll
             for (int i = 0; i < 16; ++i) { tot[mi][ni][i] = 0.f; acc[mi][ni][i] = 0.f; }
 
+    // G128_NOFOLD (an A/B build only, `make nofold`): ONE K-ascending accumulation chain, no K-quarter fold -- NOT the
+    // bits of k_mm32 / k_mmt / k_mmq any more (parity tests off), 64 instead of 128 accumulator registers at MI = 2: prices the constraint.
+#ifdef G128_NOFOLD
+#define G128_FOLD ++in_quarter;
+#define G128_RESULT(mi_, ni_, i_) acc[mi_][ni_][i_]
+#else
+#define G128_FOLD                                                                        \
+        if (++in_quarter == per_quarter) {                 /* end of a K quarter: fold the partial, restart the chain */ \
+            in_quarter = 0;                                                              \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                            \
+                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                         \
+                    _Pragma("unroll") for (int i = 0; i < 16; ++i) { tot[mi][ni][i] += acc[mi][ni][i]; acc[mi][ni][i] = 0.f; } \
+        }
+#define G128_RESULT(mi_, ni_, i_) tot[mi_][ni_][i_]
+#endif
     const int per_quarter = K / 256;
     const int c_first = EPI == EPI_SLAB ? kq * per_quarter : 0, ns = EPI == EPI_SLAB ? per_quarter : K / 64;   // slices c_first .. c_first + ns - 1
     int in_quarter = 0;
@@ -151,12 +166,7 @@ __global__ __launch_bounds__(256, MI <= 2 ? 2 : 1) void k_gemm128(const GemvArgs
                 acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(am), as_bf16x8(b1), acc[mi][1], 0, 0, 0); \
             }                                                                            \
         }                                                                                \
-        if (++in_quarter == per_quarter) {                 /* end of a K quarter: fold the partial, restart the chain */ \
-            in_quarter = 0;                                                              \
-            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                            \
-                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                         \
-                    _Pragma("unroll") for (int i = 0; i < 16; ++i) { tot[mi][ni][i] += acc[mi][ni][i]; acc[mi][ni][i] = 0.f; } \
-        }                                                                                \
+        G128_FOLD                                                                        \
     }
     // (slices past the last one re-load the last one: no control flow around the register staging)
 #define G128_KOFF(s_) ((c_first + min((s_), ns - 1)) * 64)
@@ -250,11 +260,11 @@ __global__ __launch_bounds__(256, MI <= 2 ? 2 : 1) void k_gemm128(const GemvArgs
                 const int m = m0 + wm * 32 * MI + mi * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
                 if (EPI == EPI_SLAB) {
                     const int n = n0 + wn * 64 + ni * 32 + r;
-                    if (m < a.M && n < a.N) a.slab[((long)kq * a.M + m) * a.N + n] = tot[mi][ni][i];
+                    if (m < a.M && n < a.N) a.slab[((long)kq * a.M + m) * a.N + n] = G128_RESULT(mi, ni, i);
                     continue;
                 }
-                if (EPI == EPI_SWIGLU) mm_finish<EPI, HD>(a, m, n0 + wn * 32 + r, tot[mi][0][i], tot[mi][1][i]);
-                else mm_finish<EPI, HD>(a, m, n0 + wn * 64 + ni * 32 + r, tot[mi][ni][i], 0.f);
+                if (EPI == EPI_SWIGLU) mm_finish<EPI, HD>(a, m, n0 + wn * 32 + r, G128_RESULT(mi, 0, i), G128_RESULT(mi, 1, i));
+                else mm_finish<EPI, HD>(a, m, n0 + wn * 64 + ni * 32 + r, G128_RESULT(mi, ni, i), 0.f);
             }
         }
     }
@@ -264,3 +274,5 @@ __global__ __launch_bounds__(256, MI <= 2 ? 2 : 1) void k_gemm128(const GemvArgs
 #undef G128_LWRITE
 #undef G128_MMA
 #undef G128_KOFF
+#undef G128_FOLD
+#undef G128_RESULT
