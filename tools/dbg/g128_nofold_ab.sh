@@ -21,8 +21,8 @@ for lib in "" "$NF"; do
   export CSM_HIP_LIB=$lib
   rm -rf /tmp/nf_$tag; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/nf_$tag -- python3 $R/tools/prefill_prof.py 1334 10 > /dev/null 2>&1
   echo "== kernel stats, one 1,334-row prompt [$tag]: name, calls, average ns"
-  python3 $R/tools/pmc_summary.py stats /tmp/nf_$tag /tmp/nf_$tag.csv > /dev/null; grep -E "k_gemm128|k_attn_flash|k_resid_norm" /tmp/nf_$tag.csv | cut -d, -f1,2,4 | head -8
+  python3 $R/tools/pmc_summary.py stats /tmp/nf_$tag /tmp/nf_$tag.csv > /dev/null; python3 -c "import csv,sys; [print(f'   {r[0][:60]:60s} calls {r[1]:>4s}  avg {float(r[3])/1e3:9.1f} us') for r in csv.reader(open(sys.argv[1])) if r and any(k in r[0] for k in ('k_gemm128','k_attn_flash','k_resid_norm'))]" /tmp/nf_$tag.csv
   rm -rf /tmp/nf_$tag; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/nf_$tag -- python3 $R/tools/dbg/prefill_b32.py 1334 > /dev/null 2>&1
   echo "== kernel stats, 32 x 1,334 rows [$tag]"
-  python3 $R/tools/pmc_summary.py stats /tmp/nf_$tag /tmp/nf_$tag.csv > /dev/null; grep -E "k_gemm128|k_attn_flash" /tmp/nf_$tag.csv | cut -d, -f1,2,4 | head -8
+  python3 $R/tools/pmc_summary.py stats /tmp/nf_$tag /tmp/nf_$tag.csv > /dev/null; python3 -c "import csv,sys; [print(f'   {r[0][:60]:60s} calls {r[1]:>4s}  avg {float(r[3])/1e3:9.1f} us') for r in csv.reader(open(sys.argv[1])) if r and any(k in r[0] for k in ('k_gemm128','k_attn_flash'))]" /tmp/nf_$tag.csv
 done

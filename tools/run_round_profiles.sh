@@ -1,19 +1,23 @@
-# Round-end evidence run on the GPU box (rounds 4-5): full GPU suite with the parity prints, default bench line, rocprofv3 kernel stats of the bench
+# Round-end evidence run on the GPU box (rounds 4-6): full GPU suite with the parity prints, default bench line, rocprofv3 kernel stats of the bench
 # at B = 1 / B = 32 / B = 1 with the fp8 weight stream, PMC traffic passes (FETCH_SIZE) for the three, kernel stats of the S = 190 and S = 1334
-# prefills, batch sweep, timelines of the persistent launches, soaks.  Summaries land in gpurun_out/$1 (default r05a); copy what is to be
-# judged to profiles/.     gpurun --timeout 2700 -- 'bash tools/run_round_profiles.sh r05a'
+# prefills, batch sweep, timelines of the persistent launches, soaks.  Summaries land in gpurun_out/$1 (default r06a); copy what is to be
+# judged to profiles/.     gpurun --timeout 2700 -- 'bash tools/run_round_profiles.sh r06a'
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/${1:-r05a}; mkdir -p $O
+O=gpurun_out/${1:-r06a}; mkdir -p $O
 timeout 1800 python -m pytest tests -m gpu -q -s > $O/gpu_tests_full.txt 2>&1
 grep -E "passed|failed" $O/gpu_tests_full.txt | tail -2 > $O/gpu_tests.txt
-grep -E "dlogit|excused|identical|\[parity\]|\[decisive\]|composed" $O/gpu_tests_full.txt | cut -c1-400 > $O/parity_margins.txt
+grep -E "dlogit|excused|identical|\[parity\]|\[decisive|\[possweep\]|\[soak\]|\[8 ranks\]|composed" $O/gpu_tests_full.txt | cut -c1-400 > $O/parity_margins.txt
 timeout 900 python bench.py > $O/final_bench.json 2> $O/bench_default.err
+# the N > 1 control flow at full size on a one-rank RCCL process group, timed stage by stage (8 x its host-side set-up must fit the driver's 1,800 s)
+( /usr/bin/time -v env BENCH_RCCL_WORLD1=1 python bench.py --steps 20 --warmup 5 --extra-steps 5 > $O/rccl_one_rank_bench.json ) 2> $O/rccl_one_rank_bench.err
+grep -E "^\[bench|Elapsed|Maximum resident" $O/rccl_one_rank_bench.err > $O/rccl_one_rank_stages.txt
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 prof() {   # prof <name> <bench args...>: kernel stats + FETCH_SIZE pass of one bench configuration
     local name=$1; shift
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_$name -- python3 bench.py --no-cpu-baseline --no-extras --no-mimi --steps 20 --warmup 2 "$@" > $O/${name}_bench_under_rocprof.json 2> $O/${name}_rocprof.err
     python tools/pmc_summary.py stats $O/st_$name $O/${name}_kernel_stats.csv > /dev/null
     timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_$name -- python3 bench.py --no-cpu-baseline --no-extras --no-mimi --steps 20 --warmup 2 "$@" > $O/${name}_bench_under_pmc.json 2> $O/${name}_pmc.err
-    python tools/pmc_summary.py traffic $O/pmc_$name $O/${name}_pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --no-mimi --steps 20 --warmup 2 $* (round 5)" > /dev/null
+    python tools/pmc_summary.py traffic $O/pmc_$name $O/${name}_pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --no-mimi --steps 20 --warmup 2 $* (round 6)" > /dev/null
     rm -rf $O/st_$name $O/pmc_$name
 }
 prof final
@@ -22,7 +26,7 @@ prof fp8 --weights fp8
 cp $O/final_pmc_traffic.json $O/pmc_traffic.json
 # matrix-core busy of the B = 32 frame step ("an MFMA-busy pass for B = 32 at HEAD")
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mf_b32 -- python3 bench.py --batch 32 --no-cpu-baseline --no-extras --no-mimi --steps 10 --warmup 2 > /dev/null 2>&1
-python tools/pmc_summary.py mfma $O/mf_b32 $O/pmc_mfma_util_b32.json "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --batch 32 --no-cpu-baseline --no-extras --no-mimi --steps 10 --warmup 2 (round 5, config 3)" > /dev/null
+python tools/pmc_summary.py mfma $O/mf_b32 $O/pmc_mfma_util_b32.json "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --batch 32 --no-cpu-baseline --no-extras --no-mimi --steps 10 --warmup 2 (round 6, config 3)" > /dev/null
 rm -rf $O/mf_b32
 # GPU time of ONE csm_create (the table builds): kernel stats of a process that only creates a B = 1 handle
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_create -- python3 tools/dbg/create_only.py > $O/create_only.txt 2>&1
@@ -31,7 +35,7 @@ for S in 190 1334; do
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pf_$S -- python3 tools/prefill_prof.py $S 10 > $O/prefill_S$S.txt 2>&1
     python tools/pmc_summary.py stats $O/pf_$S $O/prefill_S${S}_kernel_stats.csv > /dev/null
     timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pfm_$S -- python3 tools/prefill_prof.py $S 4 > /dev/null 2>&1
-    python tools/pmc_summary.py mfma $O/pfm_$S $O/pmc_mfma_util_S$S.json "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/prefill_prof.py $S 4 (round 5)" > /dev/null
+    python tools/pmc_summary.py mfma $O/pfm_$S $O/pmc_mfma_util_S$S.json "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/prefill_prof.py $S 4 (round 6)" > /dev/null
     rm -rf $O/pf_$S $O/pfm_$S
 done
 R=$GRAFT_REPO_ROOT; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/mimi_prof -o mimi -- python3 $R/tools/mimi_prof.py > $R/$O/mimi_prof_under_rocprof.txt 2>&1)
