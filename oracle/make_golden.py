@@ -415,6 +415,31 @@ def main():
         torch.save(decisive_copy_golden(C.csm_tiny(), 1234, full=False), os.path.join(OUT, "tiny_decisive_copy.pt"))
     if want("copy"):
         torch.save(decisive_copy_golden(C.csm_1b(), 1234, full=True), os.path.join(OUT, "csm1b_decisive_copy.pt"))
+    if a.only == "copyx":
+        # more copy layers / lags on the 190-row prompt, added to the existing file: the FIRST layer with lag 1 (layer 0 normalises the embedding
+        # sum itself; lag 1 reads the row the immediately preceding frame step appended -- from frame 2 on) and the LAST layer with lag 7 (its
+        # finisher applies the stack's final norm)
+        shape = C.csm_1b()
+        path = os.path.join(OUT, "csm1b_decisive_copy.pt")
+        gold = torch.load(path)
+        seed = int(gold["weight_seed"])
+        tok, msk = bench_prompt(shape, 2025)
+        for name, flavour in (("s190_first", "decisive_copy:0:1"), ("s190_last", f"decisive_copy:{shape.backbone.num_layers - 1}:7")):
+            layer, lag = C.copy_flavour_params(shape, flavour)
+            w = C.make_weights(shape, seed=seed, flavour=flavour)
+            names = [n for n in DECISIVE_CHECKSUM_NAMES + [f"backbone.layers.{layer}.attn.{t}_proj.weight" for t in ("q", "k", "v", "output")] if n in w]
+            gold["weight_checksums"][flavour] = (names, torch.stack([w[n].view(torch.int16).to(torch.int64).sum() for n in names]))
+            gold["flavours"][name] = flavour
+            for tag in ("bf16", "fp8"):
+                wts = w if tag == "bf16" else C.fp8_dequantized(w)
+                g = free_run(shape, wts, tok, msk, 32, f"{flavour} {tag} {name}")
+                want_codes = C.decisive_copy_expected_codes(shape, seed, tok, msk, 32, lag)
+                assert torch.equal(g["codes"][:, 0].to(torch.int32), want_codes), "the oracle left the trajectory the construction implies"
+                g["prompt_rows"] = tok.shape[0]
+                g["faults_changed"] = copy_fault_check(shape, wts, flavour, tok, msk, want_codes, n=max(8, lag + 5))
+                gold[f"{tag}_{name}"] = g
+            del w
+        torch.save(gold, path)
     if want("possweep"):
         shape = C.csm_1b()
         w = C.make_weights(shape, seed=1234)

@@ -9,8 +9,8 @@ grep -E "passed|failed" $O/gpu_tests_full.txt | tail -2 > $O/gpu_tests.txt
 grep -E "dlogit|excused|identical|\[parity\]|\[decisive|\[possweep\]|\[soak\]|\[8 ranks\]|composed" $O/gpu_tests_full.txt | cut -c1-400 > $O/parity_margins.txt
 timeout 900 python bench.py > $O/final_bench.json 2> $O/bench_default.err
 # the N > 1 control flow at full size on a one-rank RCCL process group, timed stage by stage (8 x its host-side set-up must fit the driver's 1,800 s)
-( /usr/bin/time -v env BENCH_RCCL_WORLD1=1 python bench.py --steps 20 --warmup 5 --extra-steps 5 > $O/rccl_one_rank_bench.json ) 2> $O/rccl_one_rank_bench.err
-grep -E "^\[bench|Elapsed|Maximum resident" $O/rccl_one_rank_bench.err > $O/rccl_one_rank_stages.txt
+( TIMEFORMAT='whole process: %R s wall, %U s user, %S s sys'; time BENCH_RCCL_WORLD1=1 python bench.py --steps 20 --warmup 5 --extra-steps 5 > $O/rccl_one_rank_bench.json ) 2> $O/rccl_one_rank_bench.err
+grep -E "^\[bench|whole process" $O/rccl_one_rank_bench.err > $O/rccl_one_rank_stages.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 prof() {   # prof <name> <bench args...>: kernel stats + FETCH_SIZE pass of one bench configuration
     local name=$1; shift
