@@ -254,8 +254,12 @@ __global__ __launch_bounds__(256) void k_rvq(const int* codes, long stride_k, lo
 }
 
 // depthwise ConvTranspose1d k4 s2, causal: out[2t+p][c] = x[t][c] w[p][0][c] + x[t-1][c] w[p][1][c]
-__global__ void k_upsample(const float* x, long ldx, int T, int C, const float* w, float* out, long ldo) {
+// (+ the K-split tiles' arrival tickets back to zero: they reset themselves, but only in a launch that completes -- the first kernel of every
+//  pass puts them at zero so that an aborted launch cannot leave a tile one arrival ahead; no launch of its own)
+__global__ void k_upsample(const float* x, long ldx, int T, int C, const float* w, float* out, long ldo, int* tickets, int n_tickets) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tickets != nullptr)
+        for (long j = i; j < n_tickets; j += (long)gridDim.x * blockDim.x) tickets[j] = 0;
     if (i >= (long)T * 2 * C) return;
     const int c = (int)(i % C);
     const long n = i / C;
@@ -593,27 +597,17 @@ static int decode_front(MimiDecoder* m, const int32_t* codes, long stride_k, lon
     return 0;
 }
 
-__global__ void k_zero_i32(int* p, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
-}
-
 static int decode_middle(MimiDecoder* m, int T, hipStream_t st) {
     const MimiConfig& c = m->cfg;
     const int d = c.hidden;
     const long T2 = 2L * T;
     const int zero = 0;
-    // the K-split tiles' arrival tickets reset themselves (the last block of a tile stores 0), but only in a launch that completes: start
-    // every pass from zero so that an aborted launch cannot leave a tile one arrival ahead (a kernel node, so the captured chunk graph
-    // carries it too).  ONE stream per handle: the partial tiles and tickets are per handle (include/mimi_hip.h).
-    if (m->ksw.ticket != nullptr) {
-        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(256), 0, st, m->ksw.ticket, m->ksw.n_tickets);
-        MCHK(m, hipGetLastError());
-    }
+    // (ONE stream per handle: the K-split partial tiles and their tickets are per handle, include/mimi_hip.h)
     // 2. depthwise transposed conv x2 -> tok [2T][d]
     {
         const long n = T2 * d;
         hipLaunchKernelGGL(k_upsample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->rvq.row0(), (long)d, T, d,
-                           m->w.upsample, m->tok, (long)d);
+                           m->w.upsample, m->tok, (long)d, m->ksw.ticket, m->ksw.ticket ? m->ksw.n_tickets : 0);
         MCHK(m, hipGetLastError());
     }
     // 3. transformer
