@@ -440,6 +440,22 @@ def main():
                 gold[f"{tag}_{name}"] = g
             del w
         torch.save(gold, path)
+    if a.only == "copymany":
+        # the twelve utterances of the continuously refilled batch of 8 (decisive_many_prompts) on the copy checkpoint: a refill writes a prompt's K/V
+        # into ONE slot of a live batch, and every slot then steps at its own position -- what the free-running codes read back
+        shape = C.csm_1b()
+        path = os.path.join(OUT, "csm1b_decisive_copy.pt")
+        gold = torch.load(path)
+        seed = int(gold["weight_seed"])
+        _, lag = C.copy_flavour_params(shape, COPY_SHORT)
+        w = C.make_weights(shape, seed=seed, flavour=COPY_SHORT)
+        many = []
+        for i, ((tok, msk), lim) in enumerate(decisive_many_prompts(shape)):
+            g = free_run(shape, w, tok, msk, lim, f"{COPY_SHORT} bf16 many[{i}] S={tok.shape[0]}")
+            assert torch.equal(g["codes"][:, 0].to(torch.int32), C.decisive_copy_expected_codes(shape, seed, tok, msk, lim, lag))
+            many.append(g["codes"][:, 0].clone())
+        gold["bf16_many"] = many
+        torch.save(gold, path)
     if want("possweep"):
         shape = C.csm_1b()
         w = C.make_weights(shape, seed=1234)

@@ -394,6 +394,58 @@ def test_copy_checkpoint_config3_batch32_graph_loop(copy_ckpt, dtype):
     assert m.fast_paths() & 2, "the batched persistent decoder did not run"
 
 
+@pytest.mark.parametrize("beside", [True, False])
+def test_copy_checkpoint_refilled_batch_of_8(copy_ckpt, beside):
+    """Twelve utterances of mixed prompt lengths and length limits through 8 slots that are kept full, on the copy checkpoint: a refill writes a
+    prompt's K / V into ONE slot of a live batch (beside the frame loop a few layers at a time, or through csm_prefill_slot), every slot then steps
+    at its own position, and each utterance's free-running codes -- read back out of ITS slot's cache rows -- are the ones the oracle generates
+    for it alone.  (The memoryless checkpoint above holds the plumbing of the same engine; this one would move if a slot's K / V landed in
+    another slot's rows, at another position, or were left stale by a refill.)"""
+    gold, get = copy_ckpt
+    from oracle.make_golden import decisive_many_prompts
+    from oracle import csm_ref as C
+    sd = get(gold["flavours"]["s190"])
+    want = [w.to(torch.int32) for w in gold["bf16_many"]]
+    spec = decisive_many_prompts(C.csm_1b())
+    prompts, limits = [p for p, _ in spec], [lim for _, lim in spec]
+    assert [w.shape[0] for w in want] == limits
+    m = _fresh_model(sd, "bf16", 8)
+    gen = _generator(m, batch=8)
+    gen.refill_beside_the_loop = beside
+    got = gen.generate_codes_continuous(prompts, limits, 1.0, 1)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert torch.equal(g, w), f"utterance {i} (S={prompts[i][0].shape[0]}, {limits[i]} frames) differs from the oracle's (refill beside the loop = {beside})"
+    assert m.fast_paths() & 2, "the batched persistent decoder did not run"
+
+
+def test_plain_c_host_on_the_copy_checkpoint(copy_ckpt, tmp_path):
+    """examples/c_host/csm_c_host.c (gcc + the HIP runtime + include/csm_hip.h, no Python in the process) on the KV-cache-dependent checkpoint:
+    its own csm_prefill -> csm_depth -> csm_frame_step loop reproduces the oracle's 64 free-running frames."""
+    from test_c_host_gpu import HOST, _write_blob
+    gold, get = copy_ckpt
+    if not os.path.exists(HOST):
+        r = subprocess.run(["make", "-C", os.path.dirname(HOST)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    sd = get(gold["flavours"]["s190"])
+    tok, msk = _prompts(128_256)["s190"]
+    want = gold["bf16_s190"]["codes"][:, 0].to(torch.int32)
+    n = want.shape[0]
+    blob = str(tmp_path / "csm1b_decisive_copy.blob")
+    m = _fresh_model(sd, "bf16", 1)
+    _write_blob(blob, m, tok, msk)
+    del m
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD",)}
+        r = subprocess.run([HOST, blob, str(n), "1.0", "1"], capture_output=True, text=True, timeout=600, env=env)
+    finally:
+        os.unlink(blob)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln[:1].isdigit() or ln[:1] == "-" or ln.startswith(("eos_at", "replicas"))]
+    got = torch.tensor([[int(x) for x in ln.split()] for ln in lines[:n]], dtype=torch.int32)
+    assert lines[n] == "eos_at -1"
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp8"])
 def test_tiny_copy_checkpoint_free_run_single_and_batched(dtype):
     if not torch.cuda.is_available():
