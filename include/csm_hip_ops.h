@@ -56,7 +56,8 @@ int csm_debug_persist_stamps(csm_handle h, uint64_t* host, int n_words);
 
 /* Which optional all-CU launches the handle runs (so a test can assert the path it means to cover): bit 0 persistent depth decoder
  * (B = 1), bit 1 batched persistent depth decoder (B = 2..32), bit 2 backbone attention block, bit 3 one-launch backbone layer
- * (bf16 stream), bit 4 one-launch backbone layer (e4m3 stream, fp8 mode).                                                        */
+ * (bf16 stream), bit 4 one-launch backbone layer (e4m3 stream, fp8 mode), bit 5 the first depth-decoder step (codebook 1, both
+ * positions) as one launch (csrc/dec_first.cuh, B = 1).                                                                           */
 int csm_debug_fast_paths(csm_handle h);
 
 /* How many frame-step graphs the handle has captured + instantiated since csm_create.  csm_frame_step keeps up to 4 captured steps in an

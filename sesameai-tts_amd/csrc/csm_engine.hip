@@ -23,6 +23,7 @@
 #include "sampler.cuh"
 #include "dec_persist.cuh"
 #include "dec_persist_m.cuh"
+#include "dec_first.cuh"
 #include "bb_block.cuh"
 
 #define BB_NSPLIT_MAX 8
@@ -96,7 +97,10 @@ struct CsmModel {
     // persistent depth decoder (dec_persist.cuh): steps 2..ncb-1 of a batch-1 frame as one launch (env CSM_PERSIST=0 disables)
     bool persist;
     dp_u64 *pg_q, *pg_h1, *pg_h2, *pg_l, *pg_p;
-    uint32_t* p_state;                  // [0] tag epoch, [1] give-up code of the last launch (0 = ok)
+    uint32_t* p_state;                  // [0] tag epoch, [1] give-up code of the last launch (0 = ok), [2] tag epoch of the first-step launch
+    // the first decoder step (codebook 1: positions 0, 1) of a batch-1 frame as one launch (dec_first.cuh; env CSM_DEC_FIRST=0 disables)
+    bool dec_first;
+    dp_u64 *fg_q, *fg_h1, *fg_h2, *fg_l, *fg_p;
     // backbone attention block of a batch-1 decode step as one launch per layer (bb_block.cuh)
     bool bb_block;
     dp_u64 *bg_q, *bg_a, *bg_s;
@@ -848,6 +852,19 @@ static hipError_t launch_dec_persist(CsmModel* m, int B, float temperature, int 
     return hipGetLastError();
 }
 
+static bool first_usable(const CsmModel* m, int B) { return B == 1 && m->dec_first && m->persist && !m->persist_disabled; }
+static hipError_t launch_dec_first(CsmModel* m, hipStream_t st) {
+    DecFirstArgs p;
+    memset(&p, 0, sizeof p);
+    p.wsm = m->p_wsm; p.norms = m->p_norms; p.w2s = m->p_w2s; p.w13p = m->p_w13p;
+    p.dec_norm = (const bf16_t*)m->w.dec_norm; p.head_t = (const bf16_t*)m->w.audio_head_t; p.rope = m->dec.rope;
+    p.hdec = m->hdec; p.kc = m->dec.kc; p.vc = m->dec.vc; p.kv_layer_stride = m->dec.layer_stride;
+    p.V = m->cfg.audio_vocab; p.logits = m->logits;
+    p.gQ = m->fg_q; p.gH1 = m->fg_h1; p.gH2 = m->fg_h2; p.gL = m->fg_l; p.gP = m->fg_p;
+    p.err = m->p_state + 1; p.epoch = m->p_state + 2; p.eps = m->cfg.decoder.norm_eps; p.trickle_sleep = m->p_trickle; p.poll_sleep = m->p_poll;
+    return csm_launch_dec_first(p, st);
+}
+
 // c0 head + 31 depth-decoder steps (models.py:160-184); h rows = [B][S][d_bb], last row used
 // rng: the Philox words the samplers draw from -- the frame loop's {seed, step} unless a slot refill passes its own domain
 static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int topk, const int* forced,
@@ -870,6 +887,12 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
                 if (B >= m->wide_min && m->wide_path) { a.w0 = m->pk_projection; e = launch_mm(0, dbb, 0, a, st); }
                 else e = launch_gemv(0, dbb, 0, a, st);
                 if (e != hipSuccess) return e;
+            }
+            if (cb == 1 && first_usable(m, B)) {
+                // the four layers on both rows AND the head of codebook 1 as ONE launch (dec_first.cuh): K / V of positions 0, 1 and the logits row
+                // are left where the chain's step left them
+                if ((e = launch_dec_first(m, st)) != hipSuccess) return e;
+                goto head_done;
             }
             // decoder positions are static per step: rows (0,1) on the first call, then cb
             const int* pos = m->dec_pos + (long)(cb == 1 ? 0 : cb) * 2 * m->max_batch;
@@ -913,6 +936,7 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             else { a.w0 = (const bf16_t*)((const char*)m->w.audio_head8 + (long)(cb - 1) * V * dd); a.s0 = (const float*)m->w.audio_head8s + (long)(cb - 1) * V; }
             if ((e = launch_gemv8(2, cb == 0 ? dbb : dd, 0, a, st)) != hipSuccess) return e;
         } else if ((e = launch_gemv(2, cb == 0 ? dbb : dd, 0, a, st)) != hipSuccess) return e;
+    head_done:
         if (logits_out) {
             e = hipMemcpy2DAsync((char*)logits_out + (size_t)cb * B * V * 2, (size_t)V * 2, m->logits, (size_t)m->ldl * 2,
                                  (size_t)V * 2, B, hipMemcpyDeviceToDevice, st);
@@ -1185,6 +1209,16 @@ static void setup_persist(CsmModel* m) {
     { const char* e2 = getenv("CSM_PERSIST_POLL"); m->p_poll = e2 ? atoi(e2) : 0; }             // (round 3, alternating A/B at the final state: 0 beats 1 by 17 us per frame, 2.744 against 2.762 ms)
     m->persist = true;
     m->persist_allocs = A.ptrs;
+    {   // ---- the first decoder step (positions 0, 1) as one launch: shares the decoder's re-tiled weights, own granule slots ----
+        const char* evf = getenv("CSM_DEC_FIRST");
+        if (!(evf && evf[0] == '0') && all_cu_launch_fits(csm_dec_first_kernel(), DF_LDS_BYTES, "first depth-decoder step")) {
+            OptAllocs F;
+            F.small(m, &m->fg_q, (size_t)DP_NREP * 1536 * 8); F.small(m, &m->fg_h1, (size_t)DP_NREP * 1024 * 8); F.small(m, &m->fg_h2, (size_t)DP_NREP * 1024 * 8);
+            F.small(m, &m->fg_l, (size_t)DP_NREP * DP_LSLOTS * 8); F.get(&m->fg_p, (size_t)2 * 256 * 1024 * 8);
+            if (!F.ok) { F.drop(); note_fallback("first depth-decoder step", "allocation failed"); }
+            else { m->dec_first = true; m->persist_allocs.insert(m->persist_allocs.end(), F.ptrs.begin(), F.ptrs.end()); }
+        }
+    }
     // ---- the batched form (2..32 rows): shares the q|k|v|o rows and the norms, own packed MLP weights and exchange buffers ----
     const char* evm = getenv("CSM_PERSIST_M");
     { const char* e2 = getenv("CSM_PERSIST_M_TRICKLE"); m->pm_trickle = e2 ? atoi(e2) : 4; }
@@ -1249,7 +1283,7 @@ static void setup_bb_block(CsmModel* m) {
 // can be re-run; none is needed in production.  A name under those prefixes that is NOT in the table selects nothing -- a typo would silently
 // leave the default in force -- so the first csm_create / mimi_create of a process lists such names once on stderr.
 static const char* const KNOWN_SWITCHES[] = {
-    "CSM_ATTN_MERGE", "CSM_BB_BLOCK", "CSM_BB_LAYER", "CSM_BB_PREFETCH", "CSM_C_HOST_GPUS", "CSM_DEC_MLP_NT", "CSM_FP8_WIDE", "CSM_FUSE_DEC_ATTN", "CSM_G128_GATEUP_ROWS",
+    "CSM_ATTN_MERGE", "CSM_BB_BLOCK", "CSM_BB_LAYER", "CSM_BB_PREFETCH", "CSM_C_HOST_GPUS", "CSM_DEC_FIRST", "CSM_DEC_MLP_NT", "CSM_FP8_WIDE", "CSM_FUSE_DEC_ATTN", "CSM_G128_GATEUP_ROWS",
     "CSM_G128_MIN_ROWS", "CSM_G128_ROWTILES", "CSM_G256_MIN_ROWS", "CSM_G64_MAX_BLOCKS", "CSM_KEEP_FAST_PATHS", "CSM_MMT_MIN_ROWS", "CSM_MMT_OPS",
     "CSM_PERSIST", "CSM_PERSIST_FAULT", "CSM_PERSIST_M", "CSM_PERSIST_M_MAX", "CSM_PERSIST_M_TRICKLE", "CSM_PERSIST_POLL", "CSM_PERSIST_TRICKLE",
     "CSM_QKV0_TABLE", "CSM_QUIET", "CSM_SLAB_K", "CSM_WIDE", "CSM_WIDE_MIN", "CSM_XPACK", "CSM_XPACK_PROMPT", "CSM_XSLAB", "MIMI_GRAPH_MAX_T", "MIMI_KSPLIT",
@@ -1439,7 +1473,7 @@ extern "C" int csm_create(const CsmConfig* cfg, const CsmWeights* w, int max_bat
     }
     // ---- all-CU launches (persistent depth decoders, one-launch backbone layers): optional fast paths.  Anything that
     //      fails here (shape, device, occupancy, allocation) leaves the flag off and the launch chain in charge.
-    m->persist = false; m->persist_m = false; m->p_stamps = nullptr; m->bb_block = false; m->bb_layer = false; m->persist_disabled = false; m->bb_disabled = false;
+    m->persist = false; m->persist_m = false; m->dec_first = false; m->p_stamps = nullptr; m->bb_block = false; m->bb_layer = false; m->persist_disabled = false; m->bb_disabled = false;
     // the B = 1 launches' small exchange buffers (granule replicas: 18..96 KB each) come from ONE 2 MB-aligned slab at 4 KB steps instead of
     // wherever hipMalloc's sub-allocator has room -- same placement in every process (A/B: k_bb_layer 32.2..32.8 -> 31.9 us before the
     // scalar-load fix, within the noise after it; kept for the determinism).  CSM_XSLAB=0: separate allocations.
@@ -1519,7 +1553,7 @@ extern "C" int csm_broadcast_weights(void* dev_blob, size_t bytes, void* rccl_co
 // After a launch that gave up (bounded spin timed out) stale granules may carry tags the next launch would accept: move the
 // tag epoch far ahead and clear the error word, so the handle is usable again after csm_reset.
 __global__ void k_persist_recover(uint32_t* state) {
-    if (state[1] != 0u) { state[0] += 0x100000u; state[1] = 0u; }
+    if (state[1] != 0u) { state[0] += 0x100000u; state[2] += 0x100000u; state[1] = 0u; }      // ([2]: the first-step launch's epoch; unused by b_state)
 }
 
 extern "C" int csm_reset(csm_handle m, void* stream) {
@@ -1895,7 +1929,8 @@ extern "C" double csm_bytes_per_frame(csm_handle m, int B, double p_mean) {
     double w = wb * c.backbone.n_layers * layer(c.backbone) + wd * c.decoder.n_layers * layer(c.decoder);
     w += wb * 2.0 * c.audio_vocab * c.backbone.dim;                              // c0 head
     w += 2.0 * c.decoder.dim * c.backbone.dim;                                   // projection (one bf16 GEMV per frame)
-    w += (wb + wd * (c.n_codebooks - 2)) * 2.0 * (double)c.audio_vocab * c.decoder.dim;   // audio heads: codebook 1 on the chain, 2.. in the launch
+    const double w1 = first_usable(m, B) ? wd : wb;                               // codebook 1's head: in k_dec_first (bf16 copies) or on the chain
+    w += (w1 + wd * (c.n_codebooks - 2)) * 2.0 * (double)c.audio_vocab * c.decoder.dim;   // audio heads: codebook 1, then 2.. in the persistent launch
     const double kv = 2.0 * c.backbone.n_layers * 2.0 * c.backbone.n_kv_heads * (c.backbone.dim / c.backbone.n_heads) * (p_mean + 1);
     return w + B * kv;
 }
@@ -1939,7 +1974,7 @@ extern "C" int csm_describe(csm_handle m, char* buf, int n) {
     snprintf(tmp, sizeof tmp, "; backbone_step_batched=%s (rows >= %d%s)", m->wide_path ? "k_mm32 / k_attn / k_resid_norm_row chain" : "k_gemv chain", m->wide_min,
              m->xpack ? ", operand-order activations from 24 rows" : "");
     t += tmp;
-    t += std::string("; decoder_b1=") + (m->persist && !m->persist_disabled ? "k_dec_persist (codebooks 2..)" : "launch chain");
+    t += std::string("; decoder_b1=") + (m->persist && !m->persist_disabled ? (first_usable(m, 1) ? "k_dec_first (codebook 1) + k_dec_persist (codebooks 2..)" : "k_dec_persist (codebooks 2..)") : "launch chain");
     if (m->persist_m && !m->persist_disabled) { snprintf(tmp, sizeof tmp, "; decoder_batched=k_dec_persist_m (2..%d rows), chain beyond", m->pm_max_rows); t += tmp; }
     else t += "; decoder_batched=launch chain";
     t += std::string("; prompt=") + (m->wide_path ? "k_mm32 / k_mmt / k_mmq (< 256 rows), k_gemm128 + k_attn_flash (>= 256 rows)" : "k_gemv chain");
@@ -1957,7 +1992,7 @@ extern "C" int csm_debug_graph_captures(csm_handle m) { return m ? m->graph_capt
 extern "C" int csm_debug_fast_paths(csm_handle m) {
     if (!m) return 0;
     return (m->persist && !m->persist_disabled ? 1 : 0) | (m->persist_m && !m->persist_disabled ? 2 : 0) | (m->bb_block && !m->bb_disabled ? 4 : 0) |
-           (m->bb_layer && !m->bb_disabled ? 8 : 0) | (m->bb_layer8 && !m->bb_disabled ? 16 : 0);
+           (m->bb_layer && !m->bb_disabled ? 8 : 0) | (m->bb_layer8 && !m->bb_disabled ? 16 : 0) | (first_usable(m, 1) ? 32 : 0);
 }
 
 // Times the two dominant launches of a decode step on the handle's CURRENT state, each `reps` times back to back between HIP events on
