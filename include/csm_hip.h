@@ -129,10 +129,10 @@ int csm_depth(csm_handle h, int B, float temperature, int topk, const int32_t* f
  * step is captured once into a hipGraph and replayed.  Up to 4 captured steps are kept per handle, keyed on
  * (B, topk, temperature) and replaced least-recently-used first: callers that alternate sampling parameters or batch
  * sizes (tts_service.py:175 uses 0.9/50, :266 0.8/40) replay, they do not capture again.
- * Batch 1 on the CSM-1B shapes: codebooks 2..31 and every backbone attention block run as launches of 256 workgroups
- * that must all be resident at once (csrc/dec_persist.cuh, csrc/bb_block.cuh).  Drive ONE frame loop per GPU (batch, or
+ * Batch 1 on the CSM-1B shapes: codebooks 1..31 and every backbone layer run as launches of 256 workgroups
+ * that must all be resident at once (csrc/dec_first.cuh, csrc/dec_persist.cuh, csrc/bb_block.cuh).  Drive ONE frame loop per GPU (batch, or
  * one process per GPU); two loops sharing a GPU can starve each other, which ends -- after a bounded 50 ms spin, never a
- * hang -- in CSM_E_HIP from csm_read_frames; csm_reset makes the handle usable again.  CSM_PERSIST=0 / CSM_BB_BLOCK=0
+ * hang -- in CSM_E_HIP from csm_read_frames; csm_reset makes the handle usable again.  CSM_PERSIST=0 / CSM_DEC_FIRST=0 / CSM_BB_BLOCK=0
  * select the plain launch chain.                                                              */
 int csm_frame_step(csm_handle h, int B, float temperature, int topk, int use_graph, void* stream);
 /* Copies the most recent frame [B][32] i32 to out_frame (dev) on the stream.                 */

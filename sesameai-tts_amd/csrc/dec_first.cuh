@@ -64,15 +64,43 @@ enum { DF_E_XA = 0, DF_E_Q = 1, DF_E_H1 = 2, DF_E_P = 3, DF_E_H2 = 4 };
 __device__ __forceinline__ uint32_t df_tag(uint32_t base, int l, int e) { return base + 1u + (uint32_t)(l * 5 + e); }
 #define DF_EPOCH_STEP 32u
 
+// dp_attention_head for at most FOUR keys (positions 0..3; here nk <= 2): that function walks all 32 key slots of the head, 4 per group, and dead
+// keys contribute exact zeros (score -inf -> p = 0, "+ 0.0" leaves every running sum's bits unchanged) -- so walking only the first group of four
+// gives the same bits with an eighth of the LDS reads and DPP chains (and only the first KB of each head's K / V image has to be zero).
+__device__ __forceinline__ void df_attention_head4(const dp_lu4* qb, const dp_lu4* kt, const dp_lu32* vt, dp_lf32* myps, dp_lu32* att, int h, int nk,
+                                                   float ascale, int lane) {
+    const int grp = lane >> 4, sub = lane & 15;
+    const uint4 qa = dp_ldq(qb + h * 16 + sub);
+    const uint4 kv = dp_ldq(kt + lane);
+    const bool live = grp < nk;
+    const float d0 = row16_sum(dot8(qa, kv, 0.f)) * ascale;
+    float s0 = live ? d0 : -INFINITY;
+    const float mx0 = wave_max(s0);
+    s0 = (s0 == -INFINITY) ? 0.f : __expf(s0 - mx0);
+    if (sub == 0) myps[grp] = s0;
+    const float l0 = wave_sum(s0) * (1.0f / 16.0f);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const u32x4_t p4 = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>(myps);
+    const float pw[4] = {__uint_as_float(p4.x), __uint_as_float(p4.y), __uint_as_float(p4.z), __uint_as_float(p4.w)};
+    uint32_t vr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vr[u] = vt[u * 64 + lane];
+    float o00 = 0.f, o01 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { o00 += pw[u] * lo2f(vr[u]); o01 += pw[u] * hi2f(vr[u]); }
+    const float i0 = 1.0f / l0;
+    att[h * 64 + lane] = pack_bf(o00 * i0, o01 * i0);
+}
+
 // heads `wave` of layer l for both rows (row r attends to keys 0..r), then one arrival on the attention counter
 __device__ __forceinline__ void df_attention_wave(char* lds, int wave, int l, int lane) {
     dp_lu32* misc = (dp_lu32*)(lds + DF_OFF_MISC);
     const int kvh = wave >> 2;
 #pragma unroll
     for (int r = 0; r < 2; ++r)
-        dp_attention_head((const dp_lu4*)(lds + DF_OFF_QB + r * 2048), (const dp_lu4*)(lds + DF_OFF_K + ((l * 2 + kvh) * 32) * 256),
-                          (const dp_lu32*)(lds + DF_OFF_V + ((l * 2 + kvh) * 32) * 256), (dp_lf32*)(lds + DF_OFF_PS) + wave * 32,
-                          (dp_lu32*)(lds + DF_OFF_ATT + r * 2048), wave, r + 1, 0.08838834764831845f, lane);
+        df_attention_head4((const dp_lu4*)(lds + DF_OFF_QB + r * 2048), (const dp_lu4*)(lds + DF_OFF_K + ((l * 2 + kvh) * 32) * 256),
+                           (const dp_lu32*)(lds + DF_OFF_V + ((l * 2 + kvh) * 32) * 256), (dp_lf32*)(lds + DF_OFF_PS) + wave * 32,
+                           (dp_lu32*)(lds + DF_OFF_ATT + r * 2048), wave, r + 1, 0.08838834764831845f, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(misc + DF_M_ATTN, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -256,7 +284,9 @@ static __global__ __launch_bounds__(512) void k_dec_first(const DecFirstArgs a) 
         ropev = reinterpret_cast<const uint32_t*>(a.rope)[lane * (DP_HD / 2) + e / 2];
     }
     for (int i = threadIdx.x; i < 256; i += 512) misc[i] = 0;
-    for (int i = threadIdx.x; i < (DF_OFF_PS - 0) / 16; i += 512) dp_stq((dp_lu4*)lds + i, make_uint4(0, 0, 0, 0));     // K, V (dead keys stay finite), x / q / att
+    // the first four key slots (1 KB) of each (layer, KV head) image of K and of V: positions 2, 3 stay zero (finite: a dead key's exact-zero
+    // probability times it adds +0.0); the x / q / attention buffers are written before they are read
+    for (int i = threadIdx.x; i < 16 * 64; i += 512) dp_stq((dp_lu4*)(lds + (i >> 6 & 1 ? DF_OFF_V : DF_OFF_K) + (i >> 7) * 8192) + (i & 63), make_uint4(0, 0, 0, 0));
     __syncthreads();
     const uint32_t base = dp_sload32(a.epoch);
     if (wave == 7) {

@@ -299,6 +299,9 @@ __device__ __forceinline__ void dp_reduce_partials(const uint32_t (&v)[16], floa
 // stage_attn (gemv.cuh) for one row and ONE head, with q / K / V in LDS (that kernel walks two heads of a KV group
 // per wave; per head the lane layout and the operation order are the same): lane l holds 16-byte pieces of keys
 // 4i + l/16 (i = 0..7) at element offset 8 (l % 16).  Eight waves take one head each.
+// NG = 4-key groups walked (8 = all 32 slots).  Groups beyond the live keys contribute exact zeros, so any NG with 4 NG >= nk gives the same bits
+// (DP_ATTN_GROUPS build: dp_attention_wave picks the smallest of 1 / 2 / 4 / 8 for the step's key count).
+template <int NG = 8>
 __device__ __forceinline__ void dp_attention_head(const dp_lu4* qb, const dp_lu4* kt, const dp_lu32* vt, dp_lf32* myps, dp_lu32* att,
                                                   int h, int nk, float ascale, int lane) {
     // stage_attn skips whole 4-key groups beyond nk by uniform branches; here every group is walked (its LDS reads and
@@ -306,12 +309,12 @@ __device__ __forceinline__ void dp_attention_head(const dp_lu4* qb, const dp_lu4
     // score -inf -> p = 0, v read as 0 -> "+ 0.0" leaves every running sum's bits unchanged.
     const int grp = lane >> 4, sub = lane & 15;
     const uint4 qa = dp_ldq(qb + h * 16 + sub);
-    uint4 kv[8];
+    uint4 kv[NG];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kv[i] = dp_ldq(kt + i * 64 + lane);
-    float s0[8], mx0 = -INFINITY;
+    for (int i = 0; i < NG; ++i) kv[i] = dp_ldq(kt + i * 64 + lane);
+    float s0[NG], mx0 = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NG; ++i) {
         const bool live = (4 * i + grp) < nk;
         const float d0 = row16_sum(dot8(qa, kv[i], 0.f)) * ascale;
         s0[i] = live ? d0 : -INFINITY;
@@ -320,7 +323,7 @@ __device__ __forceinline__ void dp_attention_head(const dp_lu4* qb, const dp_lu4
     mx0 = wave_max(mx0);
     float l0 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NG; ++i) {
         s0[i] = (s0[i] == -INFINITY) ? 0.f : __expf(s0[i] - mx0);
         l0 += s0[i];
         if (sub == 0) myps[4 * i + grp] = s0[i];
@@ -329,7 +332,7 @@ __device__ __forceinline__ void dp_attention_head(const dp_lu4* qb, const dp_lu4
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float o00 = 0.f, o01 = 0.f;
 #pragma unroll
-    for (int t4 = 0; t4 < 8; ++t4) {                         // 4 keys at a time: one broadcast read of their p, four reads of their v
+    for (int t4 = 0; t4 < NG; ++t4) {                        // 4 keys at a time: one broadcast read of their p, four reads of their v
         const u32x4_t p4 = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>(myps + 4 * t4);
         const float pw[4] = {__uint_as_float(p4.x), __uint_as_float(p4.y), __uint_as_float(p4.z), __uint_as_float(p4.w)};
         uint32_t vr[4];
@@ -345,9 +348,19 @@ __device__ __forceinline__ void dp_attention_head(const dp_lu4* qb, const dp_lu4
 __device__ __forceinline__ void dp_attention_wave(char* lds, int wave, int l, int cb, int lane) {
     dp_lu32* misc = (dp_lu32*)(lds + DP_OFF_MISC);
     const int kvh = wave >> 2;
-    dp_attention_head((const dp_lu4*)(lds + DP_OFF_QB), (const dp_lu4*)(lds + DP_OFF_K + ((l * 2 + kvh) * 32) * 256),
-                      (const dp_lu32*)(lds + DP_OFF_V + ((l * 2 + kvh) * 32) * 256), (dp_lf32*)(lds + DP_OFF_PS) + wave * 32,
-                      (dp_lu32*)(lds + DP_OFF_ATT), wave, cb + 1, 0.08838834764831845f, lane);
+    const dp_lu4* qb = (const dp_lu4*)(lds + DP_OFF_QB);
+    const dp_lu4* kt = (const dp_lu4*)(lds + DP_OFF_K + ((l * 2 + kvh) * 32) * 256);
+    const dp_lu32* vt = (const dp_lu32*)(lds + DP_OFF_V + ((l * 2 + kvh) * 32) * 256);
+    dp_lf32* ps = (dp_lf32*)(lds + DP_OFF_PS) + wave * 32;
+    dp_lu32* att = (dp_lu32*)(lds + DP_OFF_ATT);
+#ifdef DP_ATTN_GROUPS
+    // the step's cb + 1 live keys sit in the first ceil((cb + 1) / 4) groups: walk 1 / 2 / 4 / 8 of them (uniform branch; same bits, see dp_attention_head)
+    if (cb < 4) dp_attention_head<1>(qb, kt, vt, ps, att, wave, cb + 1, 0.08838834764831845f, lane);
+    else if (cb < 8) dp_attention_head<2>(qb, kt, vt, ps, att, wave, cb + 1, 0.08838834764831845f, lane);
+    else if (cb < 16) dp_attention_head<4>(qb, kt, vt, ps, att, wave, cb + 1, 0.08838834764831845f, lane);
+    else
+#endif
+    dp_attention_head<8>(qb, kt, vt, ps, att, wave, cb + 1, 0.08838834764831845f, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(misc + DP_M_ATTN, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
