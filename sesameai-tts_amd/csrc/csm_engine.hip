@@ -876,6 +876,9 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
     for (int cb = 0; cb < ncb; ++cb) {
         GemvArgs a;
         if (cb == 2 && persist_usable(m, B)) return launch_dec_persist(m, B, temperature, topk, forced, logits_out, noise, st, rng);
+        // codebook 1 at batch 1: the four layers on both rows AND the head as ONE launch (dec_first.cuh): the K / V of positions 0, 1 and the logits
+        // row are left where the chain's step leaves them
+        const bool one_launch = cb == 1 && first_usable(m, B);
         if (cb >= 1) {
             const int rows = cb == 1 ? 2 * B : B;
             if (cb == 1) {
@@ -888,22 +891,21 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
                 else e = launch_gemv(0, dbb, 0, a, st);
                 if (e != hipSuccess) return e;
             }
-            if (cb == 1 && first_usable(m, B)) {
-                // the four layers on both rows AND the head of codebook 1 as ONE launch (dec_first.cuh): K / V of positions 0, 1 and the logits row
-                // are left where the chain's step left them
+            if (one_launch) {
                 if ((e = launch_dec_first(m, st)) != hipSuccess) return e;
-                goto head_done;
+            } else {
+                // decoder positions are static per step: rows (0,1) on the first call, then cb
+                const int* pos = m->dec_pos + (long)(cb == 1 ? 0 : cb) * 2 * m->max_batch;
+                // cb >= 2 on the wide path: the previous sampler already wrote sa_norm(row) into attd
+                const bool wide_next = B >= m->wide_min && m->wide_path;
+                const bool qkv0_done = cb >= 2 && m->qkv0_tab != nullptr;
+                const bool x_normed = cb >= 2 && wide_next && !qkv0_done;
+                if ((e = run_stack(m, m->dec, m->hdec, m->qd, m->attd, m->actd, rows, cb == 1 ? 2 : 1, pos, cb == 1 ? 0 : cb, st, false, x_normed,
+                                   qkv0_done)) != hipSuccess) return e;
             }
-            // decoder positions are static per step: rows (0,1) on the first call, then cb
-            const int* pos = m->dec_pos + (long)(cb == 1 ? 0 : cb) * 2 * m->max_batch;
-            // cb >= 2 on the wide path: the previous sampler already wrote sa_norm(row) into attd
-            const bool wide_next = B >= m->wide_min && m->wide_path;
-            const bool qkv0_done = cb >= 2 && m->qkv0_tab != nullptr;
-            const bool x_normed = cb >= 2 && wide_next && !qkv0_done;
-            if ((e = run_stack(m, m->dec, m->hdec, m->qd, m->attd, m->actd, rows, cb == 1 ? 2 : 1, pos, cb == 1 ? 0 : cb, st, false, x_normed,
-                               qkv0_done)) != hipSuccess) return e;
         }
         // final RMSNorm + head -> logits (bf16, padded rows)
+        if (!one_launch) {
         memset(&a, 0, sizeof a);
         if (cb == 0) {
             a.x = m->h; a.x_row_stride = (long)S * dbb; a.x_row_offset = (long)(S - 1) * dbb;
@@ -936,7 +938,7 @@ static hipError_t run_depth(CsmModel* m, int B, int S, float temperature, int to
             else { a.w0 = (const bf16_t*)((const char*)m->w.audio_head8 + (long)(cb - 1) * V * dd); a.s0 = (const float*)m->w.audio_head8s + (long)(cb - 1) * V; }
             if ((e = launch_gemv8(2, cb == 0 ? dbb : dd, 0, a, st)) != hipSuccess) return e;
         } else if ((e = launch_gemv(2, cb == 0 ? dbb : dd, 0, a, st)) != hipSuccess) return e;
-    head_done:
+        }
         if (logits_out) {
             e = hipMemcpy2DAsync((char*)logits_out + (size_t)cb * B * V * 2, (size_t)V * 2, m->logits, (size_t)m->ldl * 2,
                                  (size_t)V * 2, B, hipMemcpyDeviceToDevice, st);

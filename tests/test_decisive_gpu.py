@@ -349,7 +349,7 @@ def test_copy_checkpoint_free_running_codes_come_out_of_the_kv_cache(copy_ckpt, 
         n = want.shape[0]
         assert n >= 32 and tok.shape[0] == int(g["prompt_rows"]) and bool((g["faults_changed"] > 0).all())
         m = _fresh_model(sd, dtype, 1)
-        assert m.fast_paths() & 1 and m.fast_paths() & (8 if dtype == "bf16" else 16), "the persistent decoder / one-launch backbone layer did not run"
+        assert m.fast_paths() & 1 and m.fast_paths() & (8 if dtype == "bf16" else 16) and m.fast_paths() & 32, "the persistent decoder launches / one-launch backbone layer did not run"
         gen = _generator(m)
         frames = gen.generate_codes(tok, msk, n, 1.0, 1)[:, 0]
         assert torch.equal(frames, want), f"{dtype} {name}: free-running greedy codes leave the oracle's at frame {int((frames != want).any(dim=1).nonzero()[0])}"

@@ -1874,6 +1874,48 @@ def test_persistent_launch_gives_up_instead_of_hanging_and_the_handle_recovers(t
         assert "RECOVERED" in out and "NOT_RECOVERED" not in out, f"keep={keep}: the handle did not recover:\n{out}\n{r.stderr[-2000:]}"
 
 
+def test_first_decoder_step_as_one_launch_vs_its_launch_chain(csm1b, monkeypatch):
+    """Codebook 1 -- the decoder's first step, positions 0 and 1 -- as ONE all-CU launch (csrc/dec_first.cuh, round 6) against the 16 launches of
+    the M = 2 chain + the head GEMV it replaces (CSM_DEC_FIRST=0), the persistent launch for codebooks 2..31 on both sides.  Same rounding points,
+    different fp32 summation orders (gate/up on the matrix cores, the down projection split over 256 column slices): codebook 0 bit-identical,
+    codebook 1's logits and -- through the K / V rows of positions 0, 1 that the launch files in the decoder caches -- every later codebook's
+    within the oracle's own bf16-vs-fp32 gap; greedy picks may differ only at near-ties; and the launch is deterministic."""
+    from sesameai.models import Model, csm_1b_args
+    gold, sd = csm1b
+    tok, msk = gold["prompt_tokens"], gold["prompt_mask"]
+    S = tok.shape[0]
+    noise = float(gold["bf16_vs_fp32_gap"].max())
+    outs = {}
+    for name, env in (("one launch", "1"), ("chain", "0")):
+        monkeypatch.setenv("CSM_DEC_FIRST", env)
+        m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=256)
+        m.setup_caches(1)
+        assert bool(m.fast_paths() & 32) == (env == "1") and m.fast_paths() & 1
+        m.prefill(tok.unsqueeze(0), msk.unsqueeze(0), torch.arange(S).unsqueeze(0))
+        res = []
+        for f in range(3):
+            out, logits = m.depth(1, 1.0, 1, forced=gold["codes"][f].unsqueeze(0), want_logits=True, commit=False)
+            out2, logits2 = m.depth(1, 1.0, 1, forced=gold["codes"][f].unsqueeze(0), want_logits=True, commit=False)
+            assert torch.equal(logits, logits2) and torch.equal(out, out2), "not deterministic"
+            res.append((out.cpu(), logits[:, 0].float().cpu()))
+            row = torch.zeros(1, 1, 33, dtype=torch.long); row[0, 0, :32] = gold["codes"][f].long()
+            rmask = torch.ones(1, 1, 33, dtype=torch.bool); rmask[0, 0, 32] = False
+            m.prefill(row, rmask, torch.tensor([[S + f]]))
+        outs[name] = res
+        del m
+    worst1 = worst = 0.0
+    for (oa, la), (ob, lb) in zip(outs["one launch"], outs["chain"]):
+        assert torch.equal(la[0], lb[0]), "codebook 0 is the backbone's head on both sides"
+        worst1 = max(worst1, (la[1] - lb[1]).abs().max().item())
+        worst = max(worst, (la - lb).abs().max().item())
+        top2 = torch.topk(lb, 2, dim=-1)[0]
+        for cb in (oa[0] != ob[0]).nonzero().flatten().tolist():
+            _excuse(float(top2[cb, 0] - top2[cb, 1]), noise, f"codebook {cb}: greedy index differs away from a tie")
+    print(f"first decoder step, one launch vs chain: max|dlogit| codebook 1 = {worst1:.4f}, any codebook = {worst:.4f} (oracle noise floor {noise:.4f})")
+    assert worst1 > 0.0, "both runs took the same path"
+    assert worst <= noise
+
+
 def test_backbone_attention_block_vs_launch_chain(csm1b, monkeypatch):
     """Batch-1 decode steps run q|k|v -> attention -> o-projection of every backbone layer as ONE launch
     (csrc/bb_block.cuh) instead of three.  Same rounding points, different fp32 summation orders (per-wave RMSNorm sums,

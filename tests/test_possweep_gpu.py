@@ -1,6 +1,6 @@
-"""Position coverage, at CSM-1B shapes, of the two kernels that carry 94 % of a B = 1 frame (VERDICT r5 missing #3): `k_bb_layer<false|true>`
+"""Position coverage, at CSM-1B shapes, of the kernels that carry 97 % of a B = 1 frame (VERDICT r5 missing #3): `k_bb_layer<false|true>`
 (one backbone layer of a decode step per launch; csrc/bb_block.cuh switches from one CU per head to the key range split over 8 CUs at
-768 keys) and `k_dec_persist` exist only for the CSM-1B shape, so no tiny-shape test reaches them, and until round 5 their logits were
+768 keys), `k_dec_persist` (codebooks 2..31) and, round 6, `k_dec_first` (codebook 1) exist only for the CSM-1B shape, so no tiny-shape test reaches them, and until round 5 their logits were
 compared with the oracle at about ten positions.  Reference arithmetic: sesameai/models.py:154-158 (backbone step over the position-indexed
 cache), :160-182 (depth decoder).
 
@@ -88,6 +88,7 @@ def test_logits_and_picks_across_positions_and_the_key_split_switch(sweep, dtype
     m.setup_caches(1)
     assert m.fast_paths() & 1, "the persistent depth decoder (k_dec_persist) is not in charge"
     assert m.fast_paths() & (8 if dtype == "bf16" else 16), "the one-launch backbone layer (k_bb_layer) is not in charge"
+    assert m.fast_paths() & 32, "the one-launch first decoder step (k_dec_first) is not in charge"
     stats = dict(worst=0.0, excused=[], rows=0, graph_rows=0)
     tie_noise = _sweep_gap(G)
     for g in G["per_size"]:
@@ -123,7 +124,7 @@ def test_64_consecutive_steps_across_the_key_split_switch(sweep, dtype):
     noise = float(g["bf16_vs_fp32_gap"].max())
     m = Model(csm_1b_args(), sd, max_frames=80, max_prefill_rows=2048, weights_dtype=dtype)
     m.setup_caches(1)
-    assert m.fast_paths() & 1 and m.fast_paths() & (8 if dtype == "bf16" else 16)
+    assert m.fast_paths() & 1 and m.fast_paths() & (8 if dtype == "bf16" else 16) and m.fast_paths() & 32
     stats = dict(worst=0.0, excused=[], rows=0, graph_rows=0)
     tie_noise = _sweep_gap(gold[dtype])
     m.prefill_prompt(tok[:S].unsqueeze(0), msk[:S].unsqueeze(0))
