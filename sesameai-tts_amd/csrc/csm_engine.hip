@@ -100,7 +100,7 @@ struct CsmModel {
     uint32_t* p_state;                  // [0] tag epoch, [1] give-up code of the last launch (0 = ok), [2] tag epoch of the first-step launch
     // the first decoder step (codebook 1: positions 0, 1) of a batch-1 frame as one launch (dec_first.cuh; env CSM_DEC_FIRST=0 disables)
     bool dec_first;
-    dp_u64 *fg_q, *fg_h1, *fg_h2, *fg_l, *fg_p;
+    dp_u64 *fg_q, *fg_h1, *fg_h2, *fg_p;
     // backbone attention block of a batch-1 decode step as one launch per layer (bb_block.cuh)
     bool bb_block;
     dp_u64 *bg_q, *bg_a, *bg_s;
@@ -860,7 +860,7 @@ static hipError_t launch_dec_first(CsmModel* m, hipStream_t st) {
     p.dec_norm = (const bf16_t*)m->w.dec_norm; p.head_t = (const bf16_t*)m->w.audio_head_t; p.rope = m->dec.rope;
     p.hdec = m->hdec; p.kc = m->dec.kc; p.vc = m->dec.vc; p.kv_layer_stride = m->dec.layer_stride;
     p.V = m->cfg.audio_vocab; p.logits = m->logits;
-    p.gQ = m->fg_q; p.gH1 = m->fg_h1; p.gH2 = m->fg_h2; p.gL = m->fg_l; p.gP = m->fg_p;
+    p.gQ = m->fg_q; p.gH1 = m->fg_h1; p.gH2 = m->fg_h2; p.gP = m->fg_p;
     p.err = m->p_state + 1; p.epoch = m->p_state + 2; p.eps = m->cfg.decoder.norm_eps; p.trickle_sleep = m->p_trickle; p.poll_sleep = m->p_poll;
     return csm_launch_dec_first(p, st);
 }
@@ -1216,7 +1216,7 @@ static void setup_persist(CsmModel* m) {
         if (!(evf && evf[0] == '0') && all_cu_launch_fits(csm_dec_first_kernel(), DF_LDS_BYTES, "first depth-decoder step")) {
             OptAllocs F;
             F.small(m, &m->fg_q, (size_t)DP_NREP * 1536 * 8); F.small(m, &m->fg_h1, (size_t)DP_NREP * 1024 * 8); F.small(m, &m->fg_h2, (size_t)DP_NREP * 1024 * 8);
-            F.small(m, &m->fg_l, (size_t)DP_NREP * DP_LSLOTS * 8); F.get(&m->fg_p, (size_t)2 * 256 * 1024 * 8);
+            F.get(&m->fg_p, (size_t)2 * 256 * 1024 * 8);
             if (!F.ok) { F.drop(); note_fallback("first depth-decoder step", "allocation failed"); }
             else { m->dec_first = true; m->persist_allocs.insert(m->persist_allocs.end(), F.ptrs.begin(), F.ptrs.end()); }
         }

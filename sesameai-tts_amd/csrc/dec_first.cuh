@@ -9,7 +9,8 @@
 // instruction caches.  This kernel runs once per frame: nothing in it is trickled across steps.
 //
 // What it leaves behind is what the chain's cb = 1 step left: the decoder K / V caches of positions 0, 1 for every layer (global), and
-// the logits of codebook 1 in the engine's logits row; k_sample then picks c1 and gathers the next step's table rows as before.
+// the logits of codebook 1 in the engine's logits row (written by the head units themselves: no logits all-gather -- nothing in this launch
+// samples); k_sample then picks c1 and gathers the next step's table rows as before.
 //
 // Per layer, with r = 0, 1 the two rows (positions):  x[r] = sa_norm(h[r]) -> q|k|v units (RoPE at position r) -> all-gather ->
 // attention of row r over keys 0..r (replicated on every workgroup, eight heads on eight waves) -> o-proj units + residual -> all-gather
@@ -32,7 +33,7 @@ struct DecFirstArgs {
     long kv_layer_stride;
     int V;
     bf16_t* logits;                   // [>= V + 1] bf16: the logits of codebook 1
-    dp_u64 *gQ, *gH1, *gH2, *gL, *gP; // granule slots: 8 x 2*768, 8 x 2*512, 8 x 2*512, 8 x 1088, 2 x 256 x 1024
+    dp_u64 *gQ, *gH1, *gH2, *gP;      // granule slots: 8 x 2*768, 8 x 2*512, 8 x 2*512, 2 x 256 x 1024
     uint32_t* err;
     uint32_t* epoch;
     float eps;
@@ -266,7 +267,9 @@ __device__ __forceinline__ void df_compute_wave(const DecFirstArgs& a, char* lds
         float a0 = dot8(r00, x0, 0.f); a0 = dot8(r01, x1, a0);
         float a1 = dot8(r10, x0, 0.f); a1 = dot8(r11, x1, a1);
         a0 = wave_sum(a0); a1 = wave_sum(a1);
-        if (lane < DP_NREP) dp_gran_store(a.gL + lane * DP_LSLOTS + hunit, df_tag(base, DP_NL, DF_E_Q), pack_bf(a0, a1));
+        // straight into the engine's logits row: the launch boundary in front of k_sample is the hand-off (k_dec_persist all-gathers its logits
+        // because it samples in the launch); the odd vocabulary's last unit carries one logit, its second half reads as 0
+        if (lane == 0) reinterpret_cast<uint32_t*>(a.logits)[hunit] = (2 * hunit + 1 < a.V) ? pack_bf(a0, a1) : (pack_bf(a0, a1) & 0xffffu);
     }
 }
 
@@ -293,7 +296,7 @@ static __global__ __launch_bounds__(512) void k_dec_first(const DecFirstArgs a) 
         // ------------------------------------------------------------------------------------------------ gather wave
         __builtin_amdgcn_s_setprio(2);
         const int rep = cu % DP_NREP, ln = (int)lane;
-        const dp_u64 *rgQ = a.gQ + rep * 1536, *rgH1 = a.gH1 + rep * 1024, *rgH2 = a.gH2 + rep * 1024, *rgL = a.gL + rep * DP_LSLOTS;
+        const dp_u64 *rgQ = a.gQ + rep * 1536, *rgH1 = a.gH1 + rep * 1024, *rgH2 = a.gH2 + rep * 1024;
         const dp_u64* rgP = a.gP + (long)cu * 1024;
         for (int l = 0; l < DP_NL; ++l) {
             {   // rows entering the layer -> sa_norm -> xA (layer 0: the decoder's input rows from memory)
@@ -379,19 +382,7 @@ static __global__ __launch_bounds__(512) void k_dec_first(const DecFirstArgs a) 
             dp_norm_in_lds((dp_lu4*)xw, g0, g1, a.eps, ln);
             dp_flag((dp_lvu32*)(misc + DF_M_FXA), df_tag(base, DP_NL, DF_E_XA));
         }
-        if (cu == 0) {   // the logits of codebook 1 -> the engine's logits row (k_sample reads it)
-            uint32_t v[18];
-            const int ng = (a.V + 1) / 2;
-            if (!dp_sweep<9>(rgL, ng, df_tag(base, DP_NL, DF_E_Q), v, ln, ab, a.err, 0xB50u, a.poll_sleep)) return;
-            uint32_t* lg = reinterpret_cast<uint32_t*>(a.logits);
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const int g0 = 2 * (j * 64 + ln);
-                if (g0 < ng) lg[g0] = (g0 == ng - 1 && (a.V & 1)) ? (v[2 * j] & 0xffffu) : v[2 * j];
-                if (g0 + 1 < ng) lg[g0 + 1] = (g0 + 1 == ng - 1 && (a.V & 1)) ? (v[2 * j + 1] & 0xffffu) : v[2 * j + 1];
-            }
-            if (lane == 0) __hip_atomic_store(a.epoch, base + DF_EPOCH_STEP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (cu == 0 && lane == 0) __hip_atomic_store(a.epoch, base + DF_EPOCH_STEP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     if (wave < 4) df_compute_wave<true, 2>(a, lds, wave, lane, cu, base, ropev);
