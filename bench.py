@@ -123,12 +123,12 @@ def log(msg):
 def dominant_kernels(model, B, temperature, topk, reps=20):
     """The launches that carry the timed frame step, timed live (HIP events on the launching stream, back-to-back launches on
     the handle's current state; include/csm_hip_ops.h csm_debug_time_kernels): the persistent depth-decoder launch (codebooks
-    2..31 of a frame: csrc/dec_persist.cuh at B = 1, csrc/dec_persist_m.cuh at B = 2..32) and, at B = 1, the one-launch backbone
-    layer (csrc/bb_block.cuh).  bytes = weight bytes the launch streams; the decoder's come from the Infinity Cache after the first
+    2..31 of a frame: csrc/dec_persist.cuh at B = 1, csrc/dec_persist_m.cuh at B = 2..32) and, at B = 1, the first decoder step as one
+    launch (codebook 1: csrc/dec_first.cuh) and the one-launch backbone layer (csrc/bb_block.cuh).  bytes = weight bytes the launch streams; the decoder's come from the Infinity Cache after the first
     step (30 x 226 MB per launch, 222 MB of decoder layers resident), so its rate is not an HBM rate."""
     import ctypes as C
     from sesameai import _abi
-    out = (C.c_double * 4)()
+    out = (C.c_double * 6)()
     st = torch.cuda.current_stream().cuda_stream
     with torch.cuda.device(model.device):
         _abi.check(_abi.lib.csm_debug_time_kernels(model._h, B, reps, float(temperature), int(topk), out, st), model._h)
@@ -139,6 +139,10 @@ def dominant_kernels(model, B, temperature, topk, reps=20):
                     "launches_per_frame": 1, "bytes_streamed_per_launch": out[1], "avg_us": round(out[0], 1),
                     "streamed_GBps": round(out[1] / out[0] / 1e3, 1), "us_per_decoder_step": round(out[0] / 30.0, 2),
                     "bound": "cross-workgroup hand-off latency (see DESIGN.md); bytes come from the 256 MB Infinity Cache"})
+    if out[4] == out[4]:
+        res.append({"kernel": "k_dec_first", "does": "codebook 1 of a frame: the decoder's first step, positions 0 and 1 (4 layers on two rows + the head) in one launch",
+                    "launches_per_frame": 1, "bytes_streamed_per_launch": out[5], "avg_us": round(out[4], 1), "streamed_GBps": round(out[5] / out[4] / 1e3, 1),
+                    "bound": "cross-workgroup hand-off latency, two rows per hand-off (csrc/dec_first.cuh)"})
     if out[2] == out[2]:
         res.append({"kernel": "k_bb_layer", "does": "one backbone layer of a B = 1 decode step (attention block + MLP) in one launch",
                     "launches_per_frame": 16, "bytes_per_launch": out[3], "avg_us": round(out[2], 2),

@@ -69,8 +69,10 @@ int csm_debug_graph_captures(csm_handle h);
  * csrc/dec_persist_m.cuh at B = 2..32 -- and (b) a batch-1 backbone decode step (16 one-launch layers, csrc/bb_block.cuh),
  * each between HIP events on `stream`.  out[0] = avg us per decoder launch (NaN if the launch chain is in charge),
  * out[1] = weight bytes it streams per launch, out[2] = avg us per backbone layer launch (NaN unless B == 1 and the
- * one-launch layer is active), out[3] = weight bytes of one backbone layer.  Clobbers the current frame's codes.          */
-int csm_debug_time_kernels(csm_handle h, int B, int reps, float temperature, int topk, double* out /*[4] host*/, void* stream);
+ * one-launch layer is active), out[3] = weight bytes of one backbone layer, out[4] = avg us of the first decoder step as one
+ * launch (csrc/dec_first.cuh; NaN unless B == 1 and it is in charge), out[5] = the weight bytes it streams.  Clobbers the current
+ * frame's codes.                                                                                                              */
+int csm_debug_time_kernels(csm_handle h, int B, int reps, float temperature, int topk, double* out /*[6] host*/, void* stream);
 
 #ifdef __cplusplus
 }

@@ -2028,6 +2028,17 @@ extern "C" int csm_debug_time_kernels(csm_handle m, int B, int reps, float tempe
         HIPCHK(m, hipEventElapsedTime(&ms, e0, e1));
         out[0] = ms * 1e3 / reps;
     }
+    out[4] = nan_;
+    out[5] = c.decoder.n_layers * layer_bytes(c.decoder) + 2.0 * c.audio_vocab * c.decoder.dim;
+    if (first_usable(m, B)) {
+        HIPCHK(m, launch_dec_first(m, st));
+        HIPCHK(m, hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) HIPCHK(m, launch_dec_first(m, st));
+        HIPCHK(m, hipEventRecord(e1, st));
+        HIPCHK(m, hipEventSynchronize(e1));
+        HIPCHK(m, hipEventElapsedTime(&ms, e0, e1));
+        out[4] = ms * 1e3 / reps;
+    }
     if (B == 1 && (m->bb_layer || m->bb_layer8) && !m->bb_disabled) {
         HIPCHK(m, run_stack(m, m->bb, m->h, m->q, m->att, m->act, 1, 1, m->cur_pos, -1, st));
         HIPCHK(m, hipEventRecord(e0, st));

@@ -150,9 +150,10 @@ def test_single_gpu_line_names_the_kernels_it_timed():
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
     names = [k["kernel"] for k in d["roofline"]["dominant_kernels"]]
-    assert names == ["k_dec_persist", "k_bb_layer"], names
+    assert names == ["k_dec_persist", "k_dec_first", "k_bb_layer"], names
     dk = d["roofline"]["dominant_kernels"]
-    assert 16 * dk[1]["avg_us"] * 1e-3 + dk[0]["avg_us"] * 1e-3 < d["ms_per_step"], "the dominant kernels take longer than the frame they are part of"
+    assert 16 * dk[2]["avg_us"] * 1e-3 + dk[1]["avg_us"] * 1e-3 + dk[0]["avg_us"] * 1e-3 < d["ms_per_step"], "the dominant kernels take longer than the frame they are part of"
+    assert "k_dec_first (codebook 1) + k_dec_persist" in d["config"]["paths"]
     ex = d["extras"]
     for k in ("config3", "reference_loop", "b1_long_context", "config5", "config5_b32"):
         assert k in ex, k
