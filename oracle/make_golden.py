@@ -456,6 +456,36 @@ def main():
             many.append(g["codes"][:, 0].clone())
         gold["bf16_many"] = many
         torch.save(gold, path)
+    if a.only == "cfg4":
+        # BASELINE config 4 = batch 256 sharded over 8 GPUs: 32 utterances per rank, rank r's prompts are bench.py's seeds 4000 + 32 r .. (batch32_leg).
+        # No 8-GPU node has been available to this build; what CAN be checked on one GPU is that a shard -- here the LAST rank's, seeds 4224..4255 --
+        # computes what the batched oracle computes for those prompts: top-8 logits / codes / margins of 2 teacher-forced frames + the bf16-vs-fp32 gap.
+        shape = C.csm_1b()
+        w = C.make_weights(shape, seed=1234)
+        rank, seed0 = 7, 4000 + 32 * 7
+        ps = [bench_prompt(shape, seed0 + b) for b in range(32)]
+        toks, msks = torch.stack([p[0] for p in ps]), torch.stack([p[1] for p in ps])
+        gold = frames_golden_batch(shape, w, toks, msks, 2)
+        B = 32
+        gaps = []
+        with torch.inference_mode():
+            m32 = C.OracleModel(shape, {k: v.float() for k, v in w.items()}, dtype=torch.float32); m32.setup_caches(B)
+            cur_t, cur_m = toks, msks
+            pos = torch.arange(toks.size(1)).unsqueeze(0).repeat(B, 1)
+            mb = C.OracleModel(shape, w); mb.setup_caches(B)
+            for f in range(2):
+                tr, tr32 = C.FrameTrace(), C.FrameTrace()
+                s_ = mb.generate_frame(cur_t, cur_m, pos, 1.0, 1, greedy=True, trace=tr)
+                assert torch.equal(s_, gold["codes"][f])
+                m32.generate_frame(cur_t, cur_m, pos, 1.0, 1, greedy=True, forced=s_, trace=tr32)
+                gaps.append((torch.stack(tr.logits, 0).float() - torch.stack(tr32.logits, 0)).abs().max(dim=-1)[0])
+                cur_t = torch.cat([s_.long(), torch.zeros(B, 1).long()], dim=1).unsqueeze(1)
+                cur_m = torch.cat([torch.ones_like(s_).bool(), torch.zeros(B, 1).bool()], dim=1).unsqueeze(1)
+                pos = pos[:, -1:] + 1
+        gold["bf16_vs_fp32_gap"] = torch.stack(gaps)
+        gold.update(weight_seed=1234, rank=rank, prompt_seed=seed0, prompt_checksum=gold["prompt_tokens"].sum(dim=(1, 2)))
+        del gold["prompt_tokens"], gold["prompt_mask"]
+        torch.save(gold, os.path.join(OUT, "csm1b_cfg4_rank7.pt"))
     if want("possweep"):
         shape = C.csm_1b()
         w = C.make_weights(shape, seed=1234)

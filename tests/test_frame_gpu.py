@@ -1495,6 +1495,55 @@ def test_csm1b_config5_batch32_fp8_long_context_vs_golden(csm1b):
     assert len(bad) <= 0.08 * B * 32 and n_cmp >= B * 8
 
 
+def test_csm1b_config4_one_shard_vs_golden(csm1b):
+    """BASELINE config 4 = batch 256 sharded over 8 GPUs, 32 utterances per rank, no per-step collective: rank r runs bench.py's prompts of seeds
+    4000 + 32 r .. (`batch32_leg`).  No 8-GPU node has been available to this build (the N > 1 control flow is rehearsed in
+    tests/test_bench_contract_gpu.py); what one GPU CAN show is that a shard computes what the batched oracle computes for ITS prompts --
+    here the last rank's, seeds 4224..4255 (tests/golden/csm1b_cfg4_rank7.pt: top-8 logits, codes, margins of 2 teacher-forced frames, the
+    oracle's bf16-vs-fp32 gap on those 2,048 rows): prefill of 32 x 190 rows, frame 0, the replayed graph step."""
+    import bench
+    from oracle import csm_ref as C
+    from sesameai.models import Model, csm_1b_args
+    _, sd = csm1b
+    path = os.path.join(GOLD, "csm1b_cfg4_rank7.pt")
+    if not os.path.exists(path):
+        pytest.skip("csm1b_cfg4_rank7 golden not generated (oracle/make_golden.py --only cfg4)")
+    gold = torch.load(path)
+    g2 = torch.load(os.path.join(GOLD, "csm1b_cfg2.pt"))
+    noise = float(g2["bf16_vs_fp32_gap"].max())                         # per-row near-tie scale (one utterance)
+    noise32 = float(gold["bf16_vs_fp32_gap"].max())                     # the oracle's gap on THESE 2,048 rows
+    B = 32
+    assert int(gold["prompt_seed"]) == 4000 + 32 * int(gold["rank"])
+    tok, msk = bench.synthetic_prompt(_bench_args(), B, C.csm_1b().text_vocab_size, seed0=int(gold["prompt_seed"]))
+    S = tok.shape[1]
+    assert S == 190 and torch.equal(tok.sum(dim=(1, 2)), gold["prompt_checksum"]), "these are not the golden's prompts"
+    m = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S)
+    m.setup_caches(B)
+    assert m.fast_paths() & 2, "the batched persistent decoder must be on this path"
+    m.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+    codes0 = gold["codes"][0]
+    out, logits = m.depth(B, 1.0, 1, forced=codes0, want_logits=True, commit=True)
+    d0 = (torch.gather(logits.float().cpu(), 2, gold["top_i"][0].long()) - gold["top_v"][0].float()).abs().max().item()
+    bad = (out.cpu() != codes0).nonzero()
+    for b, cb in bad.tolist():
+        _excuse(float(gold["margin"][0][cb, b]), noise, f"frame 0 utterance {b} codebook {cb}", tie=BATCH32_TIE)
+    row = torch.zeros(B, 1, 33, dtype=torch.long); row[:, 0, :32] = codes0.long()
+    rmask = torch.ones(B, 1, 33, dtype=torch.bool); rmask[:, 0, 32] = False
+    got = m.generate_frame(row, rmask, torch.full((B, 1), S), 1.0, 1).cpu()
+    n_cmp = sum(_same_until_a_near_tie(got[b], gold["codes"][1][b], gold["margin"][1][:, b], noise, f"graph step, utterance {b}", tie=BATCH32_TIE) for b in range(B))
+    del m
+    m2 = Model(csm_1b_args(), sd, max_frames=16, max_prefill_rows=B * S)
+    m2.setup_caches(B)
+    m2.prefill(tok, msk, torch.arange(S).unsqueeze(0).repeat(B, 1))
+    m2.prefill(row, rmask, torch.full((B, 1), S))
+    out1, logits1 = m2.depth(B, 1.0, 1, forced=gold["codes"][1], want_logits=True, commit=False)
+    d1 = (torch.gather(logits1.float().cpu(), 2, gold["top_i"][1].long()) - gold["top_v"][1].float()).abs().max().item()
+    print(f"config 4, rank {int(gold['rank'])}'s shard (B=32, seeds {int(gold['prompt_seed'])}..): max|dlogit| frame 0 {d0:.4f}, frame 1 {d1:.4f} (the oracle's gap on these rows "
+          f"{noise32:.4f}); {len(bad)} of {B * 32} greedy rows excused; {n_cmp} of {B * 32} graph-step decisions compared")
+    assert max(d0, d1) <= noise32
+    assert len(bad) <= 0.08 * B * 32 and n_cmp >= B * 8
+
+
 def test_csm1b_prompt_to_pcm_composed_on_the_bench_checkpoint(csm1b):
     """The composed path on the N(0, 0.02^2) BENCH checkpoint: BASELINE config 2's prompt given as the reference gives it (a voice-prompt
     Segment + the text to speak) -> Generator.generate (prompt assembly, prefill, hipGraph frame loop, Mimi decode on the GPU), greedy, 10
