@@ -394,6 +394,32 @@ def test_copy_checkpoint_config3_batch32_graph_loop(copy_ckpt, dtype):
     assert m.fast_paths() & 2, "the batched persistent decoder did not run"
 
 
+def test_copy_checkpoint_through_generate_and_generate_stream(copy_ckpt):
+    """The two reference surfaces (generator.py:119-300) on the copy checkpoint, from Segments + text: `generate` returns the Mimi decode of the
+    oracle's 64 frames (within PCM_TOL x peak of the HIP codec's decode of the golden codes: the codec's own parity is tests/test_mimi_gpu.py's),
+    and the frames behind `generate_stream`'s chunks are the oracle's."""
+    gold, get = copy_ckpt
+    sd = get(gold["flavours"]["s190"])
+    tok, msk = _prompts(128_256)["s190"]
+    want = gold["bf16_s190"]["codes"][:, 0].to(torch.int32)
+    n = want.shape[0]
+    codec = _codec()
+    gen = _generator(_fresh_model(sd, "bf16", 1), codec)
+    ctx, text = _as_segments(tok, 1, 40, 125)
+    pt, pm = gen._build_prompt(text, 1, ctx)
+    assert torch.equal(pt.cpu(), tok) and torch.equal(pm.cpu(), msk)
+    pcm = gen.generate(text, 1, ctx, max_audio_length_ms=n * 80, temperature=1.0, topk=1).cpu()
+    ref = codec.decode(want.t().unsqueeze(0).contiguous().cuda())[0, 0].cpu()
+    assert pcm.shape == ref.shape == (n * 1920,)
+    assert float((pcm - ref).abs().max()) <= PCM_TOL * float(ref.abs().max())
+    seen = []
+    inner = gen._decode_frames
+    gen._decode_frames = lambda fr: (seen.append(fr.clone().cpu()), inner(fr))[1]
+    chunks = [c.cpu() for c in gen.generate_stream(text, 1, ctx, max_audio_length_ms=n * 80, temperature=1.0, topk=1)]
+    assert torch.equal(torch.cat(seen)[:, 0], want), "the frames behind the streamed chunks differ from the oracle's"
+    assert sum(c.shape[0] for c in chunks) == n * 1920
+
+
 @pytest.mark.parametrize("beside", [True, False])
 def test_copy_checkpoint_refilled_batch_of_8(copy_ckpt, beside):
     """Twelve utterances of mixed prompt lengths and length limits through 8 slots that are kept full, on the copy checkpoint: a refill writes a
